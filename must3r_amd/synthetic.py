@@ -1,0 +1,93 @@
+"""Seeded random-init weights and inputs with the reference's state-dict contract.
+
+No checkpoint can be fetched (no network), so tests and ``bench.py`` run on weights drawn the way the
+reference initialises them (``BaseTransformer._init_weights`` must3r/model/blocks/layers.py:23-33:
+xavier-uniform Linear weights, LayerNorm 1/0; ``image2_embed ~ N(0, .02)`` decoder.py:52; Conv2d
+default init for ``patch_embed.proj``) with three deliberate departures so that parity tests exercise
+every term: biases and LayerNorm affine parameters are perturbed instead of exactly 0/1, and
+``feedback_layer.fc2`` is non-zero (the reference zero-inits it, feedback_mechanism.py:26-36, which
+would make the feedback path a no-op).
+
+The key set / shapes are exactly those of SURVEY.md section 8b so that the reference modules accept
+the dicts with ``load_state_dict(strict=True)``.
+"""
+import math
+
+import torch
+
+from .config import ModelConfig
+
+
+def _xavier(g, out_f, in_f):
+    bound = math.sqrt(6.0 / (in_f + out_f))
+    return (torch.rand((out_f, in_f), generator=g) * 2 - 1) * bound
+
+
+def _bias(g, n, std=0.02):
+    return torch.randn((n,), generator=g) * std
+
+
+def _ln(g, sd, prefix, dim):
+    sd[prefix + ".weight"] = 1.0 + torch.randn((dim,), generator=g) * 0.05
+    sd[prefix + ".bias"] = torch.randn((dim,), generator=g) * 0.02
+
+
+def _linear(g, sd, prefix, out_f, in_f):
+    sd[prefix + ".weight"] = _xavier(g, out_f, in_f)
+    sd[prefix + ".bias"] = _bias(g, out_f)
+
+
+def make_encoder_state_dict(cfg: ModelConfig, seed: int = 0):
+    g = torch.Generator().manual_seed(seed)
+    sd = {}
+    C, p = cfg.enc_dim, cfg.patch_size
+    fan_in = 3 * p * p
+    bound = 1.0 / math.sqrt(fan_in)  # kaiming_uniform(a=sqrt(5)) == U(-1/sqrt(fan_in), +)
+    sd["patch_embed.proj.weight"] = (torch.rand((C, 3, p, p), generator=g) * 2 - 1) * bound
+    sd["patch_embed.proj.bias"] = (torch.rand((C,), generator=g) * 2 - 1) * bound
+    for i in range(cfg.enc_depth):
+        b = f"blocks_enc.{i}"
+        _ln(g, sd, b + ".norm1", C)
+        _linear(g, sd, b + ".attn.qkv", 3 * C, C)
+        _linear(g, sd, b + ".attn.proj", C, C)
+        _ln(g, sd, b + ".norm2", C)
+        _linear(g, sd, b + ".mlp.fc1", cfg.mlp_ratio * C, C)
+        _linear(g, sd, b + ".mlp.fc2", C, cfg.mlp_ratio * C)
+    _ln(g, sd, "norm_enc", C)
+    return sd
+
+
+def make_decoder_state_dict(cfg: ModelConfig, seed: int = 0):
+    g = torch.Generator().manual_seed(seed + 7919)
+    sd = {}
+    C, D = cfg.enc_dim, cfg.dec_dim
+    sd["image2_embed"] = torch.randn((1, 1, D), generator=g) * 0.02
+    _linear(g, sd, "feat_embed_enc_to_dec", D, C)
+    for i in range(cfg.dec_depth):
+        b = f"blocks_dec.{i}"
+        _ln(g, sd, b + ".norm1", D)
+        _linear(g, sd, b + ".attn.qkv", 3 * D, D)
+        _linear(g, sd, b + ".attn.proj", D, D)
+        _ln(g, sd, b + ".norm2", D)
+        _ln(g, sd, b + ".norm_y", D)
+        for n in ("projq", "projk", "projv", "proj"):
+            _linear(g, sd, b + ".cross_attn." + n, D, D)
+        _ln(g, sd, b + ".norm3", D)
+        _linear(g, sd, b + ".mlp.fc1", cfg.mlp_ratio * D, D)
+        _linear(g, sd, b + ".mlp.fc2", D, cfg.mlp_ratio * D)
+    _linear(g, sd, "feedback_layer.fc1", 4 * D, D)
+    sd["feedback_layer.fc2.weight"] = torch.randn((D, 4 * D), generator=g) * 0.02
+    sd["feedback_layer.fc2.bias"] = _bias(g, D)
+    _ln(g, sd, "feedback_norm", D)
+    _ln(g, sd, "norm_dec", D)
+    _linear(g, sd, "head_dec.proj", cfg.output_dim, D)
+    return sd
+
+
+def make_images(n_views: int, H: int, W: int, seed: int = 0):
+    """``randn(V,3,H,W)`` fp32 (what the reference's own smoke test feeds, decoder.py:580) and the
+    matching ``true_shape`` int64[V,2] = (H, W)."""
+    g = torch.Generator().manual_seed(seed + 104729)
+    imgs = torch.randn((n_views, 3, H, W), generator=g)
+    true_shape = torch.tensor([[H, W]] * n_views, dtype=torch.int64)
+    return imgs, true_shape
