@@ -1,0 +1,213 @@
+#!/usr/bin/env python
+"""Headline benchmark: views/sec for MUSt3R_512 (ViT-L encoder / ViT-B memory decoder), 20-view 512x384 scenes.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path over one batch of synthetic input already resident in HBM:
+  N = 1 : one scene of 20 views -- encode 20, memory update with the demo schedule [2,1,...,1] (20-view memory),
+          render 20 against the final memory, fp32 activation (BASELINE.json configs[2]).
+  N > 1 : weak scaling of the same workload: every rank owns 20 views (20*N views per step); the memory is still
+          built from 20 keyframes (every N-th view), whose encoded tokens are all-gathered over RCCL/xGMI and the
+          sequential update is replicated on every rank; encode and render are view-sharded (must3r_amd/parallel.py).
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_TFLOPS = {"bf16": 2500.0, "fp16": 2500.0}   # dense MFMA peak, MI355X_MICROARCH.md "Peak BF16/FP16 MFMA"
+
+
+def build_models(cfg, precision, device):
+    import must3r_amd.model as M
+    from must3r_amd import synthetic as S
+    enc = M.Dust3rEncoder(img_size=(cfg.img_size,) * 2, embed_dim=cfg.enc_dim, depth=cfg.enc_depth, num_heads=cfg.enc_heads,
+                          precision=precision)
+    dec = M.MUSt3R(img_size=(cfg.img_size,) * 2, enc_embed_dim=cfg.enc_dim, embed_dim=cfg.dec_dim, depth=cfg.dec_depth,
+                   num_heads=cfg.dec_heads, feedback_type="single_mlp", memory_mode="kv", landscape_only=False,
+                   precision=precision)
+    sde, sdd = S.make_encoder_state_dict(cfg, 0), S.make_decoder_state_dict(cfg, 0)
+    enc.load_state_dict(sde, strict=True)
+    dec.load_state_dict(sdd, strict=True)
+    return enc.to(device).eval(), dec.to(device).eval(), sde, sdd
+
+
+def scene_flops(N, V, K):
+    """Algorithmic FLOPs of one scene: V views encoded+rendered, K-keyframe memory."""
+    enc = 2 * N * 768 * 1024 + 24 * (24 * N * 1024 ** 2 + 4 * N * N * 1024)
+    dec_fixed = 2 * N * 1024 * 768 + 12 * (28 * N * 768 ** 2 + 4 * N * N * 768) + 2 * N * 768 * 1792
+    ca = 12 * 4 * N * 768
+    memw = 12 * 4 * N * 768 ** 2 + 16 * N * 768 ** 2
+    upd_ca = ca * N * (2 + sum(range(2, K)))   # init: 2 views x 1 other view; then view i attends i previous views
+    return V * enc + K * (dec_fixed + memw) + upd_ca + 2 * 12 * 4 * N * 768 ** 2 + V * dec_fixed + V * ca * N * K
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--views", type=int, default=20)
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp16"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-alt", action="store_true")
+    args = ap.parse_args()
+
+    import torch.distributed as dist
+    from must3r_amd.config import MUST3R_512
+    from must3r_amd import synthetic as S
+    from must3r_amd.engine import run_scene, demo_mem_batches
+    from must3r_amd.parallel import run_scene_sharded
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    cfg, H, W, V = MUST3R_512, 384, 512, args.views
+    N = (H // 16) * (W // 16)
+    enc, dec, sde, sdd = build_models(cfg, args.precision, device)
+    imgs, ts = S.make_images(V, H, W, seed=rank)           # each rank its own views, resident in HBM
+    imgs, ts = imgs.to(device), ts.to(device)
+    tdt = torch.bfloat16 if args.precision == "bf16" else torch.float16
+    if world > 1:
+        gidx = torch.arange(rank * V, (rank + 1) * V)
+        keyframes = (gidx % world == 0)                    # 20 keyframes spread over all ranks
+    n_key = V
+
+    def step():
+        if world == 1:
+            return run_scene(enc, dec, imgs, ts)
+        return run_scene_sharded(enc, dec, imgs, ts, keyframes, comm_dtype=tdt)
+
+    def sync():
+        torch.cuda.synchronize(device)
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize(device)
+
+    def timed(nsteps):
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(nsteps):
+            step()
+        sync()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], device=device, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt
+
+    for _ in range(args.warmup):
+        step()
+    dt = timed(args.steps)
+    views_per_step = V * world
+    value = views_per_step * args.steps / dt
+
+    # ---- per-kernel-class timing with HIP events on the launch stream (one extra, untimed step)
+    roofline, stages, classes = None, None, None
+    for m in (enc, dec):
+        m._context().set_profiling(True)
+    step()
+    torch.cuda.synchronize(device)
+    prof = {}
+    for m in (enc, dec):
+        for k, v in m._context().get_profile().items():
+            p = prof.setdefault(k, {"ms": 0.0, "flops": 0.0, "calls": 0})
+            p["ms"] += v["ms"]; p["flops"] += v["flops"]; p["calls"] += v["calls"]
+        m._context().set_profiling(False)
+    classes = {k: {"ms": round(v["ms"], 3), "calls": int(v["calls"]),
+                   "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1) if v["ms"] > 0 and v["flops"] > 0 else None}
+               for k, v in prof.items()}
+    dom = max((k for k in prof if prof[k]["flops"] > 0), key=lambda k: prof[k]["ms"])
+    ach = prof[dom]["flops"] / (prof[dom]["ms"] * 1e-3) / 1e12
+    roofline = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 1), "peak": PEAK_TFLOPS[args.precision], "unit": "TFLOP/s",
+                "frac": round(ach / PEAK_TFLOPS[args.precision], 4), "traffic": None,
+                "avg_launch_ms": round(prof[dom]["ms"] / max(1, prof[dom]["calls"]), 4), "launches": int(prof[dom]["calls"])}
+    # stage split (untimed extra step, single GPU only)
+    if world == 1:
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+        ev[0].record()
+        x, pos = enc(imgs, ts)
+        ev[1].record()
+        mem, i = None, 0
+        for nb in demo_mem_batches(V):
+            mem, _ = dec(x[i:i + nb].unsqueeze(0), pos[i:i + nb].unsqueeze(0), ts[i:i + nb].unsqueeze(0), mem)
+            i += nb
+        ev[2].record()
+        dec(x.unsqueeze(0), pos.unsqueeze(0), ts.unsqueeze(0), mem, render=True)
+        ev[3].record()
+        torch.cuda.synchronize(device)
+        stages = {"encode": round(ev[0].elapsed_time(ev[1]), 2), "update": round(ev[1].elapsed_time(ev[2]), 2),
+                  "render": round(ev[2].elapsed_time(ev[3]), 2)}
+
+    alt = None
+    if not args.no_alt and world == 1:
+        other = "fp16" if args.precision == "bf16" else "bf16"
+        enc.precision = dec.precision = other
+        step()
+        dta = timed(args.steps)
+        alt = {"dtype": other, "value": round(views_per_step * args.steps / dta, 2)}
+        enc.precision = dec.precision = args.precision
+
+    cpu_baseline, parity = None, None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        # the oracle (a port of the reference's CPU path) on a bounded sample of the same workload: the first 2 views
+        # (encode 2, init update, render 2) on all host cores; also the parity numbers of the metric's second half.
+        from oracle import must3r_ref as R
+        ncores = os.cpu_count() or 1
+        torch.set_num_threads(ncores)
+        im2, ts2 = imgs[:2].cpu(), ts[:2].cpu()
+        tm = {}
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            upd_o, ren_o, _ = R.run_scene(sde, sdd, cfg, im2, ts2, timings=tm)
+        tcpu = time.perf_counter() - t0
+        cpu_baseline = {"value": round(2 / tcpu, 4), "unit": "views/s", "cores": torch.get_num_threads(), "kind": "port",
+                        "sample": "first 2 of the 20 views, 384x512: encode 2 + init memory update + render 2 (fp32, torch CPU, SDPA)",
+                        "seconds": round(tcpu, 2), "stages_s": {k: round(v, 2) for k, v in tm.items()}}
+        parity = {}
+        for prec in ("fp16", "bf16"):
+            enc.precision = dec.precision = prec
+            out = run_scene(enc, dec, imgs[:2], ts[:2])
+            d = (out["render"].cpu() - ren_o)
+            parity[prec] = {"pointmap_max_abs_err": float(d.abs().max()), "rel_inf": float(d.abs().max() / ren_o.abs().max()),
+                            "rel_l2": float(d.norm() / ren_o.norm())}
+        enc.precision = dec.precision = args.precision
+
+    if rank == 0:
+        flops = scene_flops(N, V * world, n_key) if world == 1 else None
+        line = {
+            "metric": "views/sec (whole node) MUSt3R_512 20-view 512x384; pointmap max-abs-err vs ref",
+            "value": round(value, 2), "unit": "views/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": args.precision, "data": "synthetic",
+            "config": {"workload": f"MUSt3R_512 ViT-L/ViT-B random-init, {V}-view memory, {V * world} views/step 384x512 "
+                                   f"(encode+update[2,1..]+render+activation)", "views_per_step": V * world, "keyframes": n_key,
+                       "H": H, "W": W, "parallelism": "single" if world == 1 else f"view-sharded x{world} + all-gather(keyframe tokens)"},
+            "roofline": roofline, "cpu_baseline": cpu_baseline, "parity_vs_cpu_oracle": parity,
+            "kernel_classes": classes, "stages_ms": stages, "alt": alt,
+            "scene_tflop": round(flops / 1e12, 2) if flops else None,
+            "end_to_end_mfma_frac": round(flops * args.steps / dt / 1e12 / PEAK_TFLOPS[args.precision], 4) if flops else None,
+        }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

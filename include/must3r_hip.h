@@ -1,0 +1,146 @@
+/*
+ * libmust3r_hip -- C ABI of the MI355X-native MUSt3R multi-view forward path.
+ *
+ * Drop-in boundary: everything behind the reference's two nn.Module forwards
+ *     Dust3rEncoder.forward(img, true_shape) -> (x, pos)              must3r/model/encoder.py:46-52
+ *     MUSt3R.forward / forward_list(x, pos, true_shape, mem, render)  must3r/model/decoder.py:158-350
+ * plus the fp32 output activation of engine/inference.py:16-27.
+ *
+ * Conventions
+ *   - plain C types only: raw DEVICE pointers (tensor.data_ptr()), sizes, an opaque context handle and a
+ *     hipStream_t passed as void*.  No torch types, no exceptions across the boundary.
+ *   - every entry point returns 0 on success, non-zero on error; must3r_hip_last_error() returns a
+ *     thread-local, NUL-terminated description of the last failure.
+ *   - the caller owns all input/output buffers.  The context owns its weights (fp32 master + packed 16-bit
+ *     copies) and a grow-only workspace arena; no allocation happens on the hot path once shapes have been
+ *     seen.  A context is bound to one device and is not re-entrant (one forward in flight per context),
+ *     like the reference (slam/slam.py:533 runs forwards from a single worker thread).
+ *   - "16-bit" buffers hold bf16 or fp16 elements according to the `dtype` argument.
+ */
+#ifndef MUST3R_HIP_H
+#define MUST3R_HIP_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MUST3R_HIP_ABI_VERSION 1
+
+typedef struct must3r_hip_ctx must3r_hip_ctx;
+
+/* MFMA operand type (accumulation, softmax, LayerNorm and the residual stream are always fp32) */
+enum { MUST3R_BF16 = 0, MUST3R_F16 = 1 };
+
+/* layout of the caller-visible memory tensors; CachedDecoderBlock MEMORY_MODES, must3r/model/blocks/layers.py:9 */
+enum { MUST3R_MEM_KV = 0, MUST3R_MEM_NORM_Y = 1, MUST3R_MEM_RAW = 2 };
+
+/* constructor arguments of Dust3rEncoder (encoder.py:14-23) and MUSt3R (decoder.py:19-37) */
+typedef struct must3r_hip_config {
+    int32_t img_size, patch_size;
+    int32_t enc_dim, enc_depth, enc_heads;
+    int32_t dec_dim, dec_depth, dec_heads;
+    int32_t mlp_ratio;
+    float rope_freq; /* 'RoPE100' -> 100 (blocks/pos_embed.py:20) */
+    float rope_f0;   /* F0 = old/new size (blocks/pos_embed.py:12-19) */
+} must3r_hip_config;
+
+int must3r_hip_abi_version(void);
+const char* must3r_hip_last_error(void);
+
+/* lifetime.  replaces: eval(encoder_args)/eval(decoder_args) + .to(device) in load_model, model/__init__.py:38-46 */
+int must3r_hip_create(const must3r_hip_config* cfg, int device, must3r_hip_ctx** out);
+void must3r_hip_destroy(must3r_hip_ctx* ctx);
+
+/* Weight ingestion.  replaces: load_state_dict(strict=True), model/__init__.py:43-44.
+ * `name` is the reference state-dict key prefixed by "encoder." or "decoder." (SURVEY.md section 8b), e.g.
+ * "encoder.blocks_enc.0.attn.qkv.weight".  `data` is fp32, contiguous, on host (is_device=0) or device.
+ * The tensor is copied.  Unknown names and shape mismatches are errors. */
+int must3r_hip_load_weight(must3r_hip_ctx* ctx, const char* name, const float* data, int is_device,
+                           int ndim, const int64_t* shape);
+/* strict check that every parameter of the selected module(s) has been loaded; builds the fused / permuted
+ * device copies (K|V projection, pixel-shuffled head, RoPE table).  The reference returns encoder and decoder
+ * as two independent nn.Modules (model/__init__.py:50), so each half can be finalized on its own context. */
+enum { MUST3R_PART_ENCODER = 1, MUST3R_PART_DECODER = 2 };
+int must3r_hip_finalize_weights(must3r_hip_ctx* ctx, int parts);
+
+/* Dust3rEncoder.forward (encoder.py:46-52): img fp32 [n_views,3,H,W] (one aspect ratio per call)
+ *   -> tokens fp32 [n_views, N, enc_dim] (after norm_enc), pos int64 [n_views, N, 2] = (y, x); N = H/16 * W/16. */
+int must3r_hip_encode(must3r_hip_ctx* ctx, int dtype, const float* img, int n_views, int H, int W,
+                      float* out_tokens, int64_t* out_pos, void* stream);
+
+/* one aspect-ratio group of a decoder call (one list entry of MUSt3R.forward_list, decoder.py:158) */
+typedef struct must3r_hip_group {
+    const float* tokens;  /* fp32 [n_views, n_tokens, enc_dim] encoder output */
+    const int64_t* pos;   /* int64 [n_views, n_tokens, 2] */
+    int32_t n_views, n_tokens, H, W;
+    float* pointmaps;     /* out fp32 [n_views, H, W, 7] raw head output (decoder.py:149-156) */
+} must3r_hip_group;
+
+typedef struct must3r_hip_decode_args {
+    int32_t dtype;        /* MUST3R_BF16 / MUST3R_F16: operand type AND element type of the memory buffers */
+    int32_t mem_mode;     /* MUST3R_MEM_* */
+    int32_t render;       /* decoder.py:267 `render`: memory is read-only, no exclusion mask */
+    int32_t first_call;   /* current_mem is None: view 0 of group 0 gets no image2_embed (decoder.py:280-282) */
+    int32_t n_groups;
+    const must3r_hip_group* groups;
+    int32_t n_mem;        /* Nm: valid memory tokens before this call */
+    /* per decoder layer: 16-bit [capacity, mem_dim] row-major, mem_dim = 2*dec_dim (KV) or dec_dim.
+     * Rows [0,n_mem) are read; unless render, rows [n_mem, n_mem + sum(n_views*n_tokens)) are WRITTEN
+     * (the caller guarantees capacity) -- the in-place form of torch.concatenate at decoder.py:239/330. */
+    void* const* mem;
+} must3r_hip_decode_args;
+
+/* MUSt3R.forward / forward_list (decoder.py:158-350), batch B = 1. */
+int must3r_hip_decode(must3r_hip_ctx* ctx, const must3r_hip_decode_args* args, void* stream);
+
+/* postprocess activation (engine/inference.py:19-27; tools/geometry.py:14-18): pointmaps fp32 [npix,7]
+ *   -> pts3d [npix,3], pts3d_local [npix,3], conf [npix] */
+int must3r_hip_postprocess(const float* pointmaps, float* pts3d, float* pts3d_local, float* conf, size_t npix,
+                           void* stream);
+
+/* ------------------------------------------------------------------------------------------------------
+ * Operator-level entry points (the same kernels the two forwards are built from), exported so that parity
+ * tests and roofline measurements can drive each kernel alone.
+ * ------------------------------------------------------------------------------------------------------ */
+enum { MUST3R_EPI_STORE16 = 0, MUST3R_EPI_STORE16_GELU = 1, MUST3R_EPI_QKV_ROPE = 2, MUST3R_EPI_RESID_F32 = 3,
+       MUST3R_EPI_F32 = 4, MUST3R_EPI_HEAD = 5 };
+
+/* out[M,N] = epi(A[M,K] . W[N,K]^T + bias): nn.Linear (+ fused epilogue).  A, W 16-bit. */
+int must3r_hip_op_gemm(int dtype, int epi, const void* A, const void* W, const float* bias, void* out,
+                       int M, int N, int K, int lda, int ldc,
+                       const int64_t* pos, const float* rope_tab, int rope_cols, int rope_npos, /* QKV_ROPE */
+                       const float* bias2, int row_start2, int accumulate,                      /* F32 / HEAD */
+                       int ntok, int gw, int H, int W_img,                                      /* HEAD */
+                       void* stream);
+/* cos/sin table fp32 [npos][16][2] for RoPE2D(freq, F0) with head dim 64 (host pointer) */
+int must3r_hip_rope_table(float freq, float f0, int npos, float* out_host);
+
+/* softmax(Q K^T / 8) V per head of 64; views: int32 [n_views][6] = q_row0, nq, kv_row0, nk, skip_lo, skip_hi
+ * (DEVICE pointer).  Q/K/V/O 16-bit with row strides in elements. */
+int must3r_hip_op_attention(int dtype, const void* Q, const void* K, const void* V, void* O,
+                            int ldq, int ldk, int ldv, int ldo, int heads,
+                            const int32_t* views_dev, int n_views, int max_nq, void* stream);
+
+/* y = LN(x (+ add)) * w + b over rows of C; optional outputs may be NULL */
+int must3r_hip_op_layernorm(int dtype, const float* x, const float* add, const float* w, const float* b,
+                            void* out16, void* out16_lo, float* out32, float* copy32, int M, int C, float eps,
+                            void* stream);
+int must3r_hip_op_im2col(int dtype, const float* img, void* out16, int n_views, int H, int W, void* stream);
+int must3r_hip_op_cast(int dtype, const float* in, void* out16, void* out16_lo, size_t n, void* stream);
+
+/* debug: lane -> element mapping of the gfx950 transposing LDS read the attention kernel relies on; writes 256 int16 */
+int must3r_hip_debug_tr_probe(void* out256_i16_dev, void* stream);
+
+/* timing hooks used by bench.py: per-stage HIP-event timers recorded on the call's stream */
+int must3r_hip_set_profiling(must3r_hip_ctx* ctx, int enabled);
+/* returns the number of records written (<= max); each record: name (<=31 chars), milliseconds, flops */
+typedef struct must3r_hip_prof_record { char name[32]; double ms; double flops; int64_t calls; } must3r_hip_prof_record;
+int must3r_hip_get_profile(must3r_hip_ctx* ctx, must3r_hip_prof_record* out, int max, int reset);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MUST3R_HIP_H */

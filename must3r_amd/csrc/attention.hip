@@ -1,0 +1,246 @@
+// Flash-style softmax attention for gfx950, head dim 64, 16-bit operands / fp32 softmax + accumulation.
+//
+// Transposed formulation so that nothing ever moves across lanes except the row max / row sum:
+//     S^T[key][q] = K . Q^T        (MFMA A = K tile rows from LDS,       B = Q fragments held in VGPRs)
+//     O^T[d][q]   = V^T . P^T      (MFMA A = V^T via ds_read_b64_tr_b16, B = P^T = exp2(S^T - m) in place)
+// With v_mfma_f32_16x16x32 the C layout of S^T (lane: q = l&15, keys 4*(l>>4)+r) is exactly the B-operand
+// layout the second product needs (k-slot (l>>4)*8+e <-> keys {4g+e, 16+4g+e}), and V^T is read from the
+// row-major V tile with the hardware transposing LDS read, keyed the same way.  q is per-lane in both
+// accumulators, so the online-softmax rescale is a per-lane multiply.
+//
+// Block = 4 waves x 32 query rows; K/V tiles of 64 keys DMA'd HBM->LDS (global_load_lds), double
+// buffered, one barrier per tile.  Keys may exclude one contiguous range per view (MUSt3R own-token rule,
+// decoder.py:119-139): fully excluded tiles are never loaded, partially excluded ones are masked.
+#include "common.hpp"
+#include "kernels.hpp"
+
+namespace m3r {
+
+constexpr int ATT_QW = 32;               // query rows per wave
+constexpr int ATT_QB = 4 * ATT_QW;       // per block
+constexpr int ATT_KT = 64;               // keys per tile
+
+template <class T>
+__global__ void __launch_bounds__(256) attn_kernel(const AttnArgs p, const int nqb, const int ngrp) {
+    typedef typename Vec<T>::v8 v8;
+    typedef typename Vec<T>::v4 v4;
+    constexpr int QF = ATT_QW / 16;
+    __shared__ __attribute__((aligned(16))) T sK[2][ATT_KT * 64];
+    __shared__ __attribute__((aligned(16))) T sV[2][ATT_KT * 64];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 15, fg = lane >> 4;
+
+    // blocks of one (view, head) group stay on one XCD (blockIdx % 8) so its K/V tiles are L2 hits
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int grp = (slot / nqb) * 8 + xcd;
+    const int qb = slot % nqb;
+    if (grp >= ngrp) return;
+    const int view = grp / p.heads, head = grp - view * p.heads;
+    const AttnView vw = p.views[view];
+    if (qb * ATT_QB >= vw.nq) return;
+
+    const T* __restrict__ Q = reinterpret_cast<const T*>(p.Q);
+    const T* __restrict__ K = reinterpret_cast<const T*>(p.K) + (size_t)vw.kv_row0 * p.ldk + head * 64;
+    const T* __restrict__ V = reinterpret_cast<const T*>(p.V) + (size_t)vw.kv_row0 * p.ldv + head * 64;
+
+    // ---- Q fragments (B operand): lane (j = fr, g = fg) holds Q[q = 16 qf + j][d = 32 ks + 8 g ..+7]
+    const int qr0 = qb * ATT_QB + wave * ATT_QW;
+    v8 qf_[QF][2];
+#pragma unroll
+    for (int f = 0; f < QF; ++f) {
+        int r = qr0 + f * 16 + fr;
+        r = r < vw.nq ? r : vw.nq - 1;
+        const T* src = Q + (size_t)(vw.q_row0 + r) * p.ldq + head * 64 + fg * 8;
+        qf_[f][0] = *reinterpret_cast<const v8*>(src);
+        qf_[f][1] = *reinterpret_cast<const v8*>(src + 32);
+    }
+
+    const int nk = vw.nk, slo = vw.skip_lo, shi = vw.skip_hi;
+    const int ntiles = (nk + ATT_KT - 1) / ATT_KT;
+    auto fully_skipped = [&](int t) {
+        const int k0 = t * ATT_KT;
+        const int k1 = (k0 + ATT_KT < nk) ? k0 + ATT_KT : nk;
+        return k0 >= slo && k1 <= shi;
+    };
+    auto advance = [&](int t) {
+        ++t;
+        while (t < ntiles && fully_skipped(t)) ++t;
+        return t;
+    };
+
+    // ---- staging: per tile 8 wave-instructions for K and 8 for V (8 rows x 128 B each); 2 + 2 per wave
+    const int srow = lane >> 3, pch = lane & 7;
+    auto stage = [&](int t, int buf) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int piece = wave * 2 + i;
+            const int r = piece * 8 + srow;
+            int key = t * ATT_KT + r;
+            key = key < nk ? key : nk - 1;
+            const int lc = swz(r, pch);
+            glds16(K + (size_t)key * p.ldk + lc * 8, &sK[buf][piece * 8 * 64]);
+            glds16(V + (size_t)key * p.ldv + lc * 8, &sV[buf][piece * 8 * 64]);
+        }
+    };
+
+    f32x4 o_[4][QF];
+    float m_[QF], l_[QF];
+#pragma unroll
+    for (int f = 0; f < QF; ++f) {
+        m_[f] = -INFINITY;
+        l_[f] = 0.f;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) o_[d][f] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const float c = p.scale * 1.44269504088896340736f;  // softmax in base 2
+
+    int t = -1;
+    t = advance(t);
+    if (t < ntiles) stage(t, 0);
+    int buf = 0;
+    while (t < ntiles) {
+        __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0)
+        __syncthreads();
+        const int tn = advance(t);
+        if (tn < ntiles) stage(tn, buf ^ 1);
+
+        const T* k_ = sK[buf];
+        const T* v_ = sV[buf];
+        // ---- S^T = K Q^T
+        f32x4 s_[4][QF];
+#pragma unroll
+        for (int kf = 0; kf < 4; ++kf)
+#pragma unroll
+            for (int f = 0; f < QF; ++f) s_[kf][f] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+            for (int kf = 0; kf < 4; ++kf) {
+                const int r = kf * 16 + fr;
+                const v8 kfrag = *reinterpret_cast<const v8*>(k_ + r * 64 + swz(r, ks * 4 + fg) * 8);
+#pragma unroll
+                for (int f = 0; f < QF; ++f) s_[kf][f] = mfma16(kfrag, qf_[f][ks], s_[kf][f]);
+            }
+        }
+        // ---- exclusion / tail mask: s_[kf][f][r] is key k0 + 16 kf + 4 fg + r
+        const int k0 = t * ATT_KT;
+        const bool need_mask = (k0 + ATT_KT > nk) || (k0 < shi && k0 + ATT_KT > slo);
+        if (need_mask) {
+#pragma unroll
+            for (int kf = 0; kf < 4; ++kf)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int key = k0 + kf * 16 + fg * 4 + r;
+                    const bool bad = key >= nk || (key >= slo && key < shi);
+                    if (bad) {
+#pragma unroll
+                        for (int f = 0; f < QF; ++f) s_[kf][f][r] = -INFINITY;
+                    }
+                }
+        }
+        // ---- online softmax (base 2), per query = per lane column; keys of a query live in lanes fr+16*g
+#pragma unroll
+        for (int f = 0; f < QF; ++f) {
+            float mx = -INFINITY;
+#pragma unroll
+            for (int kf = 0; kf < 4; ++kf)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s_[kf][f][r]);
+            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float mnew = fmaxf(m_[f], mx * c);
+            const float msafe = (mnew == -INFINITY) ? 0.f : mnew;
+            const float alpha = __builtin_amdgcn_exp2f(m_[f] - msafe);
+            m_[f] = mnew;
+            float ps = 0.f;
+#pragma unroll
+            for (int kf = 0; kf < 4; ++kf)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float e = __builtin_amdgcn_exp2f(s_[kf][f][r] * c - msafe);
+                    s_[kf][f][r] = e;
+                    ps += e;
+                }
+            l_[f] = l_[f] * alpha + ps;
+#pragma unroll
+            for (int d = 0; d < 4; ++d) o_[d][f] *= alpha;
+        }
+        // ---- O^T += V^T P^T ; k-slot e of lane group g <-> keys {4g+e (e<4), 16+4g+e-4 (e>=4)} of the 32-key slot
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            v8 pb[QF];
+#pragma unroll
+            for (int f = 0; f < QF; ++f) {
+                f32x8 pv;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    pv[r] = s_[2 * ks][f][r];
+                    pv[4 + r] = s_[2 * ks + 1][f][r];
+                }
+                pb[f] = cvt8<T>(pv);
+            }
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                // transposing read: chunk m = fr of the 16-lane group = row (m>>2), d-columns 4*(m&3)..+3
+                const int r0 = ks * 32 + fg * 4 + (fr >> 2);
+                const int dc = d * 16 + (fr & 3) * 4;
+                const int r1 = r0 + 16;
+                const v4 lo = lds_read_tr4<T>(v_ + r0 * 64 + swz(r0, dc >> 3) * 8 + (dc & 7));
+                const v4 hi = lds_read_tr4<T>(v_ + r1 * 64 + swz(r1, dc >> 3) * 8 + (dc & 7));
+                const v8 vfrag = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+                for (int f = 0; f < QF; ++f) o_[d][f] = mfma16(vfrag, pb[f], o_[d][f]);
+            }
+        }
+        t = tn;
+        buf ^= 1;
+    }
+
+    // ---- normalise and store: lane (q = fr, g) holds O[q][d = 16 dd + 4 g + r]
+    T* __restrict__ O = reinterpret_cast<T*>(p.O);
+#pragma unroll
+    for (int f = 0; f < QF; ++f) {
+        float l = l_[f];
+        l += __shfl_xor(l, 16, 64);
+        l += __shfl_xor(l, 32, 64);
+        const float inv = l > 0.f ? 1.0f / l : 0.f;
+        const int q = qr0 + f * 16 + fr;
+        if (q < vw.nq) {
+            T* dst = O + (size_t)(vw.q_row0 + q) * p.ldo + head * 64 + fg * 4;
+#pragma unroll
+            for (int d = 0; d < 4; ++d) *reinterpret_cast<v4*>(dst + d * 16) = cvt4<T>(o_[d][f] * inv);
+        }
+    }
+}
+
+// hardware-semantics probe used by the tests: LDS holds element index e at position e; every lane issues the
+// transposing read on its canonical chunk (lane*4 elements) and reports the 4 values it received.
+__global__ void tr_probe_kernel(short* out) {
+    __shared__ __attribute__((aligned(16))) short lds[256];
+    const int l = threadIdx.x;
+    for (int i = l; i < 256; i += 64) lds[i] = (short)i;
+    __syncthreads();
+    s16x4 r = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(lds + l * 4));
+    for (int e = 0; e < 4; ++e) out[l * 4 + e] = r[e];
+}
+int launch_tr_probe(short* out, hipStream_t s) {
+    hipLaunchKernelGGL(tr_probe_kernel, dim3(1), dim3(64), 0, s, out);
+    return hipGetLastError() == hipSuccess ? 0 : 1;
+}
+
+int launch_attention(DType dt, const AttnArgs& a, hipStream_t s, const char** err) {
+    if (a.nviews <= 0 || a.max_nq <= 0) return 0;
+    if ((a.ldq % 8) || (a.ldk % 8) || (a.ldv % 8) || (a.ldo % 4)) { *err = "attention: row strides must be 16-byte aligned"; return 1; }
+    const int nqb = (a.max_nq + ATT_QB - 1) / ATT_QB;
+    const int ngrp = a.nviews * a.heads;
+    const int grid = ((ngrp + 7) / 8) * 8 * nqb;
+    if (dt == DT_BF16) hipLaunchKernelGGL(attn_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, a, nqb, ngrp);
+    else hipLaunchKernelGGL(attn_kernel<f16_t>, dim3(grid), dim3(256), 0, s, a, nqb, ngrp);
+    if (hipGetLastError() != hipSuccess) { *err = "attention: kernel launch failed"; return 1; }
+    return 0;
+}
+
+}  // namespace m3r

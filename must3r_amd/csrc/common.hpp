@@ -1,0 +1,71 @@
+// Shared device helpers for the gfx950 (CDNA4) kernels of the MUSt3R multi-view forward path.
+// Wave = 64 lanes. MFMA shape used everywhere: v_mfma_f32_16x16x32_{bf16,f16}
+//   A[i][k]: lane l holds i = l&15, k = (l>>4)*8 .. +7     (8 x 16-bit, 16 bytes)
+//   B[k][j]: lane l holds j = l&15, k = (l>>4)*8 .. +7
+//   C[i][j]: lane l holds j = l&15, i = (l>>4)*4 + r, r = 0..3  (f32x4)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace m3r {
+
+typedef __bf16 bf16_t;
+typedef _Float16 f16_t;
+
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(8))) float f32x8;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(4))) int i32x4;
+
+template <class T> struct Vec;
+template <> struct Vec<bf16_t> { typedef bf16x8 v8; typedef bf16x4 v4; };
+template <> struct Vec<f16_t>  { typedef f16x8 v8;  typedef f16x4 v4; };
+
+__device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4 mfma16(f16x8 a, f16x8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+}
+
+template <class T> __device__ __forceinline__ typename Vec<T>::v4 cvt4(f32x4 v) {
+    return __builtin_convertvector(v, typename Vec<T>::v4);
+}
+template <class T> __device__ __forceinline__ typename Vec<T>::v8 cvt8(f32x8 v) {
+    return __builtin_convertvector(v, typename Vec<T>::v8);
+}
+
+// LDS transposed read: each lane passes the address of its own 8-byte (4 x 16-bit) chunk; inside a
+// 16-lane group the 16 chunks form a 4 x 16 row-major matrix X (chunk m = row m>>2, cols 4*(m&3)..+3)
+// and lane i of the group receives column i: {X[0][i], X[1][i], X[2][i], X[3][i]}.
+template <class T> __device__ __forceinline__ typename Vec<T>::v4 lds_read_tr4(const T* p) {
+    s16x4 r = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p));
+    typename Vec<T>::v4 o;
+    __builtin_memcpy(&o, &r, 8);
+    return o;
+}
+
+// async global -> LDS, 16 bytes per lane; LDS destination = (wave-uniform) lds_base + lane*16.
+__device__ __forceinline__ void glds16(const void* gptr, void* lds_base_uniform) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gptr,
+                                     (__attribute__((address_space(3))) void*)lds_base_uniform, 16, 0, 0);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// 16-byte-chunk XOR swizzle for [rows][64 x 16-bit] (128-byte rows) LDS tiles read with ds_read_b128:
+// physical chunk = logical chunk ^ ((row >> 1) & 7).  Rows r, r+1 sit in different halves of the 256-byte
+// bank row, so 16 consecutive rows reading the same logical chunk hit 16 distinct 16-byte slots.
+__device__ __forceinline__ int swz(int row, int chunk) { return chunk ^ ((row >> 1) & 7); }
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+
+}  // namespace m3r

@@ -1,0 +1,246 @@
+// MFMA GEMM for gfx950:  out[M,N] = epi(A[M,K] . W[N,K]^T + bias)
+//
+// * 256 threads = 4 waves arranged 2 (m) x 2 (n); block tile BM x BN x 64, wave tile (BM/2) x (BN/2)
+//   built from v_mfma_f32_16x16x32 fragments.  The WEIGHT tile is the MFMA A operand (i = n) and the
+//   ACTIVATION tile the B operand (j = m), so a lane ends up with 4 consecutive output columns of one
+//   row: 8-byte (16-bit out) / 16-byte (fp32 out) stores, float4 bias loads, and the 2-D RoPE pairs
+//   (d, d+16) of a head live in the same lane (fragments nf, nf+1) -> RoPE is a pure-register epilogue.
+// * HBM -> LDS with global_load_lds (16 B/lane, no VGPR round trip), double-buffered, one barrier per
+//   K-tile; the next tile's DMA is in flight while the current one is multiplied.
+// * LDS tiles are [rows][64] 16-bit (128-byte rows).  global_load_lds writes lane-linear, so the
+//   bank-conflict swizzle (common.hpp swz) is applied to the per-lane SOURCE address and again on the
+//   ds_read_b128 side (same involution).
+// * blockIdx -> tile mapping is XCD-aware: each XCD (blockIdx % 8) walks a contiguous m-major chunk of
+//   the tile grid so blocks sharing activation rows share one L2.
+#include "common.hpp"
+#include "kernels.hpp"
+
+namespace m3r {
+
+template <class T, int BM, int BN, int EPI>
+__global__ void __launch_bounds__(256) gemm_kernel(const GemmArgs p) {
+    typedef typename Vec<T>::v8 v8;
+    typedef typename Vec<T>::v4 v4;
+    constexpr int BK = 64;
+    constexpr int WM = BM / 2, WN = BN / 2;
+    constexpr int MF = WM / 16, NF = WN / 16;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    T* sA = reinterpret_cast<T*>(smem);   // [2][BM][BK]
+    T* sW = sA + 2 * BM * BK;             // [2][BN][BK]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+
+    // ---- XCD-aware bijective remap of the linear block id
+    const int nbn = p.N / BN;
+    const int nbm = (p.M + BM - 1) / BM;
+    const int nwg = nbm * nbn;
+    int bid = blockIdx.x;
+    {
+        const int xcd = bid & 7, slot = bid >> 3;
+        const int q = nwg >> 3, r = nwg & 7;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+    }
+    const int m0 = (bid / nbn) * BM;
+    const int n0 = (bid % nbn) * BN;
+
+    const T* __restrict__ A = reinterpret_cast<const T*>(p.A);
+    const T* __restrict__ W = reinterpret_cast<const T*>(p.W);
+
+    // ---- staging: one wave instruction moves 8 rows x 128 B
+    const int srow = lane >> 3;
+    const int pch = lane & 7;
+    const T* a_src[BM / 32];
+    const T* w_src[BN / 32];
+#pragma unroll
+    for (int t = 0; t < BM / 32; ++t) {
+        const int r = (wave * (BM / 32) + t) * 8 + srow;
+        int gr = m0 + r;
+        gr = gr < p.M ? gr : p.M - 1;
+        a_src[t] = A + (size_t)gr * p.lda + swz(r, pch) * 8;
+    }
+#pragma unroll
+    for (int t = 0; t < BN / 32; ++t) {
+        const int r = (wave * (BN / 32) + t) * 8 + srow;
+        int gr = n0 + r;
+        gr = gr < p.N ? gr : p.N - 1;
+        w_src[t] = W + (size_t)gr * p.K + swz(r, pch) * 8;
+    }
+    auto stage = [&](int kt, int buf) {
+#pragma unroll
+        for (int t = 0; t < BM / 32; ++t)
+            glds16(a_src[t] + kt * BK, sA + (buf * BM + (wave * (BM / 32) + t) * 8) * BK);
+#pragma unroll
+        for (int t = 0; t < BN / 32; ++t)
+            glds16(w_src[t] + kt * BK, sW + (buf * BN + (wave * (BN / 32) + t) * 8) * BK);
+    };
+
+    f32x4 acc[MF][NF];
+#pragma unroll
+    for (int i = 0; i < MF; ++i)
+#pragma unroll
+        for (int j = 0; j < NF; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int fr = lane & 15;   // fragment row supplied by this lane
+    const int fg = lane >> 4;   // k-group (16-byte chunk) supplied by this lane
+    const int nk = p.K / BK;
+
+    stage(0, 0);
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): this wave's DMA for tile kt has landed
+        __syncthreads();                     // ... everyone's has, and tile kt-1 is no longer being read
+        if (kt + 1 < nk) stage(kt + 1, buf ^ 1);
+        const T* a = sA + buf * BM * BK;
+        const T* w = sW + buf * BN * BK;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            v8 wf[NF], af[MF];
+            const int lc = ks * 4 + fg;
+#pragma unroll
+            for (int j = 0; j < NF; ++j) {
+                const int r = wn * WN + j * 16 + fr;
+                wf[j] = *reinterpret_cast<const v8*>(w + r * BK + swz(r, lc) * 8);
+            }
+#pragma unroll
+            for (int i = 0; i < MF; ++i) {
+                const int r = wm * WM + i * 16 + fr;
+                af[i] = *reinterpret_cast<const v8*>(a + r * BK + swz(r, lc) * 8);
+            }
+#pragma unroll
+            for (int i = 0; i < MF; ++i)
+#pragma unroll
+                for (int j = 0; j < NF; ++j) acc[i][j] = mfma16(wf[j], af[i], acc[i][j]);
+        }
+    }
+
+    // ---- epilogue: acc[i][j][r] = C[m = m0 + wm*WM + i*16 + fr][n = n0 + wn*WN + j*16 + fg*4 + r]
+    const int nb = n0 + wn * WN + fg * 4;
+#pragma unroll
+    for (int i = 0; i < MF; ++i) {
+        const int m = m0 + wm * WM + i * 16 + fr;
+        if (m >= p.M) continue;
+        f32x4 v[NF];
+#pragma unroll
+        for (int j = 0; j < NF; ++j) {
+            v[j] = acc[i][j];
+            const bool nobias = (EPI == EPI_F32 || EPI == EPI_HEAD) && p.accumulate;
+            if (p.bias != nullptr && !nobias) {
+                const f32x4 b = *reinterpret_cast<const f32x4*>(p.bias + nb + j * 16);
+                v[j] += b;
+            }
+        }
+        if constexpr (EPI == EPI_QKV_ROPE) {
+            // wave tile is 32- or 64-column aligned inside a 64-wide head: fragments (2q, 2q+1) are the
+            // rotate-half pair of one 32-wide half; even halves rotate by y, odd halves by x.
+            if (n0 + wn * WN < p.rope_cols) {
+                const long long py = p.pos[(size_t)m * 2 + 0];
+                const long long px = p.pos[(size_t)m * 2 + 1];
+#pragma unroll
+                for (int q = 0; q < NF / 2; ++q) {
+                    const int nh = n0 + wn * WN + q * 32;
+                    int pp = (int)(((nh >> 5) & 1) ? px : py);
+                    pp = pp < 0 ? 0 : (pp >= p.rope_npos ? p.rope_npos - 1 : pp);
+                    const float* tb = p.rope_tab + ((size_t)pp * 16 + fg * 4) * 2;
+                    const f32x4 t0 = *reinterpret_cast<const f32x4*>(tb);      // cos0 sin0 cos1 sin1
+                    const f32x4 t1 = *reinterpret_cast<const f32x4*>(tb + 4);  // cos2 sin2 cos3 sin3
+                    const float cs[4] = {t0[0], t0[2], t1[0], t1[2]};
+                    const float sn[4] = {t0[1], t0[3], t1[1], t1[3]};
+                    const f32x4 x0 = v[2 * q], x1 = v[2 * q + 1];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        v[2 * q][r] = x0[r] * cs[r] - x1[r] * sn[r];
+                        v[2 * q + 1][r] = x1[r] * cs[r] + x0[r] * sn[r];
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NF; ++j) {
+            const int n = nb + j * 16;
+            if constexpr (EPI == EPI_STORE16 || EPI == EPI_QKV_ROPE) {
+                *reinterpret_cast<v4*>(reinterpret_cast<T*>(p.out) + (size_t)m * p.ldc + n) = cvt4<T>(v[j]);
+            } else if constexpr (EPI == EPI_STORE16_GELU) {
+                f32x4 g;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) g[r] = gelu_erf(v[j][r]);
+                *reinterpret_cast<v4*>(reinterpret_cast<T*>(p.out) + (size_t)m * p.ldc + n) = cvt4<T>(g);
+            } else if constexpr (EPI == EPI_RESID_F32) {
+                f32x4* o = reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + (size_t)m * p.ldc + n);
+                *o = *o + v[j];
+            } else if constexpr (EPI == EPI_F32) {
+                f32x4* o = reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + (size_t)m * p.ldc + n);
+                f32x4 x = v[j];
+                if (p.accumulate) {
+                    x += *o;
+                } else if (p.bias2 != nullptr && m >= p.row_start2) {
+                    x += *reinterpret_cast<const f32x4*>(p.bias2 + n);
+                }
+                *o = x;
+            } else if constexpr (EPI == EPI_HEAD) {
+                // permuted feature n = (i*16 + jj)*7 + c ; token t of view vv at grid (gy, gx)
+                const int vv = m / p.ntok, t = m - vv * p.ntok;
+                const int gy = t / p.gw, gx = t - gy * p.gw;
+                const int pi = n / 112, rem = n - pi * 112;
+                const size_t off = ((size_t)(vv * p.H + gy * 16 + pi) * p.Wimg + gx * 16) * 7 + rem;
+                f32x4* o = reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + off);
+                f32x4 x = v[j];
+                if (p.accumulate) x += *o;
+                *o = x;
+            }
+        }
+    }
+}
+
+template <class T, int BM, int BN, int EPI>
+static int launch_cfg(const GemmArgs& a, hipStream_t s) {
+    const int nbn = a.N / BN, nbm = (a.M + BM - 1) / BM;
+    const size_t lds = (size_t)2 * (BM + BN) * 64 * sizeof(T);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<T, BM, BN, EPI>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((gemm_kernel<T, BM, BN, EPI>), dim3(nbm * nbn), dim3(256), lds, s, a);
+    return hipGetLastError() == hipSuccess ? 0 : 1;
+}
+
+template <class T, int EPI>
+static int launch_epi(const GemmArgs& a, hipStream_t s, const char** err) {
+    const bool n128 = (a.N % 128) == 0;
+    const long tiles128 = (long)((a.M + 127) / 128) * (a.N / 128);
+    int rc;
+    if (n128 && tiles128 >= 192) rc = launch_cfg<T, 128, 128, EPI>(a, s);
+    else rc = launch_cfg<T, 64, 64, EPI>(a, s);
+    if (rc) *err = "gemm: kernel launch failed";
+    return rc;
+}
+
+template <class T>
+static int launch_t(Epi epi, const GemmArgs& a, hipStream_t s, const char** err) {
+    switch (epi) {
+        case EPI_STORE16: return launch_epi<T, EPI_STORE16>(a, s, err);
+        case EPI_STORE16_GELU: return launch_epi<T, EPI_STORE16_GELU>(a, s, err);
+        case EPI_QKV_ROPE: return launch_epi<T, EPI_QKV_ROPE>(a, s, err);
+        case EPI_RESID_F32: return launch_epi<T, EPI_RESID_F32>(a, s, err);
+        case EPI_F32: return launch_epi<T, EPI_F32>(a, s, err);
+        case EPI_HEAD: return launch_epi<T, EPI_HEAD>(a, s, err);
+        default: *err = "gemm: bad epilogue"; return 1;
+    }
+}
+
+int launch_gemm(DType dt, Epi epi, const GemmArgs& a, hipStream_t s, const char** err) {
+    if (a.M <= 0) return 0;
+    if (a.N % 64 != 0 || a.K % 64 != 0 || a.N <= 0 || a.K <= 0) { *err = "gemm: N and K must be multiples of 64"; return 1; }
+    if (a.lda % 8 != 0 || (epi != EPI_HEAD && a.ldc % 4 != 0)) { *err = "gemm: lda%8 / ldc%4 alignment"; return 1; }
+    if (epi == EPI_QKV_ROPE && (a.pos == nullptr || a.rope_tab == nullptr || a.rope_cols % 64 != 0)) {
+        *err = "gemm: rope epilogue needs pos, table and 64-aligned rope_cols"; return 1;
+    }
+    if (epi == EPI_HEAD && (a.N % 112 != 0 || a.ntok <= 0 || a.gw <= 0)) { *err = "gemm: head epilogue geometry"; return 1; }
+    return dt == DT_BF16 ? launch_t<bf16_t>(epi, a, s, err) : launch_t<f16_t>(epi, a, s, err);
+}
+
+}  // namespace m3r

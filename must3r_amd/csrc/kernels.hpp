@@ -1,0 +1,99 @@
+// Host-side launcher declarations for the hand-written gfx950 kernels (one process per GPU, explicit stream).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace m3r {
+
+enum DType { DT_BF16 = 0, DT_F16 = 1 };
+
+// ---------------------------------------------------------------------------------------------
+// GEMM   out[M,N] = epilogue( A[M,K] (16-bit, row-major, lda) x W[N,K]^T (16-bit, row-major) + bias[N] )
+// ---------------------------------------------------------------------------------------------
+enum Epi {
+    EPI_STORE16 = 0,   // out 16-bit [M,ldc]
+    EPI_STORE16_GELU,  // out 16-bit, exact-erf GELU
+    EPI_QKV_ROPE,      // out 16-bit, 2-D RoPE on columns < rope_cols (q and k of a fused qkv projection)
+    EPI_RESID_F32,     // out fp32 [M,ldc] += acc + bias   (in-place residual stream update)
+    EPI_F32,           // out fp32 = acc + bias (+ bias2 on rows >= row_start2) ; accumulate -> out += acc
+    EPI_HEAD,          // fp32 pixel-shuffled scatter into [view][H][W][7] (weights pre-permuted) ; accumulate alike
+    EPI_COUNT
+};
+
+struct GemmArgs {
+    const void* A;
+    const void* W;
+    const float* bias;
+    void* out;
+    int M, N, K, lda, ldc;
+    // EPI_QKV_ROPE
+    const int64_t* pos;      // [M,2] (y,x)
+    const float* rope_tab;   // [npos][16][2] (cos,sin)
+    int rope_cols;
+    int rope_npos;
+    // EPI_F32
+    const float* bias2;
+    int row_start2;
+    int accumulate;          // EPI_F32 / EPI_HEAD: add into out, skip bias
+    // EPI_HEAD: rows are `ntok`-token views of one aspect ratio
+    int ntok, gw, H, Wimg;
+};
+
+// returns 0 on success, non-zero (and sets *err) on an unsupported shape
+int launch_gemm(DType dt, Epi epi, const GemmArgs& a, hipStream_t s, const char** err);
+
+// ---------------------------------------------------------------------------------------------
+// fused softmax attention, head dim 64, flash-style (no N x M score matrix in HBM)
+// ---------------------------------------------------------------------------------------------
+struct AttnView {
+    int q_row0;   // first query row of this view in Q / O
+    int nq;       // number of query tokens
+    int kv_row0;  // first key row in K / V
+    int nk;       // number of keys (before exclusion)
+    int skip_lo;  // keys [skip_lo, skip_hi) (relative to kv_row0) are excluded (own-token rule,
+    int skip_hi;  //   MUSt3R.make_mem_mask decoder.py:119-139); skip_lo == skip_hi -> none
+};
+
+struct AttnArgs {
+    const void* Q; const void* K; const void* V; void* O;   // 16-bit
+    int ldq, ldk, ldv, ldo;                                   // row strides in elements
+    int heads;
+    const AttnView* views;                                    // device pointer
+    int nviews;
+    int max_nq;                                               // max over views of nq
+    float scale;                                              // 1/sqrt(64)
+};
+int launch_attention(DType dt, const AttnArgs& a, hipStream_t s, const char** err);
+
+// ---------------------------------------------------------------------------------------------
+// row / elementwise kernels
+// ---------------------------------------------------------------------------------------------
+struct LnArgs {
+    const float* x;      // [M,C]
+    const float* add;    // optional [M,C] added to x before the statistics (feedback offset)
+    const float* w; const float* b;
+    void* out16;         // optional 16-bit [M,C]
+    void* out16_lo;      // optional 16-bit residual part: T(y - float(T(y)))  (split-precision head GEMM)
+    float* out32;        // optional fp32 [M,C]
+    float* copy32;       // optional raw copy of x (+add) (memorised layer input, decoder.py:304-305)
+    int M, C;
+    float eps;
+};
+int launch_layernorm(DType dt, const LnArgs& a, hipStream_t s, const char** err);
+
+// img fp32 [V,3,H,W] -> patches 16-bit [V*gh*gw, 3*16*16]; column = c*256 + i*16 + j
+int launch_im2col(DType dt, const float* img, void* out16, int V, int H, int W, hipStream_t s, const char** err);
+// fp32 -> 16-bit (and optional low part)
+int launch_cast(DType dt, const float* in, void* out16, void* out16_lo, size_t n, hipStream_t s, const char** err);
+// pos int64 [V, gh*gw, 2] = (y, x) row-major grid
+int launch_fill_pos(int64_t* pos, int V, int gh, int gw, hipStream_t s, const char** err);
+// pointmaps [npix,7] fp32 -> pts3d [npix,3], pts3d_local [npix,3], conf [npix]
+int launch_postprocess(const float* pm, float* pts3d, float* pts3d_local, float* conf, size_t npix, hipStream_t s,
+                       const char** err);
+// 16-bit weight low part: lo = T(w - float(T(w)))  and hi = T(w), from fp32
+int launch_split16(DType dt, const float* in, void* hi, void* lo, size_t n, hipStream_t s, const char** err);
+
+// debug: mapping of ds_read_b64_tr_b16 (out: 256 shorts)
+int launch_tr_probe(short* out, hipStream_t s);
+
+}  // namespace m3r

@@ -1,0 +1,198 @@
+// HBM-bound row / elementwise kernels: LayerNorm (wave per row, fp32 statistics, 16-bit and/or fp32 output),
+// patch im2col, casts, position grid, pointmap activation.  All vectorised to 16 B per lane where the
+// layout allows; no LDS needed (wave shuffles only).
+#include "common.hpp"
+#include "kernels.hpp"
+
+namespace m3r {
+
+// ------------------------------------------------------------------------------------------------
+// LayerNorm: one wave per row, C <= 1024, C % 4 == 0.  Two-pass statistics in registers.
+// ------------------------------------------------------------------------------------------------
+template <class T>
+__global__ void __launch_bounds__(256) ln_kernel(const LnArgs p) {
+    typedef typename Vec<T>::v4 v4;
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= p.M) return;
+    const float* x = p.x + (size_t)row * p.C;
+    f32x4 v[4];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (c < p.C) {
+            v[i] = *reinterpret_cast<const f32x4*>(x + c);
+            if (p.add) v[i] += *reinterpret_cast<const f32x4*>(p.add + (size_t)row * p.C + c);
+            if (p.copy32) *reinterpret_cast<f32x4*>(p.copy32 + (size_t)row * p.C + c) = v[i];
+            s += v[i][0] + v[i][1] + v[i][2] + v[i][3];
+        }
+    }
+    const float mean = wave_sum(s) / (float)p.C;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        if (c < p.C) {
+            v[i] -= mean;
+            q += v[i][0] * v[i][0] + v[i][1] * v[i][1] + v[i][2] * v[i][2] + v[i][3] * v[i][3];
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)p.C + p.eps);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        if (c < p.C) {
+            const f32x4 w = *reinterpret_cast<const f32x4*>(p.w + c);
+            const f32x4 b = *reinterpret_cast<const f32x4*>(p.b + c);
+            const f32x4 y = v[i] * rstd * w + b;
+            if (p.out32) *reinterpret_cast<f32x4*>(p.out32 + (size_t)row * p.C + c) = y;
+            if (p.out16) {
+                const v4 h = cvt4<T>(y);
+                *reinterpret_cast<v4*>(reinterpret_cast<T*>(p.out16) + (size_t)row * p.C + c) = h;
+                if (p.out16_lo) {
+                    const f32x4 hf = __builtin_convertvector(h, f32x4);
+                    *reinterpret_cast<v4*>(reinterpret_cast<T*>(p.out16_lo) + (size_t)row * p.C + c) = cvt4<T>(y - hf);
+                }
+            }
+        }
+    }
+}
+
+int launch_layernorm(DType dt, const LnArgs& a, hipStream_t s, const char** err) {
+    if (a.M <= 0) return 0;
+    if (a.C > 1024 || a.C % 4) { *err = "layernorm: C must be <= 1024 and a multiple of 4"; return 1; }
+    const int grid = (a.M + 3) / 4;
+    if (dt == DT_BF16) hipLaunchKernelGGL(ln_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(ln_kernel<f16_t>, dim3(grid), dim3(256), 0, s, a);
+    if (hipGetLastError() != hipSuccess) { *err = "layernorm: launch failed"; return 1; }
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// im2col for the 16x16/16 patch embedding: out[(v*N + t)*768 + c*256 + i*16 + j] = img[v][c][16gy+i][16gx+j]
+// one thread = 8 consecutive j (two float4 loads, one 16-byte store)
+// ------------------------------------------------------------------------------------------------
+template <class T>
+__global__ void im2col_kernel(const float* __restrict__ img, T* __restrict__ out, int V, int H, int W) {
+    typedef typename Vec<T>::v8 v8;
+    const int gh = H / 16, gw = W / 16;
+    const size_t total = (size_t)V * gh * gw * 96;  // 768/8 chunks per token
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int ch = (int)(idx % 96);
+        const size_t tok = idx / 96;
+        const int t = (int)(tok % (gh * gw));
+        const int v = (int)(tok / (gh * gw));
+        const int gy = t / gw, gx = t - gy * gw;
+        const int c = ch / 32, rem = ch - c * 32;
+        const int i = rem >> 1, j0 = (rem & 1) * 8;
+        const float* src = img + (((size_t)v * 3 + c) * H + gy * 16 + i) * W + gx * 16 + j0;
+        const f32x4 a = *reinterpret_cast<const f32x4*>(src);
+        const f32x4 b = *reinterpret_cast<const f32x4*>(src + 4);
+        const f32x8 f = __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+        *reinterpret_cast<v8*>(out + tok * 768 + ch * 8) = cvt8<T>(f);
+    }
+}
+
+int launch_im2col(DType dt, const float* img, void* out16, int V, int H, int W, hipStream_t s, const char** err) {
+    if (H % 16 || W % 16) { *err = "im2col: H and W must be multiples of 16"; return 1; }
+    const size_t total = (size_t)V * (H / 16) * (W / 16) * 96;
+    if (!total) return 0;
+    const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    if (dt == DT_BF16) hipLaunchKernelGGL(im2col_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, img, (bf16_t*)out16, V, H, W);
+    else hipLaunchKernelGGL(im2col_kernel<f16_t>, dim3(grid), dim3(256), 0, s, img, (f16_t*)out16, V, H, W);
+    if (hipGetLastError() != hipSuccess) { *err = "im2col: launch failed"; return 1; }
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// fp32 -> 16-bit (hi) and optional lo = T(x - float(hi))
+// ------------------------------------------------------------------------------------------------
+template <class T>
+__global__ void cast_kernel(const float* __restrict__ in, T* __restrict__ hi, T* __restrict__ lo, size_t n4) {
+    typedef typename Vec<T>::v4 v4;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        const f32x4 x = reinterpret_cast<const f32x4*>(in)[i];
+        const v4 h = cvt4<T>(x);
+        reinterpret_cast<v4*>(hi)[i] = h;
+        if (lo) reinterpret_cast<v4*>(lo)[i] = cvt4<T>(x - __builtin_convertvector(h, f32x4));
+    }
+}
+
+int launch_split16(DType dt, const float* in, void* hi, void* lo, size_t n, hipStream_t s, const char** err) {
+    if (n % 4) { *err = "cast: element count must be a multiple of 4"; return 1; }
+    if (!n) return 0;
+    const size_t n4 = n / 4;
+    const int grid = (int)((n4 + 255) / 256 < 8192 ? (n4 + 255) / 256 : 8192);
+    if (dt == DT_BF16) hipLaunchKernelGGL(cast_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, in, (bf16_t*)hi, (bf16_t*)lo, n4);
+    else hipLaunchKernelGGL(cast_kernel<f16_t>, dim3(grid), dim3(256), 0, s, in, (f16_t*)hi, (f16_t*)lo, n4);
+    if (hipGetLastError() != hipSuccess) { *err = "cast: launch failed"; return 1; }
+    return 0;
+}
+
+int launch_cast(DType dt, const float* in, void* out16, void* out16_lo, size_t n, hipStream_t s, const char** err) {
+    return launch_split16(dt, in, out16, out16_lo, n, s, err);
+}
+
+// ------------------------------------------------------------------------------------------------
+// positions: pos[v][gy*gw+gx] = (gy, gx)   (croco PositionGetter)
+// ------------------------------------------------------------------------------------------------
+__global__ void fill_pos_kernel(int64_t* pos, int V, int gh, int gw) {
+    const size_t total = (size_t)V * gh * gw;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int t = (int)(i % (gh * gw));
+        pos[i * 2 + 0] = t / gw;
+        pos[i * 2 + 1] = t % gw;
+    }
+}
+
+int launch_fill_pos(int64_t* pos, int V, int gh, int gw, hipStream_t s, const char** err) {
+    const size_t total = (size_t)V * gh * gw;
+    if (!total) return 0;
+    const int grid = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+    hipLaunchKernelGGL(fill_pos_kernel, dim3(grid), dim3(256), 0, s, pos, V, gh, gw);
+    if (hipGetLastError() != hipSuccess) { *err = "fill_pos: launch failed"; return 1; }
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// pointmap activation (engine/inference.py:19-27, tools/geometry.py:14-18):
+//   pts3d = v/max(|v|,1e-8) * expm1(|v|) on ch 0:3, same on ch 3:6, conf = 1 + exp(ch 6)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void norm_exp3(const float* v, float* o) {
+    const float d = sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+    const float sc = expm1f(d) / fmaxf(d, 1e-8f);
+    o[0] = v[0] * sc;
+    o[1] = v[1] * sc;
+    o[2] = v[2] * sc;
+}
+
+__global__ void postprocess_kernel(const float* __restrict__ pm, float* __restrict__ p3, float* __restrict__ pl,
+                                   float* __restrict__ cf, size_t npix) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += (size_t)gridDim.x * blockDim.x) {
+        float v[7];
+#pragma unroll
+        for (int k = 0; k < 7; ++k) v[k] = pm[i * 7 + k];
+        float a[3], b[3];
+        norm_exp3(v, a);
+        norm_exp3(v + 3, b);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            p3[i * 3 + k] = a[k];
+            pl[i * 3 + k] = b[k];
+        }
+        cf[i] = 1.0f + expf(v[6]);
+    }
+}
+
+int launch_postprocess(const float* pm, float* pts3d, float* pts3d_local, float* conf, size_t npix, hipStream_t s,
+                       const char** err) {
+    if (!npix) return 0;
+    const int grid = (int)((npix + 255) / 256 < 8192 ? (npix + 255) / 256 : 8192);
+    hipLaunchKernelGGL(postprocess_kernel, dim3(grid), dim3(256), 0, s, pm, pts3d, pts3d_local, conf, npix);
+    if (hipGetLastError() != hipSuccess) { *err = "postprocess: launch failed"; return 1; }
+    return 0;
+}
+
+}  // namespace m3r

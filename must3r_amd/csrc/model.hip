@@ -1,0 +1,822 @@
+// Native host runtime of libmust3r_hip: context, weight store, workspace arena and the two forwards
+// (per-view ViT-L encoder, ViT-B memory decoder) expressed as launches of the gfx950 kernels in
+// gemm.hip / attention.hip / misc.hip on the caller's HIP stream.  C ABI: include/must3r_hip.h.
+//
+// Algorithm citations are to the reference tree (must3r/model/...):
+//   encoder.py:46-52, blocks/layers.py:51-54,90-99, blocks/attention.py:37-149, decoder.py:158-350,
+//   feedback_mechanism.py:39-53, blocks/head.py:63-72, tools/image.py:9-14.
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/must3r_hip.h"
+#include "kernels.hpp"
+
+using namespace m3r;
+
+// ------------------------------------------------------------------------------------------------
+// error plumbing
+// ------------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+static int fail(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return 1;
+}
+#define HIP_OK(expr)                                                                              \
+    do {                                                                                          \
+        hipError_t e__ = (expr);                                                                  \
+        if (e__ != hipSuccess) return fail("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), __FILE__, __LINE__); \
+    } while (0)
+#define M3R_OK(expr)                  \
+    do {                              \
+        int rc__ = (expr);            \
+        if (rc__) return rc__;        \
+    } while (0)
+
+// ------------------------------------------------------------------------------------------------
+// context
+// ------------------------------------------------------------------------------------------------
+struct Param {
+    std::vector<int64_t> shape;
+    size_t n = 0;
+    float* d = nullptr;       // fp32 master on device
+    void* h16[2] = {nullptr, nullptr};   // packed 16-bit copy per dtype (lazy)
+    void* l16[2] = {nullptr, nullptr};   // low part (split precision), lazy, only where needed
+    bool loaded = false;
+    bool derived = false;     // built by finalize, not loaded
+};
+
+struct ProfEntry { hipEvent_t a, b; int cat; double flops; };
+enum ProfCat { PC_GEMM128 = 0, PC_GEMM64, PC_ATTN_SA, PC_ATTN_CA, PC_LN, PC_MISC, PC_COUNT };
+static const char* kProfNames[PC_COUNT] = {"gemm128", "gemm64", "attn_self", "attn_cross", "layernorm", "misc"};
+
+struct must3r_hip_ctx {
+    must3r_hip_config cfg;
+    int device = 0;
+    std::map<std::string, Param> params;
+    bool fin_enc = false, fin_dec = false;
+    float* rope_tab = nullptr;
+    int rope_npos = 0;
+    // workspace arena (grow-only)
+    char* ws = nullptr;
+    size_t ws_cap = 0, ws_off = 0;
+    // pinned staging for per-call view tables
+    static constexpr int kSlots = 32;
+    static constexpr size_t kSlotBytes = 64 * 1024;
+    char* pin = nullptr;
+    char* pin_dev = nullptr;
+    hipEvent_t slot_ev[kSlots];
+    bool slot_used[kSlots];
+    int slot_next = 0;
+    // profiling
+    bool prof = false;
+    std::vector<ProfEntry> prof_entries;
+    std::vector<hipEvent_t> ev_pool;
+    double prof_ms[PC_COUNT] = {0}, prof_flops[PC_COUNT] = {0};
+    long long prof_calls[PC_COUNT] = {0};
+};
+
+static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+static int ws_reserve(must3r_hip_ctx* c, size_t bytes, hipStream_t s) {
+    if (bytes <= c->ws_cap) { c->ws_off = 0; return 0; }
+    if (c->ws) {
+        HIP_OK(hipStreamSynchronize(s));
+        HIP_OK(hipDeviceSynchronize());
+        HIP_OK(hipFree(c->ws));
+        c->ws = nullptr;
+    }
+    const size_t cap = align_up(bytes + bytes / 8, 1 << 20);
+    HIP_OK(hipMalloc(reinterpret_cast<void**>(&c->ws), cap));
+    c->ws_cap = cap;
+    c->ws_off = 0;
+    return 0;
+}
+template <class T> static T* ws_take(must3r_hip_ctx* c, size_t count) {
+    const size_t off = align_up(c->ws_off, 256);
+    c->ws_off = off + count * sizeof(T);
+    if (c->ws_off > c->ws_cap) return nullptr;  // cannot happen if reserve() was sized with ws_need()
+    return reinterpret_cast<T*>(c->ws + off);
+}
+static size_t ws_need(size_t cur, size_t count, size_t elt) { return align_up(cur, 256) + count * elt; }
+
+// upload a small host table to device memory that stays valid until the stream has consumed it
+static int upload_table(must3r_hip_ctx* c, const void* host, size_t bytes, void** dev, hipStream_t s) {
+    if (bytes > must3r_hip_ctx::kSlotBytes) return fail("view table too large (%zu bytes)", bytes);
+    const int i = c->slot_next;
+    c->slot_next = (i + 1) % must3r_hip_ctx::kSlots;
+    if (c->slot_used[i]) HIP_OK(hipEventSynchronize(c->slot_ev[i]));
+    char* h = c->pin + (size_t)i * must3r_hip_ctx::kSlotBytes;
+    char* d = c->pin_dev + (size_t)i * must3r_hip_ctx::kSlotBytes;
+    memcpy(h, host, bytes);
+    HIP_OK(hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, s));
+    HIP_OK(hipEventRecord(c->slot_ev[i], s));
+    c->slot_used[i] = true;
+    *dev = d;
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// profiling helpers
+// ------------------------------------------------------------------------------------------------
+static hipEvent_t ev_get(must3r_hip_ctx* c) {
+    if (!c->ev_pool.empty()) { hipEvent_t e = c->ev_pool.back(); c->ev_pool.pop_back(); return e; }
+    hipEvent_t e;
+    (void)hipEventCreate(&e);
+    return e;
+}
+struct ProfScope {
+    must3r_hip_ctx* c; hipStream_t s; ProfEntry e; bool on;
+    ProfScope(must3r_hip_ctx* c_, hipStream_t s_, int cat, double flops) : c(c_), s(s_), on(c_ && c_->prof) {
+        if (on) { e.a = ev_get(c); e.b = ev_get(c); e.cat = cat; e.flops = flops; (void)hipEventRecord(e.a, s); }
+    }
+    ~ProfScope() { if (on) { (void)hipEventRecord(e.b, s); c->prof_entries.push_back(e); } }
+};
+static void prof_flush(must3r_hip_ctx* c) {
+    for (auto& e : c->prof_entries) {
+        (void)hipEventSynchronize(e.b);
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, e.a, e.b);
+        c->prof_ms[e.cat] += ms;
+        c->prof_flops[e.cat] += e.flops;
+        c->prof_calls[e.cat] += 1;
+        c->ev_pool.push_back(e.a);
+        c->ev_pool.push_back(e.b);
+    }
+    c->prof_entries.clear();
+}
+
+// ------------------------------------------------------------------------------------------------
+// launch wrappers
+// ------------------------------------------------------------------------------------------------
+static int gemm(must3r_hip_ctx* c, DType dt, Epi epi, GemmArgs a, hipStream_t s) {
+    const char* err = "";
+    const long tiles128 = (long)((a.M + 127) / 128) * (a.N / 128);
+    const int cat = (a.N % 128 == 0 && tiles128 >= 192) ? PC_GEMM128 : PC_GEMM64;
+    ProfScope ps(c, s, cat, 2.0 * a.M * a.N * a.K);
+    if (launch_gemm(dt, epi, a, s, &err)) return fail("%s (M=%d N=%d K=%d epi=%d)", err, a.M, a.N, a.K, (int)epi);
+    return 0;
+}
+static GemmArgs gargs(const void* A, const void* W, const float* bias, void* out, int M, int N, int K, int lda, int ldc) {
+    GemmArgs a;
+    memset(&a, 0, sizeof(a));
+    a.A = A; a.W = W; a.bias = bias; a.out = out; a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldc = ldc;
+    return a;
+}
+static int layernorm(must3r_hip_ctx* c, DType dt, const float* x, const float* add, const float* w, const float* b,
+                     void* o16, void* o16lo, float* o32, float* copy, int M, int C, float eps, hipStream_t s) {
+    const char* err = "";
+    LnArgs a{x, add, w, b, o16, o16lo, o32, copy, M, C, eps};
+    ProfScope ps(c, s, PC_LN, 0.0);
+    if (launch_layernorm(dt, a, s, &err)) return fail("%s", err);
+    return 0;
+}
+static int attention(must3r_hip_ctx* c, DType dt, const AttnArgs& a, double flops, int cat, hipStream_t s) {
+    const char* err = "";
+    ProfScope ps(c, s, cat, flops);
+    if (launch_attention(dt, a, s, &err)) return fail("%s", err);
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// parameters
+// ------------------------------------------------------------------------------------------------
+static void expect(must3r_hip_ctx* c, const std::string& name, std::vector<int64_t> shape) {
+    Param p;
+    p.shape = shape;
+    p.n = 1;
+    for (auto d : shape) p.n *= (size_t)d;
+    c->params[name] = p;
+}
+static void expect_linear(must3r_hip_ctx* c, const std::string& pfx, int64_t out, int64_t in) {
+    expect(c, pfx + ".weight", {out, in});
+    expect(c, pfx + ".bias", {out});
+}
+static void expect_ln(must3r_hip_ctx* c, const std::string& pfx, int64_t dim) {
+    expect(c, pfx + ".weight", {dim});
+    expect(c, pfx + ".bias", {dim});
+}
+
+static void build_expected(must3r_hip_ctx* c) {
+    const must3r_hip_config& g = c->cfg;
+    const int64_t C = g.enc_dim, D = g.dec_dim, p = g.patch_size, r = g.mlp_ratio;
+    expect(c, "encoder.patch_embed.proj.weight", {C, 3, p, p});
+    expect(c, "encoder.patch_embed.proj.bias", {C});
+    for (int i = 0; i < g.enc_depth; ++i) {
+        const std::string b = "encoder.blocks_enc." + std::to_string(i);
+        expect_ln(c, b + ".norm1", C);
+        expect_linear(c, b + ".attn.qkv", 3 * C, C);
+        expect_linear(c, b + ".attn.proj", C, C);
+        expect_ln(c, b + ".norm2", C);
+        expect_linear(c, b + ".mlp.fc1", r * C, C);
+        expect_linear(c, b + ".mlp.fc2", C, r * C);
+    }
+    expect_ln(c, "encoder.norm_enc", C);
+    expect(c, "decoder.image2_embed", {1, 1, D});
+    expect_linear(c, "decoder.feat_embed_enc_to_dec", D, C);
+    for (int i = 0; i < g.dec_depth; ++i) {
+        const std::string b = "decoder.blocks_dec." + std::to_string(i);
+        expect_ln(c, b + ".norm1", D);
+        expect_linear(c, b + ".attn.qkv", 3 * D, D);
+        expect_linear(c, b + ".attn.proj", D, D);
+        expect_ln(c, b + ".norm2", D);
+        expect_ln(c, b + ".norm_y", D);
+        expect_linear(c, b + ".cross_attn.projq", D, D);
+        expect_linear(c, b + ".cross_attn.projk", D, D);
+        expect_linear(c, b + ".cross_attn.projv", D, D);
+        expect_linear(c, b + ".cross_attn.proj", D, D);
+        expect_ln(c, b + ".norm3", D);
+        expect_linear(c, b + ".mlp.fc1", r * D, D);
+        expect_linear(c, b + ".mlp.fc2", D, r * D);
+    }
+    expect_linear(c, "decoder.feedback_layer.fc1", 4 * D, D);
+    expect_linear(c, "decoder.feedback_layer.fc2", D, 4 * D);
+    expect_ln(c, "decoder.feedback_norm", D);
+    expect_ln(c, "decoder.norm_dec", D);
+    expect_linear(c, "decoder.head_dec.proj", p * p * 7, D);
+}
+
+static Param* param(must3r_hip_ctx* c, const std::string& name) {
+    auto it = c->params.find(name);
+    return it == c->params.end() ? nullptr : &it->second;
+}
+static const float* p32(must3r_hip_ctx* c, const std::string& name) { return c->params.at(name).d; }
+
+// packed 16-bit copy (and optional low part) of a parameter, created on first use for a dtype
+static int p16(must3r_hip_ctx* c, const std::string& name, DType dt, bool want_lo, const void** hi, const void** lo,
+               hipStream_t s) {
+    Param& p = c->params.at(name);
+    const char* err = "";
+    if (!p.h16[dt] || (want_lo && !p.l16[dt])) {
+        if (!p.h16[dt]) HIP_OK(hipMalloc(&p.h16[dt], p.n * 2));
+        if (want_lo && !p.l16[dt]) HIP_OK(hipMalloc(&p.l16[dt], p.n * 2));
+        if (launch_split16(dt, p.d, p.h16[dt], want_lo ? p.l16[dt] : nullptr, p.n, s, &err)) return fail("%s", err);
+    }
+    *hi = p.h16[dt];
+    if (lo) *lo = p.l16[dt];
+    return 0;
+}
+static int w16(must3r_hip_ctx* c, const std::string& name, DType dt, const void** hi, hipStream_t s) {
+    return p16(c, name, dt, false, hi, nullptr, s);
+}
+
+extern "C" int must3r_hip_rope_table(float freq, float f0, int npos, float* out) {
+    // angle(p, i) = p * f0 * freq^(-i/16), i in [0,16)  (croco RoPE2D, head dim 64)
+    for (int p = 0; p < npos; ++p)
+        for (int i = 0; i < 16; ++i) {
+            const float inv = f0 / powf(freq, (float)i / 16.0f);
+            const float ang = (float)p * inv;
+            out[(p * 16 + i) * 2 + 0] = cosf(ang);
+            out[(p * 16 + i) * 2 + 1] = sinf(ang);
+        }
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// C ABI: lifetime / weights
+// ------------------------------------------------------------------------------------------------
+extern "C" int must3r_hip_abi_version(void) { return MUST3R_HIP_ABI_VERSION; }
+extern "C" const char* must3r_hip_last_error(void) { return g_err; }
+
+extern "C" int must3r_hip_create(const must3r_hip_config* cfg, int device, must3r_hip_ctx** out) {
+    if (!cfg || !out) return fail("create: null argument");
+    if (cfg->patch_size != 16) return fail("create: patch_size must be 16");
+    if (cfg->enc_dim != cfg->enc_heads * 64 || cfg->dec_dim != cfg->dec_heads * 64)
+        return fail("create: head dim must be 64 (enc %d/%d, dec %d/%d)", cfg->enc_dim, cfg->enc_heads, cfg->dec_dim, cfg->dec_heads);
+    if (cfg->enc_dim % 64 || cfg->dec_dim % 64 || cfg->enc_dim > 1024 || cfg->dec_dim > 1024)
+        return fail("create: feature dims must be multiples of 64 and <= 1024");
+    int ndev = 0;
+    HIP_OK(hipGetDeviceCount(&ndev));
+    if (ndev <= 0) return fail("create: no HIP device visible (the HIP path has no CPU fallback)");
+    if (device < 0 || device >= ndev) return fail("create: bad device %d", device);
+    HIP_OK(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIP_OK(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail("create: device is %s, this library is built for gfx950 only", prop.gcnArchName);
+    must3r_hip_ctx* c = new must3r_hip_ctx();
+    c->cfg = *cfg;
+    c->device = device;
+    build_expected(c);
+    if (hipHostMalloc(reinterpret_cast<void**>(&c->pin), must3r_hip_ctx::kSlots * must3r_hip_ctx::kSlotBytes) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void**>(&c->pin_dev), must3r_hip_ctx::kSlots * must3r_hip_ctx::kSlotBytes) != hipSuccess) {
+        delete c;
+        return fail("create: staging allocation failed");
+    }
+    for (int i = 0; i < must3r_hip_ctx::kSlots; ++i) {
+        (void)hipEventCreateWithFlags(&c->slot_ev[i], hipEventDisableTiming);
+        c->slot_used[i] = false;
+    }
+    *out = c;
+    return 0;
+}
+
+extern "C" void must3r_hip_destroy(must3r_hip_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipDeviceSynchronize();
+    for (auto& kv : c->params) {
+        Param& p = kv.second;
+        if (p.d) (void)hipFree(p.d);
+        for (int i = 0; i < 2; ++i) {
+            if (p.h16[i]) (void)hipFree(p.h16[i]);
+            if (p.l16[i]) (void)hipFree(p.l16[i]);
+        }
+    }
+    if (c->rope_tab) (void)hipFree(c->rope_tab);
+    if (c->ws) (void)hipFree(c->ws);
+    if (c->pin) (void)hipHostFree(c->pin);
+    if (c->pin_dev) (void)hipFree(c->pin_dev);
+    for (int i = 0; i < must3r_hip_ctx::kSlots; ++i) (void)hipEventDestroy(c->slot_ev[i]);
+    prof_flush(c);
+    for (auto e : c->ev_pool) (void)hipEventDestroy(e);
+    delete c;
+}
+
+extern "C" int must3r_hip_load_weight(must3r_hip_ctx* c, const char* name, const float* data, int is_device, int ndim,
+                                      const int64_t* shape) {
+    if (!c || !name || !data) return fail("load_weight: null argument");
+    Param* p = param(c, name);
+    if (!p || p->derived) return fail("load_weight: unexpected key '%s'", name);
+    bool same = (int)p->shape.size() == ndim;
+    for (int i = 0; same && i < ndim; ++i) same = p->shape[i] == shape[i];
+    if (!same) return fail("load_weight: shape mismatch for '%s'", name);
+    HIP_OK(hipSetDevice(c->device));
+    if (!p->d) HIP_OK(hipMalloc(reinterpret_cast<void**>(&p->d), p->n * sizeof(float)));
+    HIP_OK(hipMemcpy(p->d, data, p->n * sizeof(float), is_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
+    for (int i = 0; i < 2; ++i) {  // invalidate packed copies
+        if (p->h16[i]) { (void)hipFree(p->h16[i]); p->h16[i] = nullptr; }
+        if (p->l16[i]) { (void)hipFree(p->l16[i]); p->l16[i] = nullptr; }
+    }
+    p->loaded = true;
+    if (strncmp(name, "encoder.", 8) == 0) c->fin_enc = false; else c->fin_dec = false;
+    return 0;
+}
+
+static int derive(must3r_hip_ctx* c, const std::string& name, std::vector<int64_t> shape, const std::vector<float>& host) {
+    Param& p = c->params[name];
+    if (p.d) { (void)hipFree(p.d); p.d = nullptr; }
+    for (int i = 0; i < 2; ++i) {
+        if (p.h16[i]) { (void)hipFree(p.h16[i]); p.h16[i] = nullptr; }
+        if (p.l16[i]) { (void)hipFree(p.l16[i]); p.l16[i] = nullptr; }
+    }
+    p.shape = shape;
+    p.n = host.size();
+    p.derived = true;
+    p.loaded = true;
+    HIP_OK(hipMalloc(reinterpret_cast<void**>(&p.d), p.n * sizeof(float)));
+    HIP_OK(hipMemcpy(p.d, host.data(), p.n * sizeof(float), hipMemcpyHostToDevice));
+    return 0;
+}
+static int fetch(must3r_hip_ctx* c, const std::string& name, std::vector<float>& host) {
+    Param& p = c->params.at(name);
+    host.resize(p.n);
+    HIP_OK(hipMemcpy(host.data(), p.d, p.n * sizeof(float), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+extern "C" int must3r_hip_finalize_weights(must3r_hip_ctx* c, int parts) {
+    if (!c) return fail("finalize: null context");
+    if (!(parts & 3)) return fail("finalize: parts must include MUST3R_PART_ENCODER and/or MUST3R_PART_DECODER");
+    HIP_OK(hipSetDevice(c->device));
+    for (auto& kv : c->params) {
+        const bool is_enc = kv.first.compare(0, 8, "encoder.") == 0;
+        if (!((is_enc && (parts & 1)) || (!is_enc && (parts & 2)))) continue;
+        if (!kv.second.loaded && !kv.second.derived) return fail("finalize: missing key '%s'", kv.first.c_str());
+    }
+    // RoPE table for positions up to 256 (4096-pixel side), shared by both halves
+    {
+        c->rope_npos = 256;
+        std::vector<float> t((size_t)c->rope_npos * 32);
+        must3r_hip_rope_table(c->cfg.rope_freq, c->cfg.rope_f0, c->rope_npos, t.data());
+        if (!c->rope_tab) HIP_OK(hipMalloc(reinterpret_cast<void**>(&c->rope_tab), t.size() * sizeof(float)));
+        HIP_OK(hipMemcpy(c->rope_tab, t.data(), t.size() * sizeof(float), hipMemcpyHostToDevice));
+    }
+    if (parts & 1) c->fin_enc = true;
+    if (!(parts & 2)) return 0;
+    const must3r_hip_config& g = c->cfg;
+    const int D = g.dec_dim;
+    std::vector<float> a, b, o;
+    // fused K|V projection per decoder layer: rows [0,D) = projk, [D,2D) = projv  (layers.py:87-88 cat([k,v],-1))
+    for (int l = 0; l < g.dec_depth; ++l) {
+        const std::string pb = "decoder.blocks_dec." + std::to_string(l) + ".cross_attn.";
+        M3R_OK(fetch(c, pb + "projk.weight", a));
+        M3R_OK(fetch(c, pb + "projv.weight", b));
+        o = a; o.insert(o.end(), b.begin(), b.end());
+        M3R_OK(derive(c, pb + "projkv.weight", {2 * D, D}, o));
+        M3R_OK(fetch(c, pb + "projk.bias", a));
+        M3R_OK(fetch(c, pb + "projv.bias", b));
+        o = a; o.insert(o.end(), b.begin(), b.end());
+        M3R_OK(derive(c, pb + "projkv.bias", {2 * D}, o));
+    }
+    // pixel-shuffled head: new row (i*16+j)*7 + ch <- old row ch*256 + i*16 + j  (tools/image.py:9-14)
+    {
+        M3R_OK(fetch(c, "decoder.head_dec.proj.weight", a));
+        M3R_OK(fetch(c, "decoder.head_dec.proj.bias", b));
+        const int P = 256;
+        std::vector<float> w2(a.size()), b2(b.size());
+        for (int ch = 0; ch < 7; ++ch)
+            for (int ij = 0; ij < P; ++ij) {
+                const size_t nr = (size_t)ij * 7 + ch, orow = (size_t)ch * P + ij;
+                memcpy(&w2[nr * D], &a[orow * D], sizeof(float) * D);
+                b2[nr] = b[orow];
+            }
+        M3R_OK(derive(c, "decoder.head_dec.proj_ps.weight", {7 * P, D}, w2));
+        M3R_OK(derive(c, "decoder.head_dec.proj_ps.bias", {7 * P}, b2));
+    }
+    c->fin_dec = true;
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// encoder  (Dust3rEncoder.forward encoder.py:46-52)
+// ------------------------------------------------------------------------------------------------
+static int encode_chunk(must3r_hip_ctx* c, DType dt, const float* img, int V, int H, int W, float* out_tokens,
+                        int64_t* out_pos, hipStream_t s) {
+    const must3r_hip_config& g = c->cfg;
+    const int C = g.enc_dim, gh = H / 16, gw = W / 16, N = gh * gw, R = V * N, Hh = g.enc_heads, F = g.mlp_ratio * C;
+    const char* err = "";
+    size_t need = 0;
+    need = ws_need(need, (size_t)R * 768, 2);
+    need = ws_need(need, (size_t)R * C, 4);
+    need = ws_need(need, (size_t)R * C, 2);
+    need = ws_need(need, (size_t)R * 3 * C, 2);
+    need = ws_need(need, (size_t)R * C, 2);
+    need = ws_need(need, (size_t)R * F, 2);
+    M3R_OK(ws_reserve(c, need, s));
+    uint16_t* P16 = ws_take<uint16_t>(c, (size_t)R * 768);
+    float* x = ws_take<float>(c, (size_t)R * C);
+    uint16_t* h16 = ws_take<uint16_t>(c, (size_t)R * C);
+    uint16_t* qkv = ws_take<uint16_t>(c, (size_t)R * 3 * C);
+    uint16_t* a16 = ws_take<uint16_t>(c, (size_t)R * C);
+    uint16_t* g16 = ws_take<uint16_t>(c, (size_t)R * F);
+    if (!g16) return fail("encode: workspace sizing bug");
+
+    {
+        ProfScope ps(c, s, PC_MISC, 0.0);
+        if (launch_fill_pos(out_pos, V, gh, gw, s, &err)) return fail("%s", err);
+        if (launch_im2col(dt, img, P16, V, H, W, s, &err)) return fail("%s", err);
+    }
+    std::vector<AttnView> views(V);
+    for (int v = 0; v < V; ++v) views[v] = AttnView{v * N, N, v * N, N, 0, 0};
+    void* views_dev = nullptr;
+    M3R_OK(upload_table(c, views.data(), sizeof(AttnView) * V, &views_dev, s));
+
+    const void* w;
+    M3R_OK(w16(c, "encoder.patch_embed.proj.weight", dt, &w, s));
+    M3R_OK(gemm(c, dt, EPI_F32, gargs(P16, w, p32(c, "encoder.patch_embed.proj.bias"), x, R, C, 768, 768, C), s));
+    for (int l = 0; l < g.enc_depth; ++l) {
+        const std::string b = "encoder.blocks_enc." + std::to_string(l);
+        M3R_OK(layernorm(c, dt, x, nullptr, p32(c, b + ".norm1.weight"), p32(c, b + ".norm1.bias"), h16, nullptr, nullptr,
+                         nullptr, R, C, 1e-6f, s));
+        M3R_OK(w16(c, b + ".attn.qkv.weight", dt, &w, s));
+        GemmArgs ga = gargs(h16, w, p32(c, b + ".attn.qkv.bias"), qkv, R, 3 * C, C, C, 3 * C);
+        ga.pos = out_pos; ga.rope_tab = c->rope_tab; ga.rope_cols = 2 * C; ga.rope_npos = c->rope_npos;
+        M3R_OK(gemm(c, dt, EPI_QKV_ROPE, ga, s));
+        AttnArgs aa;
+        memset(&aa, 0, sizeof(aa));
+        aa.Q = qkv; aa.K = qkv + C; aa.V = qkv + 2 * C; aa.O = a16;
+        aa.ldq = aa.ldk = aa.ldv = 3 * C; aa.ldo = C; aa.heads = Hh;
+        aa.views = reinterpret_cast<const AttnView*>(views_dev); aa.nviews = V; aa.max_nq = N; aa.scale = 0.125f;
+        M3R_OK(attention(c, dt, aa, 4.0 * V * (double)N * N * C, PC_ATTN_SA, s));
+        M3R_OK(w16(c, b + ".attn.proj.weight", dt, &w, s));
+        M3R_OK(gemm(c, dt, EPI_RESID_F32, gargs(a16, w, p32(c, b + ".attn.proj.bias"), x, R, C, C, C, C), s));
+        M3R_OK(layernorm(c, dt, x, nullptr, p32(c, b + ".norm2.weight"), p32(c, b + ".norm2.bias"), h16, nullptr, nullptr,
+                         nullptr, R, C, 1e-6f, s));
+        M3R_OK(w16(c, b + ".mlp.fc1.weight", dt, &w, s));
+        M3R_OK(gemm(c, dt, EPI_STORE16_GELU, gargs(h16, w, p32(c, b + ".mlp.fc1.bias"), g16, R, F, C, C, F), s));
+        M3R_OK(w16(c, b + ".mlp.fc2.weight", dt, &w, s));
+        M3R_OK(gemm(c, dt, EPI_RESID_F32, gargs(g16, w, p32(c, b + ".mlp.fc2.bias"), x, R, C, F, F, C), s));
+    }
+    M3R_OK(layernorm(c, dt, x, nullptr, p32(c, "encoder.norm_enc.weight"), p32(c, "encoder.norm_enc.bias"), nullptr, nullptr,
+                     out_tokens, nullptr, R, C, 1e-6f, s));
+    return 0;
+}
+
+extern "C" int must3r_hip_encode(must3r_hip_ctx* c, int dtype, const float* img, int n_views, int H, int W,
+                                 float* out_tokens, int64_t* out_pos, void* stream) {
+    if (!c || !img || !out_tokens || !out_pos) return fail("encode: null argument");
+    if (!c->fin_enc) return fail("encode: encoder weights not finalized");
+    if (dtype != MUST3R_BF16 && dtype != MUST3R_F16) return fail("encode: bad dtype %d", dtype);
+    if (n_views <= 0) return 0;
+    if (H <= 0 || W <= 0 || H % 16 || W % 16) return fail("encode: H=%d W=%d must be positive multiples of 16", H, W);
+    if (H / 16 > c->rope_npos || W / 16 > c->rope_npos) return fail("encode: image too large for the RoPE table");
+    HIP_OK(hipSetDevice(c->device));
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const int N = (H / 16) * (W / 16);
+    int per = 24576 / N;  // bound the workspace: ~24k token rows per chunk
+    if (per < 1) per = 1;
+    for (int v0 = 0; v0 < n_views; v0 += per) {
+        const int nv = (n_views - v0 < per) ? n_views - v0 : per;
+        M3R_OK(encode_chunk(c, (DType)dtype, img + (size_t)v0 * 3 * H * W, nv, H, W, out_tokens + (size_t)v0 * N * c->cfg.enc_dim,
+                            out_pos + (size_t)v0 * N * 2, s));
+    }
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// decoder  (MUSt3R.forward_list decoder.py:158-265; forward :267-350 is the single-group case)
+// ------------------------------------------------------------------------------------------------
+extern "C" int must3r_hip_decode(must3r_hip_ctx* c, const must3r_hip_decode_args* A, void* stream) {
+    if (!c || !A || !A->groups || !A->mem) return fail("decode: null argument");
+    if (!c->fin_dec) return fail("decode: decoder weights not finalized");
+    if (A->dtype != MUST3R_BF16 && A->dtype != MUST3R_F16) return fail("decode: bad dtype %d", A->dtype);
+    if (A->mem_mode != MUST3R_MEM_KV) return fail("decode: only memory_mode 'kv' is implemented natively");
+    if (A->n_groups <= 0) return fail("decode: no input group");
+    if (A->render && (A->first_call || A->n_mem <= 0)) return fail("decode: render needs a memory (decoder.py:278)");
+    if (A->first_call && A->n_mem != 0) return fail("decode: first_call with a non-empty memory");
+    HIP_OK(hipSetDevice(c->device));
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const DType dt = (DType)A->dtype;
+    const must3r_hip_config& g = c->cfg;
+    const int C = g.enc_dim, D = g.dec_dim, Hh = g.dec_heads, F = g.mlp_ratio * D, L = g.dec_depth, Nm = A->n_mem;
+    const int OUT = g.patch_size * g.patch_size * 7;
+    const char* err = "";
+
+    // ---- row layout: groups, then views, then tokens (x_cat order, decoder.py:211-214)
+    int R = 0, total_views = 0, max_n = 0;
+    std::vector<int> grow0(A->n_groups);
+    for (int gi = 0; gi < A->n_groups; ++gi) {
+        const must3r_hip_group& G = A->groups[gi];
+        if (!G.tokens || !G.pos || !G.pointmaps) return fail("decode: null buffer in group %d", gi);
+        if (G.n_views <= 0 || G.n_tokens <= 0) return fail("decode: empty group %d", gi);
+        if (G.H % 16 || G.W % 16 || (G.H / 16) * (G.W / 16) != G.n_tokens)
+            return fail("decode: group %d: %dx%d does not give %d tokens", gi, G.H, G.W, G.n_tokens);
+        grow0[gi] = R;
+        R += G.n_views * G.n_tokens;
+        total_views += G.n_views;
+        if (G.n_tokens > max_n) max_n = G.n_tokens;
+    }
+    for (int l = 0; l < L; ++l)
+        if (!A->mem[l]) return fail("decode: null memory buffer for layer %d", l);
+    const bool update = !A->render;
+    const bool use_mask = update && (Nm > 0 || total_views > 1);       // decoder.py:199 / :293
+    const bool lone_view = update && total_views == 1 && Nm > 0;       // own tokens excluded -> keys = old memory only
+    const bool need_pre_kv = update && !lone_view;                     // pre-feedback K|V of the new tokens are attended
+
+    // ---- workspace
+    size_t need = 0;
+    need = ws_need(need, (size_t)R * C, 2);           // t16
+    need = ws_need(need, (size_t)R * D, 4);           // x
+    need = ws_need(need, (size_t)R * D, 2);           // h16
+    need = ws_need(need, (size_t)R * D, 2);           // hlo (head split)
+    need = ws_need(need, (size_t)R * 3 * D, 2);       // qkv
+    need = ws_need(need, (size_t)R * D, 2);           // q16
+    need = ws_need(need, (size_t)R * D, 2);           // a16
+    need = ws_need(need, (size_t)R * F, 2);           // g16
+    if (update) {
+        need = ws_need(need, (size_t)L * R * D, 4);   // memorised layer inputs
+        need = ws_need(need, (size_t)R * D, 4);       // feedback offset
+    }
+    M3R_OK(ws_reserve(c, need, s));
+    uint16_t* t16 = ws_take<uint16_t>(c, (size_t)R * C);
+    float* x = ws_take<float>(c, (size_t)R * D);
+    uint16_t* h16 = ws_take<uint16_t>(c, (size_t)R * D);
+    uint16_t* hlo = ws_take<uint16_t>(c, (size_t)R * D);
+    uint16_t* qkv = ws_take<uint16_t>(c, (size_t)R * 3 * D);
+    uint16_t* q16 = ws_take<uint16_t>(c, (size_t)R * D);
+    uint16_t* a16 = ws_take<uint16_t>(c, (size_t)R * D);
+    uint16_t* g16 = ws_take<uint16_t>(c, (size_t)R * F);
+    float* newmem = update ? ws_take<float>(c, (size_t)L * R * D) : nullptr;
+    float* off32 = update ? ws_take<float>(c, (size_t)R * D) : nullptr;
+    if (!g16 || (update && !off32)) return fail("decode: workspace sizing bug");
+
+    // ---- per-view tables: self-attention, cross-attention; positions gathered into one [R,2] array
+    std::vector<AttnView> tab(2 * (size_t)total_views);
+    double sa_flops = 0, ca_flops = 0;
+    {
+        int vi = 0;
+        for (int gi = 0; gi < A->n_groups; ++gi) {
+            const must3r_hip_group& G = A->groups[gi];
+            for (int j = 0; j < G.n_views; ++j, ++vi) {
+                const int r0 = grow0[gi] + j * G.n_tokens, n = G.n_tokens;
+                tab[vi] = AttnView{r0, n, r0, n, 0, 0};
+                AttnView cv{r0, n, 0, Nm, 0, 0};
+                if (update) {
+                    if (lone_view) { cv.nk = Nm; }
+                    else if (use_mask) { cv.nk = Nm + R; cv.skip_lo = Nm + r0; cv.skip_hi = Nm + r0 + n; }
+                    else { cv.nk = Nm + R; }  // first view alone: attends its own (pre-feedback) tokens
+                }
+                tab[total_views + vi] = cv;
+                sa_flops += 4.0 * n * (double)n * D;
+                ca_flops += 4.0 * n * (double)(cv.nk - (cv.skip_hi - cv.skip_lo)) * D;
+            }
+        }
+    }
+    void* tab_dev = nullptr;
+    M3R_OK(upload_table(c, tab.data(), sizeof(AttnView) * tab.size(), &tab_dev, s));
+    const AttnView* sa_views = reinterpret_cast<const AttnView*>(tab_dev);
+    const AttnView* ca_views = sa_views + total_views;
+    const int64_t* pos_all = A->groups[0].pos;  // single group: the caller's array is already [R,2]
+
+    // ---- tokens -> 16 bit, enc->dec projection + image2_embed  (decoder.py:172-181 / :275-287)
+    for (int gi = 0; gi < A->n_groups; ++gi) {
+        const must3r_hip_group& G = A->groups[gi];
+        ProfScope ps(c, s, PC_MISC, 0.0);
+        if (launch_cast(dt, G.tokens, t16 + (size_t)grow0[gi] * C, nullptr, (size_t)G.n_views * G.n_tokens * C, s, &err))
+            return fail("%s", err);
+    }
+    const void* w;
+    {
+        M3R_OK(w16(c, "decoder.feat_embed_enc_to_dec.weight", dt, &w, s));
+        GemmArgs ga = gargs(t16, w, p32(c, "decoder.feat_embed_enc_to_dec.bias"), x, R, D, C, C, D);
+        ga.bias2 = p32(c, "decoder.image2_embed");
+        ga.row_start2 = A->first_call ? A->groups[0].n_tokens : 0;  // reference view (group 0, view 0) gets no embed
+        M3R_OK(gemm(c, dt, EPI_F32, ga, s));
+    }
+    // several aspect ratios: gather the positions of all rows into one [R,2] array.  t16 is dead after the
+    // projection above (stream order) and is large enough (R*C*2 >= R*16 bytes).
+    if (A->n_groups > 1) {
+        int64_t* pos_ws = reinterpret_cast<int64_t*>(t16);
+        for (int gi = 0; gi < A->n_groups; ++gi) {
+            const must3r_hip_group& G = A->groups[gi];
+            HIP_OK(hipMemcpyAsync(pos_ws + (size_t)grow0[gi] * 2, G.pos, (size_t)G.n_views * G.n_tokens * 16,
+                                  hipMemcpyDeviceToDevice, s));
+        }
+        pos_all = pos_ws;
+    }
+
+    auto kv_project = [&](int l, const float* src, const float* add, float* copy, hipStream_t st) -> int {
+        // prepare_y in 'kv' mode (layers.py:81-88): LN(norm_y) -> [projk | projv] -> memory rows [Nm, Nm+R)
+        const std::string b = "decoder.blocks_dec." + std::to_string(l);
+        M3R_OK(layernorm(c, dt, src, add, p32(c, b + ".norm_y.weight"), p32(c, b + ".norm_y.bias"), h16, nullptr, nullptr, copy,
+                         R, D, 1e-6f, st));
+        const void* wk;
+        M3R_OK(w16(c, b + ".cross_attn.projkv.weight", dt, &wk, st));
+        uint16_t* dst = reinterpret_cast<uint16_t*>(A->mem[l]) + (size_t)Nm * 2 * D;
+        M3R_OK(gemm(c, dt, EPI_STORE16, gargs(h16, wk, p32(c, b + ".cross_attn.projkv.bias"), dst, R, 2 * D, D, D, 2 * D), st));
+        return 0;
+    };
+
+    for (int l = 0; l < L; ++l) {
+        const std::string b = "decoder.blocks_dec." + std::to_string(l);
+        if (need_pre_kv) M3R_OK(kv_project(l, x, nullptr, nullptr, s));
+        // --- self attention (layers.py:91)
+        M3R_OK(layernorm(c, dt, x, nullptr, p32(c, b + ".norm1.weight"), p32(c, b + ".norm1.bias"), h16, nullptr, nullptr,
+                         update ? newmem + (size_t)l * R * D : nullptr, R, D, 1e-6f, s));
+        M3R_OK(w16(c, b + ".attn.qkv.weight", dt, &w, s));
+        GemmArgs ga = gargs(h16, w, p32(c, b + ".attn.qkv.bias"), qkv, R, 3 * D, D, D, 3 * D);
+        ga.pos = pos_all; ga.rope_tab = c->rope_tab; ga.rope_cols = 2 * D; ga.rope_npos = c->rope_npos;
+        M3R_OK(gemm(c, dt, EPI_QKV_ROPE, ga, s));
+        AttnArgs aa;
+        memset(&aa, 0, sizeof(aa));
+        aa.Q = qkv; aa.K = qkv + D; aa.V = qkv + 2 * D; aa.O = a16;
+        aa.ldq = aa.ldk = aa.ldv = 3 * D; aa.ldo = D; aa.heads = Hh;
+        aa.views = sa_views; aa.nviews = total_views; aa.max_nq = max_n; aa.scale = 0.125f;
+        M3R_OK(attention(c, dt, aa, sa_flops, PC_ATTN_SA, s));
+        M3R_OK(w16(c, b + ".attn.proj.weight", dt, &w, s));
+        M3R_OK(gemm(c, dt, EPI_RESID_F32, gargs(a16, w, p32(c, b + ".attn.proj.bias"), x, R, D, D, D, D), s));
+        // --- cross attention over the memory (layers.py:92-97; attention.py:139-149)
+        M3R_OK(layernorm(c, dt, x, nullptr, p32(c, b + ".norm2.weight"), p32(c, b + ".norm2.bias"), h16, nullptr, nullptr, nullptr,
+                         R, D, 1e-6f, s));
+        M3R_OK(w16(c, b + ".cross_attn.projq.weight", dt, &w, s));
+        M3R_OK(gemm(c, dt, EPI_STORE16, gargs(h16, w, p32(c, b + ".cross_attn.projq.bias"), q16, R, D, D, D, D), s));
+        const uint16_t* mk = reinterpret_cast<const uint16_t*>(A->mem[l]);
+        memset(&aa, 0, sizeof(aa));
+        aa.Q = q16; aa.K = mk; aa.V = mk + D; aa.O = a16;
+        aa.ldq = D; aa.ldk = aa.ldv = 2 * D; aa.ldo = D; aa.heads = Hh;
+        aa.views = ca_views; aa.nviews = total_views; aa.max_nq = max_n; aa.scale = 0.125f;
+        M3R_OK(attention(c, dt, aa, ca_flops, PC_ATTN_CA, s));
+        M3R_OK(w16(c, b + ".cross_attn.proj.weight", dt, &w, s));
+        M3R_OK(gemm(c, dt, EPI_RESID_F32, gargs(a16, w, p32(c, b + ".cross_attn.proj.bias"), x, R, D, D, D, D), s));
+        // --- MLP (layers.py:98)
+        M3R_OK(layernorm(c, dt, x, nullptr, p32(c, b + ".norm3.weight"), p32(c, b + ".norm3.bias"), h16, nullptr, nullptr, nullptr,
+                         R, D, 1e-6f, s));
+        M3R_OK(w16(c, b + ".mlp.fc1.weight", dt, &w, s));
+        M3R_OK(gemm(c, dt, EPI_STORE16_GELU, gargs(h16, w, p32(c, b + ".mlp.fc1.bias"), g16, R, F, D, D, F), s));
+        M3R_OK(w16(c, b + ".mlp.fc2.weight", dt, &w, s));
+        M3R_OK(gemm(c, dt, EPI_RESID_F32, gargs(g16, w, p32(c, b + ".mlp.fc2.bias"), x, R, D, F, F, D), s));
+    }
+
+    if (update) {
+        // --- feedback (feedback_mechanism.py:39-53): offset = Mlp(LN_1e-5(new_mem[L-1])), added to layers 0..L-2
+        M3R_OK(layernorm(c, dt, newmem + (size_t)(L - 1) * R * D, nullptr, p32(c, "decoder.feedback_norm.weight"),
+                         p32(c, "decoder.feedback_norm.bias"), h16, nullptr, nullptr, nullptr, R, D, 1e-5f, s));
+        M3R_OK(w16(c, "decoder.feedback_layer.fc1.weight", dt, &w, s));
+        M3R_OK(gemm(c, dt, EPI_STORE16_GELU, gargs(h16, w, p32(c, "decoder.feedback_layer.fc1.bias"), g16, R, 4 * D, D, D, 4 * D), s));
+        M3R_OK(w16(c, "decoder.feedback_layer.fc2.weight", dt, &w, s));
+        M3R_OK(gemm(c, dt, EPI_F32, gargs(g16, w, p32(c, "decoder.feedback_layer.fc2.bias"), off32, R, D, 4 * D, 4 * D, D), s));
+        // --- stored memory = prepare_y(new_mem + offset) (decoder.py:236-239 / :327-330)
+        for (int l = 0; l < L; ++l)
+            M3R_OK(kv_project(l, newmem + (size_t)l * R * D, l < L - 1 ? off32 : nullptr, nullptr, s));
+    }
+
+    // --- prediction head in split precision (fp32-equivalent; decoder.py:149-156 runs it in fp32):
+    //     y = LN(x); out = y_hi W_hi + y_lo W_hi + y_hi W_lo + b, pixel-shuffled to [n,H,W,7]
+    M3R_OK(layernorm(c, dt, x, nullptr, p32(c, "decoder.norm_dec.weight"), p32(c, "decoder.norm_dec.bias"), h16, hlo, nullptr, nullptr,
+                     R, D, 1e-6f, s));
+    const void *whi, *wlo;
+    M3R_OK(p16(c, "decoder.head_dec.proj_ps.weight", dt, true, &whi, &wlo, s));
+    for (int gi = 0; gi < A->n_groups; ++gi) {
+        const must3r_hip_group& G = A->groups[gi];
+        const int Rg = G.n_views * G.n_tokens;
+        const uint16_t* yh = h16 + (size_t)grow0[gi] * D;
+        const uint16_t* yl = hlo + (size_t)grow0[gi] * D;
+        for (int pass = 0; pass < 3; ++pass) {
+            GemmArgs ga = gargs(pass == 1 ? yl : yh, pass == 2 ? wlo : whi, p32(c, "decoder.head_dec.proj_ps.bias"), G.pointmaps,
+                                Rg, OUT, D, D, 0);
+            ga.accumulate = pass > 0;
+            ga.ntok = G.n_tokens; ga.gw = G.W / 16; ga.H = G.H; ga.Wimg = G.W;
+            M3R_OK(gemm(c, dt, EPI_HEAD, ga, s));
+        }
+    }
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// postprocess + operator-level entry points + profiling
+// ------------------------------------------------------------------------------------------------
+extern "C" int must3r_hip_postprocess(const float* pm, float* p3, float* pl, float* cf, size_t npix, void* stream) {
+    const char* err = "";
+    if (!pm || !p3 || !pl || !cf) return fail("postprocess: null argument");
+    if (launch_postprocess(pm, p3, pl, cf, npix, reinterpret_cast<hipStream_t>(stream), &err)) return fail("%s", err);
+    return 0;
+}
+
+extern "C" int must3r_hip_op_gemm(int dtype, int epi, const void* A, const void* W, const float* bias, void* out, int M, int N,
+                                  int K, int lda, int ldc, const int64_t* pos, const float* rope_tab, int rope_cols,
+                                  int rope_npos, const float* bias2, int row_start2, int accumulate, int ntok, int gw, int H,
+                                  int W_img, void* stream) {
+    if (dtype != MUST3R_BF16 && dtype != MUST3R_F16) return fail("op_gemm: bad dtype");
+    if (epi < 0 || epi >= EPI_COUNT) return fail("op_gemm: bad epilogue");
+    GemmArgs a = gargs(A, W, bias, out, M, N, K, lda, ldc);
+    a.pos = pos; a.rope_tab = rope_tab; a.rope_cols = rope_cols; a.rope_npos = rope_npos;
+    a.bias2 = bias2; a.row_start2 = row_start2; a.accumulate = accumulate;
+    a.ntok = ntok; a.gw = gw; a.H = H; a.Wimg = W_img;
+    const char* err = "";
+    if (launch_gemm((DType)dtype, (Epi)epi, a, reinterpret_cast<hipStream_t>(stream), &err)) return fail("%s", err);
+    return 0;
+}
+
+extern "C" int must3r_hip_op_attention(int dtype, const void* Q, const void* K, const void* V, void* O, int ldq, int ldk, int ldv,
+                                       int ldo, int heads, const int32_t* views_dev, int n_views, int max_nq, void* stream) {
+    if (dtype != MUST3R_BF16 && dtype != MUST3R_F16) return fail("op_attention: bad dtype");
+    AttnArgs a;
+    memset(&a, 0, sizeof(a));
+    a.Q = Q; a.K = K; a.V = V; a.O = O; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo; a.heads = heads;
+    a.views = reinterpret_cast<const AttnView*>(views_dev); a.nviews = n_views; a.max_nq = max_nq; a.scale = 0.125f;
+    const char* err = "";
+    if (launch_attention((DType)dtype, a, reinterpret_cast<hipStream_t>(stream), &err)) return fail("%s", err);
+    return 0;
+}
+
+extern "C" int must3r_hip_op_layernorm(int dtype, const float* x, const float* add, const float* w, const float* b, void* out16,
+                                       void* out16_lo, float* out32, float* copy32, int M, int C, float eps, void* stream) {
+    if (dtype != MUST3R_BF16 && dtype != MUST3R_F16) return fail("op_layernorm: bad dtype");
+    LnArgs a{x, add, w, b, out16, out16_lo, out32, copy32, M, C, eps};
+    const char* err = "";
+    if (launch_layernorm((DType)dtype, a, reinterpret_cast<hipStream_t>(stream), &err)) return fail("%s", err);
+    return 0;
+}
+
+extern "C" int must3r_hip_op_im2col(int dtype, const float* img, void* out16, int n_views, int H, int W, void* stream) {
+    if (dtype != MUST3R_BF16 && dtype != MUST3R_F16) return fail("op_im2col: bad dtype");
+    const char* err = "";
+    if (launch_im2col((DType)dtype, img, out16, n_views, H, W, reinterpret_cast<hipStream_t>(stream), &err)) return fail("%s", err);
+    return 0;
+}
+
+extern "C" int must3r_hip_op_cast(int dtype, const float* in, void* out16, void* out16_lo, size_t n, void* stream) {
+    if (dtype != MUST3R_BF16 && dtype != MUST3R_F16) return fail("op_cast: bad dtype");
+    const char* err = "";
+    if (launch_cast((DType)dtype, in, out16, out16_lo, n, reinterpret_cast<hipStream_t>(stream), &err)) return fail("%s", err);
+    return 0;
+}
+
+extern "C" int must3r_hip_debug_tr_probe(void* out256_i16_dev, void* stream) {
+    if (!out256_i16_dev) return fail("tr_probe: null argument");
+    if (launch_tr_probe(reinterpret_cast<short*>(out256_i16_dev), reinterpret_cast<hipStream_t>(stream))) return fail("tr_probe: launch failed");
+    return 0;
+}
+
+extern "C" int must3r_hip_set_profiling(must3r_hip_ctx* c, int enabled) {
+    if (!c) return fail("set_profiling: null context");
+    prof_flush(c);
+    c->prof = enabled != 0;
+    return 0;
+}
+
+extern "C" int must3r_hip_get_profile(must3r_hip_ctx* c, must3r_hip_prof_record* out, int max, int reset) {
+    if (!c || !out) return 0;
+    prof_flush(c);
+    int n = 0;
+    for (int i = 0; i < PC_COUNT && n < max; ++i) {
+        memset(&out[n], 0, sizeof(out[n]));
+        strncpy(out[n].name, kProfNames[i], sizeof(out[n].name) - 1);
+        out[n].ms = c->prof_ms[i];
+        out[n].flops = c->prof_flops[i];
+        out[n].calls = c->prof_calls[i];
+        ++n;
+    }
+    if (reset)
+        for (int i = 0; i < PC_COUNT; ++i) { c->prof_ms[i] = 0; c->prof_flops[i] = 0; c->prof_calls[i] = 0; }
+    return n;
+}

@@ -1,0 +1,79 @@
+"""Callers' side of the forward path, restated MI355X-first.
+
+* ``postprocess`` -- must3r/engine/inference.py:16-48, activation part (:19-27) as one fused device kernel.
+* ``run_scene``   -- the BASELINE unit of work: encode V views, update the memory with
+  the demo schedule ``[2,1,...,1]`` (demo/inference.py:188-191; loop engine/inference.py:396-442), render all V
+  views against the final memory (engine/inference.py:489-522), fp32 activation.  Views are independent in the
+  encoder and in the render pass, so both run as ONE batched native call instead of the reference's per-view
+  Python loop; the memory update is inherently sequential and stays a loop of decoder calls.
+"""
+import torch
+
+from . import _lib
+from .model import ActivationType
+
+
+@torch.no_grad()
+def postprocess(pointmaps, pointmaps_activation=ActivationType.NORM_EXP, compute_cam=False):
+    """pointmaps [...,H,W,7] fp32 (cuda) -> dict(pts3d [...,3], pts3d_local [...,3], conf [...])."""
+    if compute_cam:
+        raise NotImplementedError("compute_cam (focal / pose estimation, engine/inference.py:29-47) is outside the "
+                                  "forward path (SURVEY.md section 8f, rank 1)")
+    if isinstance(pointmaps_activation, str):
+        pointmaps_activation = ActivationType(pointmaps_activation)
+    if pointmaps_activation != ActivationType.NORM_EXP or pointmaps.shape[-1] != 7:
+        raise NotImplementedError("fused postprocess handles the 7-channel NORM_EXP layout of the released models")
+    if not pointmaps.is_cuda:
+        raise RuntimeError("must3r_amd.postprocess: input is on CPU; the HIP path has no CPU fallback")
+    pm = pointmaps.float().contiguous()
+    lead = pm.shape[:-1]
+    npix = pm.numel() // 7
+    p3 = torch.empty((*lead, 3), dtype=torch.float32, device=pm.device)
+    pl = torch.empty((*lead, 3), dtype=torch.float32, device=pm.device)
+    cf = torch.empty(lead, dtype=torch.float32, device=pm.device)
+    lib = _lib.load()
+    _lib.check(lib.must3r_hip_postprocess(pm.data_ptr(), p3.data_ptr(), pl.data_ptr(), cf.data_ptr(), npix,
+                                          torch.cuda.current_stream(pm.device).cuda_stream))
+    return {"pts3d": p3, "pts3d_local": pl, "conf": cf}
+
+
+def demo_mem_batches(n_views, init_num_images=2, batch_num_views=1):
+    """demo/inference.py:188-191."""
+    if n_views <= init_num_images:
+        return [n_views]
+    rest = n_views - init_num_images
+    out = [init_num_images] + [batch_num_views] * (rest // batch_num_views)
+    if rest % batch_num_views:
+        out.append(rest % batch_num_views)
+    return out
+
+
+@torch.no_grad()
+def run_scene(encoder, decoder, imgs, true_shape, mem_batches=None, render_bs=None, activate=True, encoder_tokens=None):
+    """One scene with a single aspect ratio.  imgs fp32 [V,3,H,W] (cuda), true_shape int64 [V,2].
+
+    Returns dict(update=[V,H,W,7], render=[V,H,W,7], mem=mem_tuple, x, pos[, pts3d, pts3d_local, conf of the render])."""
+    V = imgs.shape[0]
+    if mem_batches is None:
+        mem_batches = demo_mem_batches(V)
+    if encoder_tokens is None:
+        x, pos = encoder(imgs, true_shape)
+    else:
+        x, pos = encoder_tokens
+    mem = None
+    upd = []
+    i = 0
+    for nb in mem_batches:
+        mem, pm = decoder(x[i:i + nb].unsqueeze(0), pos[i:i + nb].unsqueeze(0), true_shape[i:i + nb].unsqueeze(0), mem)
+        upd.append(pm[0])
+        i += nb
+    ren = []
+    bs = render_bs or V
+    for v0 in range(0, V, bs):
+        _, pm = decoder(x[v0:v0 + bs].unsqueeze(0), pos[v0:v0 + bs].unsqueeze(0), true_shape[v0:v0 + bs].unsqueeze(0), mem,
+                        render=True)
+        ren.append(pm[0])
+    out = {"update": torch.cat(upd, dim=0), "render": torch.cat(ren, dim=0), "mem": mem, "x": x, "pos": pos}
+    if activate:
+        out.update(postprocess(out["render"]))
+    return out

@@ -1,0 +1,85 @@
+"""Shared plumbing of the two HIP-backed modules: context lifetime, weight synchronisation,
+operand-dtype policy, stream handling."""
+import torch
+import torch.nn as nn
+
+from .. import _lib
+
+_DT = {"bf16": _lib.BF16, "fp16": _lib.F16, torch.bfloat16: _lib.BF16, torch.float16: _lib.F16}
+_TORCH_DT = {_lib.BF16: torch.bfloat16, _lib.F16: torch.float16}
+
+
+def operand_dtype(precision):
+    if precision not in _DT:
+        raise ValueError(f"precision must be 'bf16' or 'fp16', got {precision!r}")
+    return _DT[precision]
+
+
+def autocast_dtype():
+    """dtype the reference would run a Linear in right now (blocks/__init__.py:5-16 get_current_dtype)."""
+    try:
+        if torch.is_autocast_enabled():
+            return torch.get_autocast_gpu_dtype()
+    except Exception:
+        pass
+    return None
+
+
+class HipModule(nn.Module):
+    """nn.Module whose parameters are mirrored into a libmust3r_hip context on its device."""
+
+    _part = 0        # _lib.PART_ENCODER / PART_DECODER
+    _prefix = ""     # "encoder." / "decoder."
+
+    def _hip_init(self, cfg, precision):
+        self.cfg = cfg.validate()
+        self.precision = precision
+        operand_dtype(precision)
+        self._ctx = None
+        self._ctx_dev = None
+        self._synced = None
+
+    # -- weights -------------------------------------------------------------------------------
+    def _fingerprint(self):
+        return tuple((p.data_ptr(), p._version) for p in self.parameters())
+
+    def refresh_weights(self):
+        """Force a re-upload of all parameters on the next forward."""
+        self._synced = None
+
+    def _device_index(self):
+        p = next(self.parameters())
+        if not p.is_cuda:
+            raise RuntimeError(
+                "must3r_amd: the model is on %s; the HIP path needs an MI355X (gfx950) device and has no CPU "
+                "fallback -- move the module with .to('cuda')" % p.device)
+        return p.device.index if p.device.index is not None else torch.cuda.current_device()
+
+    def _context(self):
+        dev = self._device_index()
+        if self._ctx is None or self._ctx_dev != dev:
+            if self._ctx is not None:
+                self._ctx.close()
+            self._ctx = _lib.Context(self.cfg, dev)
+            self._ctx_dev = dev
+            self._synced = None
+        fp = self._fingerprint()
+        if self._synced != fp:
+            torch.cuda.synchronize(dev)
+            for k, v in self.state_dict().items():
+                self._ctx.load_weight(self._prefix + k, v)
+            self._ctx.finalize(self._part)
+            self._synced = fp
+        return self._ctx
+
+    @staticmethod
+    def _stream(dev):
+        return torch.cuda.current_stream(dev).cuda_stream
+
+    @staticmethod
+    def _check_input(t, name, dtype=None):
+        if not t.is_cuda:
+            raise RuntimeError(f"must3r_amd: `{name}` is on {t.device}; the HIP path has no CPU fallback")
+        if dtype is not None and t.dtype != dtype:
+            t = t.to(dtype)
+        return t.contiguous()

@@ -1,0 +1,242 @@
+"""``MUSt3R`` -- drop-in for must3r/model/decoder.py:14 backed by libmust3r_hip.
+
+Same constructor arguments, attributes (``pointmaps_activation``, ``memory_mode``,
+``change_memory_mode``, ``depth``, ``embed_dim``), state-dict keys and
+``forward(x, pos, true_shape, current_mem=None, render=False) -> (mem_tuple, pointmaps)`` contract with
+tensor or list inputs (decoder.py:158-350).  One forward = ONE native call (``must3r_hip_decode``).
+
+Memory tuple (decoder.py:337): ``(list[depth] of [1,Nm,mem_D], labels int64[1,Nm], n_imgs,
+n_protected_imgs, n_protected_tokens)``.  The value tensors are plain torch tensors the caller may index,
+overwrite or rebuild (engine/inference.py:205-228).  MI355X-first difference: they are prefix views of
+over-allocated per-layer buffers, so an update appends K|V rows in place instead of re-concatenating the
+whole memory every call (decoder.py:239/330 is O(Nm) HBM traffic per layer per call).  Appending is only
+done when the caller hands back exactly the newest view; anything else (boolean-indexed copies, an older
+tuple, another dtype) is copied into a fresh buffer first, so aliasing is never observable.
+
+Precision: operands follow the active ``torch.autocast`` dtype like the reference's Linear layers
+(demo/inference.py:198); without autocast ``self.precision`` is used.  Residual stream, LayerNorm,
+softmax, accumulators and the prediction head (decoder.py:152-153 forces fp32) are fp32 / fp32-equivalent.
+"""
+import ctypes as C
+from functools import partial
+
+import torch
+import torch.nn as nn
+
+from .. import _lib
+from ..config import ModelConfig
+from .blocks import (ActivationType, DecBlockParams, LinearHeadParams, MlpParams, MEMORY_MODES, init_weights,
+                     parse_pos_embed)
+from ._hip_module import HipModule, operand_dtype, autocast_dtype, _DT, _TORCH_DT
+
+_MEM_MODE = {"kv": _lib.MEM_KV, "norm_y": _lib.MEM_NORM_Y, "raw": _lib.MEM_RAW}
+
+
+class _MemBuffers:
+    """Per-layer over-allocated K|V buffers; ``valid`` = rows handed out by the newest view."""
+
+    def __init__(self, depth, cap, mem_D, dtype, device):
+        self.bufs = [torch.empty((1, cap, mem_D), dtype=dtype, device=device) for _ in range(depth)]
+        self.cap = cap
+        self.valid = 0
+
+    def views(self, n):
+        out = []
+        for b in self.bufs:
+            v = b[:, :n]
+            v._m3r_owner = self
+            out.append(v)
+        return out
+
+
+class MUSt3R(HipModule):
+    _part = _lib.PART_DECODER
+    _prefix = "decoder."
+
+    def __init__(self, img_size=(224, 224), enc_embed_dim=1024, patch_size=16, embed_dim=768, output_dim=1792,
+                 depth=12, num_heads=12, mlp_ratio=4, norm_layer=partial(nn.LayerNorm, eps=1e-6), act_layer=nn.GELU,
+                 pos_embed="RoPE100", landscape_only=True, head="Linear", feedback_type=None, memory_mode="norm_y",
+                 pointmaps_activation=ActivationType.NORM_EXP, block_type=None, precision="fp16", **kv):
+        super().__init__()
+        if isinstance(img_size, int):
+            img_size = (img_size, img_size)
+        assert memory_mode in MEMORY_MODES
+        if head != "Linear":
+            raise ValueError(f"invalid head {head}")  # decoder.py:80
+        if feedback_type != "single_mlp":
+            raise NotImplementedError("must3r_amd implements feedback_type='single_mlp' (the released checkpoints); "
+                                      f"got {feedback_type!r}")
+        assert output_dim == patch_size * patch_size * 7
+        self.pointmaps_activation = pointmaps_activation
+        self.depth = depth
+        self.embed_dim = embed_dim
+        self.memory_mode = memory_mode
+        self.attn_num_heads = num_heads
+        self.feedback_type = feedback_type
+        self.landscape_only = landscape_only
+        self.max_seq_len = max(img_size) // patch_size
+        self.grid_size = (img_size[0] // patch_size, img_size[1] // patch_size)
+        freq, f0 = parse_pos_embed(pos_embed)
+        # parameters, reference attribute names (decoder.py:49-83)
+        self.feat_embed_enc_to_dec = nn.Linear(enc_embed_dim, embed_dim, bias=True)
+        self.image2_embed = nn.Parameter(torch.zeros(1, 1, embed_dim))
+        self.blocks_dec = nn.ModuleList([DecBlockParams(embed_dim, mlp_ratio, memory_mode) for _ in range(depth)])
+        self.feedback_layer = MlpParams(embed_dim, 4 * embed_dim, embed_dim)
+        self.feedback_norm = nn.LayerNorm(embed_dim)  # default eps 1e-5 (feedback_mechanism.py:14)
+        self.norm_dec = nn.LayerNorm(embed_dim, eps=1e-6)
+        self.head_dec = LinearHeadParams(embed_dim, output_dim, patch_size)
+        init_weights(self)
+        torch.nn.init.normal_(self.image2_embed, std=0.02)
+        nn.init.constant_(self.feedback_layer.fc2.bias, 0)    # feedback_mechanism.py:26-36
+        nn.init.constant_(self.feedback_layer.fc2.weight, 0)
+        self._hip_init(ModelConfig(img_size=max(img_size), patch_size=patch_size, enc_dim=enc_embed_dim,
+                                   enc_heads=enc_embed_dim // 64, dec_dim=embed_dim, dec_depth=depth, dec_heads=num_heads,
+                                   mlp_ratio=mlp_ratio, rope_freq=freq, rope_f0=f0), precision)
+
+    # -- reference API -------------------------------------------------------------------------
+    def change_memory_mode(self, memory_mode="norm_y"):  # decoder.py:113-117
+        assert memory_mode in MEMORY_MODES
+        for blk in self.blocks_dec:
+            blk.memory_mode = memory_mode
+        self.memory_mode = memory_mode
+
+    def from_dust3r(self, state_dict, verbose=True, load_head=False):  # decoder.py:85-94
+        state_dict = {k.replace("dec_blocks.", "blocks_dec.").replace("decoder_embed.", "feat_embed_enc_to_dec.").replace(
+            "dec_norm.", "norm_dec."): v for k, v in state_dict.items()}
+        if load_head:
+            state_dict = {k.replace("downstream_head.proj.", "head_dec.proj."): v for k, v in state_dict.items()}
+        inc = self.load_state_dict(state_dict, strict=False)
+        if verbose:
+            print(inc)
+        return inc
+
+    def from_croco(self, state_dict, verbose=True):
+        return self.from_dust3r(state_dict, verbose=verbose)
+
+    def _operand(self):
+        ac = autocast_dtype()
+        if ac in (torch.bfloat16, torch.float16):
+            return _DT[ac]
+        return operand_dtype(self.precision)
+
+    # -- memory management ---------------------------------------------------------------------
+    def _writable_memory(self, mem_vals, Nm, R, tdt, device):
+        """Return (buffers, pointers) whose rows [0,Nm) hold ``mem_vals`` and that can take R more rows."""
+        mem_D = 2 * self.embed_dim if self.memory_mode == "kv" else self.embed_dim
+        owner = None
+        if mem_vals is not None and len(mem_vals) == self.depth:
+            owner = getattr(mem_vals[0], "_m3r_owner", None)
+            ok = owner is not None and owner.valid == Nm and owner.cap >= Nm + R
+            if ok:
+                for v, b in zip(mem_vals, owner.bufs):
+                    if getattr(v, "_m3r_owner", None) is not owner or v.data_ptr() != b.data_ptr() or v.dtype != tdt \
+                            or v.shape[1] != Nm or v.device != b.device:
+                        ok = False
+                        break
+            if not ok:
+                owner = None
+        if owner is None:
+            cap = max(Nm + R, 2 * Nm, 1024)
+            owner = _MemBuffers(self.depth, cap, mem_D, tdt, device)
+            if Nm > 0:
+                for v, b in zip(mem_vals, owner.bufs):
+                    b[:, :Nm].copy_(v.reshape(1, Nm, mem_D))
+        return owner
+
+    # -- forward -------------------------------------------------------------------------------
+    @torch.no_grad()
+    def forward(self, x, pos, true_shape, current_mem=None, render=False, return_feats=False):
+        is_list = isinstance(x, (list, tuple))
+        if return_feats and not is_list:
+            # intermediate features are never materialised by the fused native path (inference callers do not ask:
+            # engine/inference.py:190; the reference's list path silently ignores the flag, decoder.py:270)
+            raise NotImplementedError("return_feats=True is not available on the HIP path")
+        if self.memory_mode != "kv":
+            raise NotImplementedError(
+                f"memory_mode={self.memory_mode!r}: the native decoder keeps the memory as projected K|V "
+                "(memory_mode='kv', what the released 512 checkpoints use); call change_memory_mode('kv')")
+        xs = list(x) if is_list else [x]
+        poss = list(pos) if is_list else [pos]
+        shapes = list(true_shape) if is_list else [true_shape]
+        ctx = self._context()
+        dev = self._ctx_dev
+        device = torch.device("cuda", dev)
+        odt = self._operand()
+        tdt = _TORCH_DT[odt]
+        D = self.embed_dim
+        assert not render or current_mem is not None  # decoder.py:278
+
+        groups = (_lib.Group * len(xs))()
+        keep = []
+        outs = []
+        R = 0
+        nimgs, Ns = [], []
+        for i, (xi, pi, ti) in enumerate(zip(xs, poss, shapes)):
+            B, n, N, Cenc = xi.shape
+            if B != 1:
+                raise NotImplementedError("must3r_amd decodes one scene (B=1) per call, like every inference caller "
+                                          "(engine/inference.py:185-188)")
+            xi = self._check_input(xi, "x", torch.float32)
+            pi = self._check_input(pi, "pos", torch.int64)
+            ts = ti.reshape(-1, 2)
+            assert bool((ts[0:1] == ts).all()), "true_shape must be all identical"  # head.py:31
+            H, W = (int(v) for v in ts[0].tolist())
+            assert (H // 16) * (W // 16) == N, (H, W, N)
+            pm = torch.empty((1, n, H, W, 7), dtype=torch.float32, device=device)
+            keep += [xi, pi]
+            outs.append(pm)
+            groups[i] = _lib.Group(xi.data_ptr(), pi.data_ptr(), n, N, H, W, pm.data_ptr())
+            R += n * N
+            nimgs.append(n)
+            Ns.append(N)
+
+        if current_mem is None:
+            mem_vals, mem_labels, mem_nimgs, mem_prot_imgs, mem_prot_tok = None, torch.zeros((1, 0), dtype=torch.int64,
+                                                                                            device=device), 0, 0, 0
+            Nm = 0
+        else:
+            mem_vals, mem_labels, mem_nimgs, mem_prot_imgs, mem_prot_tok = current_mem
+            Nm = int(mem_vals[0].shape[1])
+
+        if render:
+            vals = []
+            for v in mem_vals:
+                if not v.is_cuda or v.dtype != tdt or not v.is_contiguous():
+                    v = v.to(device=device, dtype=tdt).contiguous()
+                vals.append(v)
+            ptrs = (C.c_void_p * self.depth)(*[v.data_ptr() for v in vals])
+            keep += vals
+        else:
+            owner = self._writable_memory(mem_vals, Nm, R, tdt, device)
+            ptrs = (C.c_void_p * self.depth)(*[b.data_ptr() for b in owner.bufs])
+
+        args = _lib.DecodeArgs(odt, _MEM_MODE[self.memory_mode], 1 if render else 0, 1 if current_mem is None else 0,
+                               len(xs), groups, Nm, ptrs)
+        _lib.check(ctx.lib.must3r_hip_decode(ctx.handle, C.byref(args), self._stream(dev)))
+
+        if render:
+            out = (mem_vals, mem_labels, mem_nimgs, mem_prot_imgs, mem_prot_tok)  # decoder.py:252 / :339
+        else:
+            owner.valid = Nm + R
+            new_vals = owner.views(Nm + R)
+            labels = []
+            k = 0
+            for n, N in zip(nimgs, Ns):  # decoder.py:241-249 / :332-334
+                labels.append((torch.arange(n, dtype=torch.int64, device=device) + (mem_nimgs + k)).repeat_interleave(N).view(1, -1))
+                k += n
+            mem_labels = torch.cat([mem_labels.to(device)] + labels, dim=1)
+            tot = mem_nimgs + sum(nimgs)
+            out = (new_vals, mem_labels, tot, tot, mem_labels.shape[1])
+        return out, (outs if is_list else outs[0])
+
+    def forward_list(self, x, pos, true_shape, current_mem=None, render=False, return_feats=False):  # decoder.py:158
+        return self.forward(list(x), list(pos), list(true_shape), current_mem, render, False)
+
+
+class CausalMUSt3R(MUSt3R):
+    """Training class of the reference (decoder.py:353).  Not part of the inference forward path; kept only so
+    that checkpoint constructor strings naming it resolve (model/__init__.py:53-63 rewrites them to MUSt3R)."""
+
+    def __init__(self, *a, **k):
+        raise NotImplementedError("CausalMUSt3R is the reference's training module and is out of scope; "
+                                  "use convert_decoder_args() / load_model()")

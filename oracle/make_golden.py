@@ -1,0 +1,91 @@
+"""TEST INFRASTRUCTURE ONLY.  Generates ``tests/golden/*.npz`` by running the REAL reference
+(``/root/reference/must3r/model``, imported verbatim on top of ``oracle/ref_shims.py``) on seeded
+synthetic weights / images (``must3r_amd.synthetic``).  Run in the build container only:
+
+    python oracle/make_golden.py
+
+The reference tree does not exist on the GPU box, so the outputs are committed as small fixtures
+(full-size cases are sub-sampled; every case also stores sums as a coarse checksum of the full tensor).
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.dont_write_bytecode = True
+
+from oracle import ref_shims  # noqa: E402
+from must3r_amd.config import TINY, SMALL, MUST3R_224  # noqa: E402
+from must3r_amd import synthetic as S  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+
+CASES = {
+    # name: (cfg, H, W, V, mem_batches, pixel stride, token stride)
+    "tiny_48x64_v4": (TINY, 48, 64, 4, [2, 1, 1], 1, 1),
+    "small_224_v3": (SMALL, 224, 224, 3, [2, 1], 4, 4),
+    "must3r224_v2": (MUST3R_224, 224, 224, 2, [2], 8, 7),   # BASELINE.json configs[0]
+}
+
+
+def run_reference(cfg, H, W, V, mem_batches, seed=0):
+    sde, sdd = S.make_encoder_state_dict(cfg, seed), S.make_decoder_state_dict(cfg, seed)
+    imgs, ts = S.make_images(V, H, W, seed)
+    enc, dec = ref_shims.build_reference(cfg, sde, sdd, "kv")
+    with torch.no_grad():
+        x, pos = enc(imgs, ts)
+        mem = None
+        upd = []
+        i = 0
+        for nb in mem_batches:
+            mem, pm = dec(x[i:i + nb].unsqueeze(0), pos[i:i + nb].unsqueeze(0), ts[i:i + nb].unsqueeze(0), mem)
+            upd.append(pm[0])
+            i += nb
+        _, ren = dec(x.unsqueeze(0), pos.unsqueeze(0), ts.unsqueeze(0), mem, render=True)
+    return x, pos, torch.cat(upd, 0), ren[0], mem
+
+
+def main():
+    torch.set_num_threads(os.cpu_count() or 8)
+    os.makedirs(OUT, exist_ok=True)
+    for name, (cfg, H, W, V, mb, ps, tks) in CASES.items():
+        x, pos, upd, ren, mem = run_reference(cfg, H, W, V, mb)
+        np.savez_compressed(
+            os.path.join(OUT, name + ".npz"),
+            meta=np.array([H, W, V, ps, tks] + mb, dtype=np.int64),
+            x=x[:, ::tks, ::tks].numpy(), x_sum=np.float64(x.double().sum().item()),
+            x_abs=np.float64(x.double().abs().sum().item()),
+            pos=pos[:, ::tks].numpy(),
+            update=upd[:, ::ps, ::ps].numpy(), update_abs=np.float64(upd.double().abs().sum().item()),
+            render=ren[:, ::ps, ::ps].numpy(), render_abs=np.float64(ren.double().abs().sum().item()),
+            mem_first=mem[0][0][0, ::tks, ::tks].numpy(), mem_last=mem[0][-1][0, ::tks, ::tks].numpy(),
+            labels=mem[1].numpy(), tail=np.array(mem[2:], dtype=np.int64))
+        print(name, "x", tuple(x.shape), "update", tuple(upd.shape), "render", tuple(ren.shape), "Nm", mem[0][0].shape[1])
+
+    # mixed aspect ratios through forward_list (tiny geometry): init with [2 x 48x64, 1 x 32x64], update with
+    # [1 x 32x64, 2 x 48x64], render both groups
+    cfg = TINY
+    sde, sdd = S.make_encoder_state_dict(cfg, 0), S.make_decoder_state_dict(cfg, 0)
+    enc, dec = ref_shims.build_reference(cfg, sde, sdd, "kv")
+    ia, ta = S.make_images(2, 48, 64, 1)
+    ib, tb = S.make_images(1, 32, 64, 2)
+    L = lambda *t: [v.unsqueeze(0) for v in t]  # noqa: E731
+    with torch.no_grad():
+        xa, pa = enc(ia, ta)
+        xb, pb = enc(ib, tb)
+        mem, pm0 = dec(L(xa, xb), L(pa, pb), L(ta, tb), None)
+        mem2, pm1 = dec(L(xb, xa), L(pb, pa), L(tb, ta), mem)
+        _, pm2 = dec(L(xb, xa), L(pb, pa), L(tb, ta), mem2, render=True)
+    np.savez_compressed(os.path.join(OUT, "tiny_mixed_ar.npz"),
+                        init_a=pm0[0][0].numpy(), init_b=pm0[1][0].numpy(),
+                        upd_b=pm1[0][0].numpy(), upd_a=pm1[1][0].numpy(),
+                        ren_b=pm2[0][0].numpy(), ren_a=pm2[1][0].numpy(),
+                        mem_last=mem2[0][-1][0].numpy(), labels=mem2[1].numpy(), tail=np.array(mem2[2:], dtype=np.int64))
+    print("tiny_mixed_ar ok, Nm", mem2[0][0].shape[1])
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,106 @@
+"""CPU: host-side logic of the product package and the C-ABI surface (no compute calls -- no GPU here)."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+from conftest import ROOT
+from must3r_amd import _lib, synthetic as S
+from must3r_amd.config import TINY, MUST3R_512
+from must3r_amd.engine import demo_mem_batches
+import must3r_amd.model as M
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "must3r_hip.h")).read()
+    declared = sorted(set(re.findall(r"\b(must3r_hip_[a-z0-9_]+)\s*\(", hdr)))
+    assert set(declared) == set(_lib.EXPORTS), set(declared) ^ set(_lib.EXPORTS)
+    assert os.path.exists(_lib.LIB_PATH), "build the extension first: python -c 'import __graft_entry__ as g; g.build()'"
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert _lib.load().must3r_hip_abi_version() == _lib.ABI_VERSION
+
+
+def test_rope_table_host_entry_point():
+    lib = _lib.load()
+    buf = (ctypes.c_float * (8 * 32))()
+    assert lib.must3r_hip_rope_table(100.0, 1.0, 8, buf) == 0
+    t = torch.tensor(list(buf)).view(8, 16, 2)
+    from oracle import must3r_ref as R
+    cos, sin = R.rope_tables(8, 100.0, 1.0, 32)
+    assert torch.allclose(t[..., 0], cos, atol=1e-6) and torch.allclose(t[..., 1], sin, atol=1e-6)
+
+
+def test_create_without_gpu_fails_loudly():
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(_lib.HipError):
+        _lib.Context(TINY, 0)
+
+
+def test_modules_have_reference_state_dict_keys_and_refuse_cpu():
+    cfg = TINY
+    enc = M.Dust3rEncoder(img_size=(cfg.img_size,) * 2, embed_dim=cfg.enc_dim, depth=cfg.enc_depth, num_heads=cfg.enc_heads)
+    dec = M.MUSt3R(img_size=(cfg.img_size,) * 2, enc_embed_dim=cfg.enc_dim, embed_dim=cfg.dec_dim, depth=cfg.dec_depth,
+                   num_heads=cfg.dec_heads, feedback_type="single_mlp", memory_mode="kv", mem_dropout=0.1,
+                   use_xformers_mask=True)  # training kwargs are swallowed like decoder.py:37
+    sde, sdd = S.make_encoder_state_dict(cfg, 0), S.make_decoder_state_dict(cfg, 0)
+    assert set(enc.state_dict()) == set(sde) and set(dec.state_dict()) == set(sdd)
+    for k, v in enc.state_dict().items():
+        assert tuple(v.shape) == tuple(sde[k].shape), k
+    enc.load_state_dict(sde, strict=True)
+    dec.load_state_dict(sdd, strict=True)
+    assert float(dec.feedback_layer.fc2.weight.abs().sum()) > 0
+    assert enc.patch_size == 16 and enc.embed_dim == cfg.enc_dim and dec.memory_mode == "kv"
+    assert M.get_pointmaps_activation(dec, verbose=False) == M.ActivationType.NORM_EXP
+    imgs, ts = S.make_images(1, 32, 32, 0)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        enc(imgs, ts)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        dec(torch.zeros(1, 1, 4, cfg.enc_dim), torch.zeros(1, 1, 4, 2, dtype=torch.int64), torch.tensor([[[32, 32]]]))
+    dec.change_memory_mode("norm_y")
+    assert all(b.memory_mode == "norm_y" for b in dec.blocks_dec)
+
+
+def test_full_size_key_contract():
+    # key names / shapes of the released geometry without allocating the model
+    sde = S.make_encoder_state_dict(TINY, 0)
+    assert "patch_embed.proj.weight" in sde and "blocks_enc.1.mlp.fc2.bias" in sde and "norm_enc.weight" in sde
+    assert MUST3R_512.output_dim == 1792 and MUST3R_512.enc_dim // MUST3R_512.enc_heads == 64
+
+
+def test_arg_rewriting():
+    s = M.convert_decoder_args("CausalMUSt3R(img_size=(512, 512), feedback_type='single_mlp', memory_mode=\"kv\")")
+    assert s == "MUSt3R(img_size=(512,512),feedback_type='single_mlp',memory_mode=\"kv\",landscape_only=False)"
+    s2 = M.set_image_size_in_args("MUSt3R(img_size=(224, 224))", 512, verbose=False)
+    assert s2 == "MUSt3R(img_size=(512,512),pos_embed='RoPE100_224:512')"
+    assert M.set_image_size_in_args("MUSt3R(img_size=(512,512),pos_embed='RoPE100')", 512, verbose=False) == \
+        "MUSt3R(img_size=(512,512),pos_embed='RoPE100')"
+    from must3r_amd.model.blocks import parse_pos_embed
+    assert parse_pos_embed("RoPE100") == (100.0, 1.0) and parse_pos_embed("RoPE100_224:512") == (100.0, 224 / 512)
+
+
+def test_load_model_roundtrip_on_cpu(tmp_path):
+    cfg = TINY
+    class A:  # noqa: E301
+        encoder = f"Dust3rEncoder(img_size=({cfg.img_size},{cfg.img_size}),embed_dim={cfg.enc_dim},depth={cfg.enc_depth},num_heads={cfg.enc_heads})"
+        decoder = (f"CausalMUSt3R(img_size=({cfg.img_size}, {cfg.img_size}), enc_embed_dim={cfg.enc_dim}, embed_dim={cfg.dec_dim}, "
+                   f"depth={cfg.dec_depth}, num_heads={cfg.dec_heads}, feedback_type='single_mlp', memory_mode='kv', mem_dropout=0.1)")
+    import argparse
+    ns = argparse.Namespace(encoder=A.encoder, decoder=A.decoder)
+    p = tmp_path / "ckpt.pth"
+    torch.save({"args": ns, "encoder": S.make_encoder_state_dict(cfg, 1), "decoder": S.make_decoder_state_dict(cfg, 1)}, p)
+    enc, dec = M.load_model(str(p), device="cpu", verbose=False)
+    assert isinstance(enc, M.Dust3rEncoder) and isinstance(dec, M.MUSt3R) and not enc.training
+    assert torch.equal(dec.image2_embed, S.make_decoder_state_dict(cfg, 1)["image2_embed"])
+    enc2, dec2 = M.load_model(str(p), device="cpu", img_size=128, verbose=False)
+    assert dec2.cfg.rope_f0 == 64 / 128 and dec2.cfg.img_size == 128
+
+
+def test_demo_mem_batches():
+    assert demo_mem_batches(20) == [2] + [1] * 18          # demo/inference.py:188-191 defaults
+    assert demo_mem_batches(2) == [2] and demo_mem_batches(1) == [1]
+    assert demo_mem_batches(7, 2, 2) == [2, 2, 2, 1]

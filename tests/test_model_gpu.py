@@ -1,0 +1,195 @@
+"""GPU (-m gpu): the two HIP forwards behind the reference's nn.Module API against
+(a) the committed fixtures produced by the REAL reference (tests/golden), (b) the fp32 CPU oracle on the
+same seeded inputs, and (c) size-independent properties at the BASELINE geometry (512x384, ViT-L/ViT-B)."""
+import numpy as np
+import pytest
+import torch
+
+from must3r_amd import synthetic as S
+from must3r_amd.config import TINY, SMALL, MUST3R_224, MUST3R_512
+from util import TOL, load_golden, rel_inf, rel_l2
+from test_ops_gpu import record
+
+pytestmark = pytest.mark.gpu
+
+CASES = {"tiny_48x64_v4": TINY, "small_224_v3": SMALL, "must3r224_v2": MUST3R_224}
+_models = {}
+
+
+def build(cfg, precision, seed=0):
+    """HIP-backed modules with the seeded synthetic weights, cached per (cfg, precision)."""
+    import must3r_amd.model as M
+    key = (cfg, precision, seed)
+    if key not in _models:
+        enc = M.Dust3rEncoder(img_size=(cfg.img_size,) * 2, embed_dim=cfg.enc_dim, depth=cfg.enc_depth, num_heads=cfg.enc_heads,
+                              precision=precision)
+        dec = M.MUSt3R(img_size=(cfg.img_size,) * 2, enc_embed_dim=cfg.enc_dim, embed_dim=cfg.dec_dim, depth=cfg.dec_depth,
+                       num_heads=cfg.dec_heads, feedback_type="single_mlp", memory_mode="kv", landscape_only=False,
+                       precision=precision)
+        enc.load_state_dict(S.make_encoder_state_dict(cfg, seed), strict=True)
+        dec.load_state_dict(S.make_decoder_state_dict(cfg, seed), strict=True)
+        _models[key] = (enc.cuda().eval(), dec.cuda().eval())
+    return _models[key]
+
+
+def hip_scene(cfg, precision, H, W, V, mb, seed=0):
+    from must3r_amd.engine import run_scene
+    enc, dec = build(cfg, precision)
+    imgs, ts = S.make_images(V, H, W, seed)
+    out = run_scene(enc, dec, imgs.cuda(), ts.cuda(), mem_batches=mb)
+    torch.cuda.synchronize()
+    return out
+
+
+@pytest.mark.parametrize("precision", ["fp16", "bf16"])
+@pytest.mark.parametrize("name", list(CASES))
+def test_scene_matches_reference_fixture(name, precision):
+    g = load_golden(name)
+    H, W, V, ps, tks = (int(v) for v in g["meta"][:5])
+    mb = [int(v) for v in g["meta"][5:]]
+    out = hip_scene(CASES[name], precision, H, W, V, mb)
+    tol = TOL[precision]
+    x, upd, ren, mem = out["x"].cpu(), out["update"].cpu(), out["render"].cpu(), out["mem"]
+    errs = dict(x=rel_inf(x[:, ::tks, ::tks], g["x"]), update=rel_inf(upd[:, ::ps, ::ps], g["update"]),
+                render=rel_inf(ren[:, ::ps, ::ps], g["render"]), render_l2=rel_l2(ren[:, ::ps, ::ps], g["render"]),
+                mem_first=rel_inf(mem[0][0][0, ::tks, ::tks].float().cpu(), g["mem_first"]),
+                mem_last=rel_inf(mem[0][-1][0, ::tks, ::tks].float().cpu(), g["mem_last"]),
+                render_maxabs=float((ren[:, ::ps, ::ps] - torch.from_numpy(g["render"])).abs().max()))
+    record("scene_vs_fixture", case=name, precision=precision, **errs)
+    assert np.array_equal(out["pos"].cpu()[:, ::tks].numpy(), g["pos"])
+    assert np.array_equal(mem[1].cpu().numpy(), g["labels"]) and [int(v) for v in mem[2:]] == [int(v) for v in g["tail"]]
+    assert torch.isfinite(ren).all() and torch.isfinite(upd).all()
+    assert errs["x"] < tol and errs["update"] < tol and errs["render"] < tol, errs
+    # memory is stored as 16-bit K|V: one extra rounding on top of the path error
+    u = 2.0 ** -8 if precision == "bf16" else 2.0 ** -11
+    assert errs["mem_first"] < tol + u and errs["mem_last"] < tol + u, errs
+
+
+@pytest.mark.parametrize("precision", ["fp16", "bf16"])
+def test_mixed_aspect_ratio_list_path(precision):
+    g = load_golden("tiny_mixed_ar")
+    enc, dec = build(TINY, precision)
+    ia, ta = S.make_images(2, 48, 64, 1)
+    ib, tb = S.make_images(1, 32, 64, 2)
+    L = lambda *t: [v.unsqueeze(0) for v in t]  # noqa: E731
+    xa, pa = enc(ia.cuda(), ta.cuda())
+    xb, pb = enc(ib.cuda(), tb.cuda())
+    ta, tb = ta.cuda(), tb.cuda()
+    mem, pm0 = dec(L(xa, xb), L(pa, pb), L(ta, tb), None)
+    mem2, pm1 = dec(L(xb, xa), L(pb, pa), L(tb, ta), mem)
+    mem3, pm2 = dec(L(xb, xa), L(pb, pa), L(tb, ta), mem2, render=True)
+    assert mem3[0] is mem2[0] and mem3[2:] == mem2[2:]          # render returns the memory untouched (decoder.py:339)
+    tol = TOL[precision]
+    errs = {}
+    for got, key in ((pm0[0], "init_a"), (pm0[1], "init_b"), (pm1[0], "upd_b"), (pm1[1], "upd_a"), (pm2[0], "ren_b"), (pm2[1], "ren_a")):
+        errs[key] = rel_inf(got[0].cpu(), g[key])
+    record("mixed_ar", precision=precision, **errs)
+    assert max(errs.values()) < tol, errs
+    assert np.array_equal(mem2[1].cpu().numpy(), g["labels"]) and [int(v) for v in mem2[2:]] == [int(v) for v in g["tail"]]
+    assert rel_inf(mem2[0][-1][0].float().cpu(), g["mem_last"]) < tol + 2.0 ** -8
+
+
+def test_forward_list_equals_forward_and_memory_cow():
+    """SURVEY.md section 4 invariant 2, plus the append-in-place memory never aliases observable state."""
+    enc, dec = build(TINY, "fp16")
+    imgs, ts = S.make_images(4, 48, 64, 7)
+    imgs, ts = imgs.cuda(), ts.cuda()
+    x, pos = enc(imgs, ts)
+    m_t, p_t = dec(x[:2].unsqueeze(0), pos[:2].unsqueeze(0), ts[:2].unsqueeze(0), None)
+    m_l, p_l = dec([x[:2].unsqueeze(0)], [pos[:2].unsqueeze(0)], [ts[:2].unsqueeze(0)], None)
+    assert torch.equal(p_t, p_l[0]) and all(torch.equal(a, b) for a, b in zip(m_t[0], m_l[0]))
+    snap = [v.clone() for v in m_t[0]]
+    # branch twice from the same memory (SLAM pattern: non-keyframe results are discarded, slam/model.py:520-521)
+    m_a, p_a = dec(x[2:3].unsqueeze(0), pos[2:3].unsqueeze(0), ts[2:3].unsqueeze(0), m_t)
+    keep_a = [v.clone() for v in m_a[0]]
+    m_b, p_b = dec(x[3:4].unsqueeze(0), pos[3:4].unsqueeze(0), ts[3:4].unsqueeze(0), m_t)
+    assert all(torch.equal(a, b) for a, b in zip(m_t[0], snap)), "old memory view changed"
+    assert all(torch.equal(a, b) for a, b in zip(m_a[0], keep_a)), "first branch was clobbered by the second"
+    m_a2, p_a2 = dec(x[2:3].unsqueeze(0), pos[2:3].unsqueeze(0), ts[2:3].unsqueeze(0), m_t)
+    assert torch.equal(p_a, p_a2) and all(torch.equal(a, b) for a, b in zip(m_a[0], m_a2[0]))
+    assert m_a[2:] == (3, 3, 36) and m_a[1].shape == (1, 36)
+
+
+def test_caller_side_memory_surgery():
+    """engine/inference.py:205-214 _remove_from_mem: the caller boolean-indexes the memory; the next call must
+    accept the rebuilt tensors and equal the oracle run on the same edited memory."""
+    from oracle import must3r_ref as R
+    cfg = TINY
+    enc, dec = build(cfg, "fp16")
+    sdd = S.make_decoder_state_dict(cfg, 0)
+    imgs, ts = S.make_images(3, 48, 64, 0)
+    x, pos = enc(imgs.cuda(), ts.cuda())
+    tsc = ts.cuda()
+    mem, _ = dec(x[:2].unsqueeze(0), pos[:2].unsqueeze(0), tsc[:2].unsqueeze(0), None)
+    mem, _ = dec(x[2:].unsqueeze(0), pos[2:].unsqueeze(0), tsc[2:].unsqueeze(0), mem)
+    keep = mem[1] != 1                                        # drop view 1
+    vals = [v[keep].view(1, -1, v.shape[-1]) for v in mem[0]]
+    labels = mem[1][keep].view(1, -1)
+    edited = (vals, labels, mem[2], mem[3], mem[4])
+    _, pm = dec(x.unsqueeze(0), pos.unsqueeze(0), tsc.unsqueeze(0), edited, render=True)
+    mem_cpu = ([v.float().cpu() for v in vals], labels.cpu(), mem[2], mem[3], mem[4])
+    _, ref = R.decoder_forward(sdd, cfg, x.cpu().unsqueeze(0), pos.cpu().unsqueeze(0), ts.unsqueeze(0), mem_cpu, True, "kv")
+    e = rel_inf(pm.cpu(), ref)
+    record("memory_surgery", err=e)
+    assert e < TOL["fp16"], e
+    # and an update on top of the edited memory appends after the surviving rows
+    mem2, _ = dec(x[1:2].unsqueeze(0), pos[1:2].unsqueeze(0), tsc[1:2].unsqueeze(0), edited)
+    assert mem2[0][0].shape[1] == 24 + 12 and torch.equal(mem2[0][3][:, :24], vals[3])
+
+
+@pytest.mark.parametrize("precision", ["fp16", "bf16"])
+def test_baseline_geometry_vs_oracle_and_properties(precision):
+    """MUSt3R_512 (ViT-L enc / ViT-B dec), 384x512.  Oracle comparison on 2 views (CPU cost ~20 s) plus
+    size-independent properties on 5 views: batch-invariance of the encoder and of the render pass (bit-exact),
+    render does not modify the memory, labels."""
+    from oracle import must3r_ref as R
+    cfg = MUST3R_512
+    H, W, V = 384, 512, 5
+    enc, dec = build(cfg, precision)
+    imgs, ts = S.make_images(V, H, W, 0)
+    imgs_c, ts_c = imgs.cuda(), ts.cuda()
+    x, pos = enc(imgs_c, ts_c)
+    x1, pos1 = enc(imgs_c[3:4], ts_c[3:4])
+    assert torch.equal(x1[0], x[3]) and torch.equal(pos1[0], pos[3]), "encoder is not batch-invariant"
+    mem = None
+    for a, b in ((0, 2), (2, 3), (3, 4), (4, 5)):
+        mem, _ = dec(x[a:b].unsqueeze(0), pos[a:b].unsqueeze(0), ts_c[a:b].unsqueeze(0), mem)
+    assert mem[0][0].shape == (1, V * 768, 1536) and mem[2:] == (V, V, V * 768)
+    assert torch.equal(mem[1].cpu(), torch.arange(V).repeat_interleave(768).view(1, -1))
+    snap = [v.clone() for v in mem[0]]
+    mem_r, ren = dec(x.unsqueeze(0), pos.unsqueeze(0), ts_c.unsqueeze(0), mem, render=True)
+    assert mem_r[0] is mem[0] and all(torch.equal(a, b) for a, b in zip(mem[0], snap))
+    _, ren1 = dec(x[2:3].unsqueeze(0), pos[2:3].unsqueeze(0), ts_c[2:3].unsqueeze(0), mem, render=True)
+    assert torch.equal(ren1[0, 0], ren[0, 2]), "render pass is not per-view independent"
+    assert torch.isfinite(ren).all()
+    # oracle on the first two views (init call + render)
+    torch.set_num_threads(max(1, torch.get_num_threads()))
+    sde, sdd = S.make_encoder_state_dict(cfg, 0), S.make_decoder_state_dict(cfg, 0)
+    with torch.no_grad():
+        xo, po = R.encoder_forward(sde, cfg, imgs[:2], ts[:2], sdpa=True)
+        memo, updo = R.decoder_forward(sdd, cfg, xo.unsqueeze(0), po.unsqueeze(0), ts[:2].unsqueeze(0), None, False, "kv", sdpa=True)
+        _, reno = R.decoder_forward(sdd, cfg, xo.unsqueeze(0), po.unsqueeze(0), ts[:2].unsqueeze(0), memo, True, "kv", sdpa=True)
+    mem2, upd = dec(x[:2].unsqueeze(0), pos[:2].unsqueeze(0), ts_c[:2].unsqueeze(0), None)
+    _, ren2 = dec(x[:2].unsqueeze(0), pos[:2].unsqueeze(0), ts_c[:2].unsqueeze(0), mem2, render=True)
+    errs = dict(x=rel_inf(x[:2].cpu(), xo), update=rel_inf(upd.cpu(), updo), render=rel_inf(ren2.cpu(), reno),
+                render_l2=rel_l2(ren2.cpu(), reno), render_maxabs=float((ren2.cpu() - reno).abs().max()))
+    record("baseline_geometry_vs_oracle", precision=precision, **errs)
+    tol = TOL[precision]
+    assert errs["x"] < tol and errs["update"] < tol and errs["render"] < tol, errs
+
+
+def test_autocast_selects_operand_dtype():
+    enc, dec = build(TINY, "fp16")
+    imgs, ts = S.make_images(2, 48, 64, 0)
+    x, pos = enc(imgs.cuda(), ts.cuda())
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        mem, _ = dec(x.unsqueeze(0), pos.unsqueeze(0), ts.cuda().unsqueeze(0), None)
+    assert mem[0][0].dtype == torch.bfloat16       # memory dtype follows autocast like decoder.py:142 / blocks/__init__.py:5
+    mem, _ = dec(x.unsqueeze(0), pos.unsqueeze(0), ts.cuda().unsqueeze(0), None)
+    assert mem[0][0].dtype == torch.float16
+    with pytest.raises(NotImplementedError):
+        dec.change_memory_mode("norm_y")
+        try:
+            dec(x.unsqueeze(0), pos.unsqueeze(0), ts.cuda().unsqueeze(0), None)
+        finally:
+            dec.change_memory_mode("kv")

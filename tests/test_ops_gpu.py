@@ -1,0 +1,291 @@
+"""GPU (-m gpu): every HIP kernel alone, through the C ABI, against an fp64 torch evaluation of the same
+16-bit-rounded operands (so only accumulation order and output rounding differ)."""
+import ctypes as C
+import json
+import math
+import os
+
+import pytest
+import torch
+
+from conftest import ROOT
+from util import rel_inf
+
+pytestmark = pytest.mark.gpu
+
+DT = {"bf16": (0, torch.bfloat16, 2.0 ** -8), "fp16": (1, torch.float16, 2.0 ** -11)}  # id, torch dtype, unit round-off
+
+
+def record(name, **kw):
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", "test_metrics.jsonl"), "a") as f:
+        f.write(json.dumps({"test": name, **kw}) + "\n")
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from must3r_amd import _lib
+    return _lib
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def P(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def run_gemm(lib, dt, epi, A, W, bias, out, ldc=None, pos=None, tab=None, rope_cols=0, npos=0, bias2=None, row2=0, acc=0,
+             ntok=0, gw=0, H=0, Wimg=0):
+    M, K = A.shape
+    N = W.shape[0]
+    L = lib.load()
+    lib.check(L.must3r_hip_op_gemm(DT[dt][0], epi, P(A), P(W), P(bias), P(out), M, N, K, A.stride(0),
+                                   ldc if ldc is not None else N, P(pos), P(tab), rope_cols, npos, P(bias2), row2, acc,
+                                   ntok, gw, H, Wimg, stream()))
+    torch.cuda.synchronize()
+
+
+def test_transposing_lds_read_mapping(lib):
+    """ds_read_b64_tr_b16: inside a 16-lane group the 16 8-byte chunks form a 4x16 row-major matrix and lane i gets
+    column i (common.hpp lds_read_tr4).  The attention kernel's V^T operand depends on exactly this."""
+    out = torch.full((256,), -1, dtype=torch.int16, device="cuda")
+    lib.check(lib.load().must3r_hip_debug_tr_probe(P(out), stream()))
+    torch.cuda.synchronize()
+    got = out.cpu().view(64, 4).tolist()
+    record("tr_probe", mapping=got)
+    exp = [[(l // 16) * 64 + (l % 16) + 16 * e for e in range(4)] for l in range(64)]
+    assert got == exp, got
+
+
+SHAPES = [(200, 128, 64), (768, 768, 768), (1000, 1024, 256), (3072, 1024, 512), (3000, 2304, 768), (196, 3072, 1024),
+          (12, 128, 128)]
+
+
+@pytest.mark.parametrize("dt", ["bf16", "fp16"])
+@pytest.mark.parametrize("shape", SHAPES)
+def test_gemm_store_gelu_resid_f32(lib, dt, shape):
+    M, N, K = shape
+    g = torch.Generator(device="cuda").manual_seed(M * 7 + N)
+    tdt, u = DT[dt][1], DT[dt][2]
+    A = (torch.randn((M, K), device="cuda", generator=g)).to(tdt)
+    W = (torch.randn((N, K), device="cuda", generator=g) / math.sqrt(K)).to(tdt)
+    bias = torch.randn((N,), device="cuda", generator=g)
+    ref = A.double() @ W.double().t() + bias.double()
+    # 16-bit store
+    out = torch.empty((M, N), device="cuda", dtype=tdt)
+    run_gemm(lib, dt, lib.EPI_STORE16, A, W, bias, out)
+    e1 = rel_inf(out, ref)
+    assert torch.allclose(out.double(), ref, rtol=2 * u, atol=2 * u), e1
+    # asymmetric check: transposed result must NOT match (catches row/col swaps on square shapes)
+    if M == N:
+        assert not torch.allclose(out.double().t(), ref, rtol=2 * u, atol=2 * u)
+    # GELU
+    run_gemm(lib, dt, lib.EPI_STORE16_GELU, A, W, bias, out)
+    refg = torch.nn.functional.gelu(ref)
+    e2 = rel_inf(out, refg)
+    assert torch.allclose(out.double(), refg, rtol=2 * u, atol=2 * u), e2
+    # residual: x += A W^T + b
+    x0 = torch.randn((M, N), device="cuda", generator=g)
+    x = x0.clone()
+    run_gemm(lib, dt, lib.EPI_RESID_F32, A, W, bias, x)
+    e3 = rel_inf(x, x0.double() + ref)
+    assert torch.allclose(x.double(), x0.double() + ref, rtol=1e-5, atol=1e-4), e3
+    # fp32 out + second bias on rows >= row2, then accumulate
+    b2 = torch.randn((N,), device="cuda", generator=g)
+    row2 = M // 3
+    o32 = torch.empty((M, N), device="cuda")
+    run_gemm(lib, dt, lib.EPI_F32, A, W, bias, o32, bias2=b2, row2=row2)
+    ref2 = ref.clone()
+    ref2[row2:] += b2.double()
+    e4 = rel_inf(o32, ref2)
+    assert torch.allclose(o32.double(), ref2, rtol=1e-5, atol=1e-4), e4
+    run_gemm(lib, dt, lib.EPI_F32, A, W, bias, o32, acc=1)
+    assert torch.allclose(o32.double(), ref2 + (ref - bias.double()), rtol=1e-5, atol=2e-4)
+    record("gemm", dt=dt, shape=shape, store=e1, gelu=e2, resid=e3, f32=e4)
+
+
+@pytest.mark.parametrize("dt", ["bf16", "fp16"])
+@pytest.mark.parametrize("geom", [(2, 14, 14, 128), (1, 24, 32, 768), (3, 3, 4, 1024)])
+def test_gemm_qkv_rope(lib, dt, geom):
+    from oracle import must3r_ref as R
+    V, gh, gw, Cdim = geom
+    N = gh * gw
+    M = V * N
+    Hn = Cdim // 64
+    g = torch.Generator(device="cuda").manual_seed(5)
+    tdt, u = DT[dt][1], DT[dt][2]
+    A = torch.randn((M, Cdim), device="cuda", generator=g).to(tdt)
+    W = (torch.randn((3 * Cdim, Cdim), device="cuda", generator=g) / math.sqrt(Cdim)).to(tdt)
+    bias = torch.randn((3 * Cdim,), device="cuda", generator=g) * 0.1
+    ys, xs = torch.meshgrid(torch.arange(gh), torch.arange(gw), indexing="ij")
+    pos = torch.stack((ys.reshape(-1), xs.reshape(-1)), -1).view(1, N, 2).expand(V, -1, -1).contiguous()
+    npos = 64
+    buf = (C.c_float * (npos * 32))()
+    lib.load().must3r_hip_rope_table(100.0, 1.0, npos, buf)
+    tab = torch.tensor(list(buf), device="cuda")
+    out = torch.empty((M, 3 * Cdim), device="cuda", dtype=tdt)
+    run_gemm(lib, dt, lib.EPI_QKV_ROPE, A, W, bias, out, pos=pos.cuda().view(M, 2), tab=tab, rope_cols=2 * Cdim, npos=npos)
+    lin = (A.double() @ W.double().t() + bias.double()).cpu().view(V, N, 3, Hn, 64)
+    q, k, v = (lin[:, :, i].permute(0, 2, 1, 3).float() for i in range(3))
+    q = R.rope2d(q, pos)
+    k = R.rope2d(k, pos)
+    ref = torch.stack((q, k, v), dim=2).permute(0, 3, 2, 1, 4).reshape(M, 3 * Cdim)  # [V,N,3,H,64]
+    e = rel_inf(out.cpu(), ref)
+    record("gemm_rope", dt=dt, geom=geom, err=e)
+    assert torch.allclose(out.cpu().double(), ref.double(), rtol=2 * u, atol=4 * u), e
+
+
+@pytest.mark.parametrize("dt", ["bf16", "fp16"])
+def test_gemm_head_pixel_shuffle(lib, dt):
+    nv, gh, gw, D = 2, 3, 4, 128
+    H, Wd, N = gh * 16, gw * 16, gh * gw
+    g = torch.Generator(device="cuda").manual_seed(9)
+    tdt = DT[dt][1]
+    A = torch.randn((nv * N, D), device="cuda", generator=g).to(tdt)
+    W = (torch.randn((1792, D), device="cuda", generator=g) / math.sqrt(D)).to(tdt)   # reference row order c*256+i*16+j
+    b = torch.randn((1792,), device="cuda", generator=g)
+    f = (A.double() @ W.double().t() + b.double()).view(nv, gh, gw, 7, 16, 16).permute(0, 1, 4, 2, 5, 3).reshape(nv, H, Wd, 7)
+    idx = torch.arange(1792, device="cuda")
+    old = (idx % 7) * 256 + idx // 7          # new row (i*16+j)*7+c <- old row c*256 + i*16 + j
+    Wp, bp = W[old].contiguous(), b[old].contiguous()
+    out = torch.full((nv, H, Wd, 7), float("nan"), device="cuda")
+    run_gemm(lib, dt, lib.EPI_HEAD, A, Wp, bp, out, ldc=0, ntok=N, gw=gw, H=H, Wimg=Wd)
+    e = rel_inf(out, f)
+    record("gemm_head", dt=dt, err=e)
+    assert torch.allclose(out.double(), f, rtol=1e-5, atol=1e-4), e
+    run_gemm(lib, dt, lib.EPI_HEAD, A, Wp, bp, out, ldc=0, acc=1, ntok=N, gw=gw, H=H, Wimg=Wd)
+    assert torch.allclose(out.double(), 2 * f - b.double()[old].view(16, 16, 7)[None, None, :, None].expand(nv, gh, 16, gw, 16, 7)
+                          .reshape(nv, H, Wd, 7), rtol=1e-5, atol=2e-4)
+
+
+def attn_ref(q, k, v, views, heads):
+    """fp64 softmax attention per view/head from the 16-bit operands; q [Rq, H*64], k/v [Rk, H*64]."""
+    out = torch.zeros(q.shape, dtype=torch.float64)
+    for (q0, nq, k0, nk, slo, shi) in views:
+        keep = torch.ones(nk, dtype=torch.bool)
+        keep[slo:shi] = False
+        for h in range(heads):
+            qq = q[q0:q0 + nq, h * 64:(h + 1) * 64].double()
+            kk = k[k0:k0 + nk, h * 64:(h + 1) * 64].double()[keep]
+            vv = v[k0:k0 + nk, h * 64:(h + 1) * 64].double()[keep]
+            p = torch.softmax(qq @ kk.t() / 8.0, dim=-1)
+            out[q0:q0 + nq, h * 64:(h + 1) * 64] = p @ vv
+    return out
+
+
+ATT_CASES = {
+    # name: (heads, views [(q0,nq,k0,nk,skip_lo,skip_hi)], total q rows, total k rows, self?)
+    "sa_196x2": (2, [(0, 196, 0, 196, 0, 0), (196, 196, 196, 196, 0, 0)], 392, 392, True),
+    "sa_768": (3, [(0, 768, 0, 768, 0, 0)], 768, 768, True),
+    "sa_tiny12": (2, [(0, 12, 0, 12, 0, 0), (12, 12, 12, 12, 0, 0), (24, 12, 24, 12, 0, 0)], 36, 36, True),
+    "ca_tail_skip": (2, [(0, 100, 0, 1000, 300, 496), (100, 100, 0, 1000, 496, 692)], 200, 1000, False),
+    "ca_aligned_skip": (2, [(0, 130, 0, 640, 128, 320)], 130, 640, False),
+    "ca_skip_to_end": (1, [(0, 64, 0, 500, 304, 500)], 64, 500, False),
+    "ca_skip_from_start": (1, [(0, 70, 0, 392, 0, 196), (70, 70, 0, 392, 196, 392)], 140, 392, False),
+    "ca_long": (12, [(0, 768, 0, 4000, 0, 0)], 768, 4000, False),
+}
+
+
+@pytest.mark.parametrize("dt", ["bf16", "fp16"])
+@pytest.mark.parametrize("case", list(ATT_CASES))
+def test_attention(lib, dt, case):
+    heads, views, Rq, Rk, is_self = ATT_CASES[case]
+    D = heads * 64
+    g = torch.Generator(device="cuda").manual_seed(11)
+    tdt, u = DT[dt][1], DT[dt][2]
+    if is_self:  # packed qkv rows like the fused projection writes them: [R, 3D]
+        qkv = (torch.randn((Rq, 3 * D), device="cuda", generator=g) * 1.5).to(tdt)
+        q, k, v = qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:]
+    else:        # q [Rq, D], memory rows [Rk, 2D] = K|V
+        q = (torch.randn((Rq, D), device="cuda", generator=g) * 1.5).to(tdt)
+        kvm = (torch.randn((Rk, 2 * D), device="cuda", generator=g) * 1.5).to(tdt)
+        k, v = kvm[:, :D], kvm[:, D:]
+    o = torch.full((Rq, D), float("nan"), device="cuda", dtype=tdt)
+    tab = torch.tensor(views, dtype=torch.int32, device="cuda")
+    lib.check(lib.load().must3r_hip_op_attention(DT[dt][0], P(q), P(k), P(v), P(o), q.stride(0), k.stride(0), v.stride(0),
+                                                 o.stride(0), heads, P(tab), len(views), max(vw[1] for vw in views), stream()))
+    torch.cuda.synchronize()
+    ref = attn_ref(q.cpu(), k.cpu(), v.cpu(), views, heads)
+    e = rel_inf(o.cpu(), ref)
+    record("attention", dt=dt, case=case, err=e)
+    assert torch.isfinite(o.float()).all()
+    assert e < 8 * u, e  # P and O are rounded to 16 bit; everything else is fp32
+
+
+@pytest.mark.parametrize("dt", ["bf16", "fp16"])
+def test_attention_running_max_jump(lib, dt):
+    """Force the online-softmax rescale branch: one key late in the sequence dominates one query row."""
+    heads, nq, nk = 1, 64, 512
+    g = torch.Generator(device="cuda").manual_seed(13)
+    tdt, u = DT[dt][1], DT[dt][2]
+    q = torch.randn((nq, 64), device="cuda", generator=g).to(tdt)
+    kv = torch.randn((nk, 128), device="cuda", generator=g).to(tdt)
+    kv[400, :64] = (q[5].float() * 6).to(tdt)   # q5 . k400 >> every other score, in the 7th tile
+    kv[3, :64] = (q[40].float() * 6).to(tdt)    # and one in the first tile
+    views = [(0, nq, 0, nk, 0, 0)]
+    o = torch.empty((nq, 64), device="cuda", dtype=tdt)
+    tab = torch.tensor(views, dtype=torch.int32, device="cuda")
+    lib.check(lib.load().must3r_hip_op_attention(DT[dt][0], P(q), P(kv), P(kv[:, 64:]), P(o), 64, 128, 128, 64, heads, P(tab), 1, nq,
+                                                 stream()))
+    torch.cuda.synchronize()
+    ref = attn_ref(q.cpu(), kv[:, :64].cpu(), kv[:, 64:].cpu(), views, heads)
+    e = rel_inf(o.cpu(), ref)
+    record("attention_jump", dt=dt, err=e)
+    assert e < 8 * u, e
+
+
+@pytest.mark.parametrize("dt", ["bf16", "fp16"])
+@pytest.mark.parametrize("MC", [(7, 128), (1000, 768), (513, 1024)])
+def test_layernorm(lib, dt, MC):
+    M, Cc = MC
+    g = torch.Generator(device="cuda").manual_seed(3)
+    tdt, u = DT[dt][1], DT[dt][2]
+    x = torch.randn((M, Cc), device="cuda", generator=g) * 3 + 0.5
+    add = torch.randn((M, Cc), device="cuda", generator=g)
+    w = torch.randn((Cc,), device="cuda", generator=g)
+    b = torch.randn((Cc,), device="cuda", generator=g)
+    o16 = torch.empty((M, Cc), device="cuda", dtype=tdt)
+    olo = torch.empty((M, Cc), device="cuda", dtype=tdt)
+    o32 = torch.empty((M, Cc), device="cuda")
+    cp = torch.empty((M, Cc), device="cuda")
+    L = lib.load()
+    lib.check(L.must3r_hip_op_layernorm(DT[dt][0], P(x), P(add), P(w), P(b), P(o16), P(olo), P(o32), P(cp), M, Cc, 1e-6, stream()))
+    torch.cuda.synchronize()
+    ref = torch.nn.functional.layer_norm((x + add).double(), (Cc,), w.double(), b.double(), 1e-6)
+    assert torch.equal(cp, x + add)
+    e = rel_inf(o32, ref)
+    record("layernorm", dt=dt, MC=MC, err=e)
+    assert torch.allclose(o32.double(), ref, rtol=1e-5, atol=1e-5), e
+    assert torch.equal(o16, o32.to(tdt))
+    assert torch.allclose(o16.double() + olo.double(), o32.double(), rtol=4 * u * u, atol=1e-6)
+    lib.check(L.must3r_hip_op_layernorm(DT[dt][0], P(x), None, P(w), P(b), P(o16), None, None, None, M, Cc, 1e-5, stream()))
+    torch.cuda.synchronize()
+    ref = torch.nn.functional.layer_norm(x.double(), (Cc,), w.double(), b.double(), 1e-5)
+    assert torch.allclose(o16.double(), ref, rtol=2 * u, atol=2 * u)
+
+
+@pytest.mark.parametrize("dt", ["bf16", "fp16"])
+def test_im2col_cast_postprocess(lib, dt):
+    from oracle import must3r_ref as R
+    tdt = DT[dt][1]
+    L = lib.load()
+    img = torch.randn((2, 3, 48, 64), device="cuda")
+    out = torch.empty((2 * 12, 768), device="cuda", dtype=tdt)
+    lib.check(L.must3r_hip_op_im2col(DT[dt][0], P(img), P(out), 2, 48, 64, stream()))
+    ref = torch.nn.functional.unfold(img, kernel_size=16, stride=16).transpose(1, 2).reshape(24, 768)
+    torch.cuda.synchronize()
+    assert torch.equal(out, ref.to(tdt))
+    x = torch.randn((4096,), device="cuda") * 10
+    hi = torch.empty_like(x, dtype=tdt)
+    lo = torch.empty_like(x, dtype=tdt)
+    lib.check(L.must3r_hip_op_cast(DT[dt][0], P(x), P(hi), P(lo), x.numel(), stream()))
+    torch.cuda.synchronize()
+    assert torch.equal(hi, x.to(tdt)) and torch.equal(lo, (x - x.to(tdt).float()).to(tdt))
+    from must3r_amd.engine import postprocess
+    pm = torch.randn((2, 16, 16, 7), device="cuda") * 2
+    o = postprocess(pm)
+    r = R.postprocess(pm.cpu())
+    for k in r:
+        assert torch.allclose(o[k].cpu(), r[k], rtol=1e-5, atol=1e-6), k

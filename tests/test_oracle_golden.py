@@ -1,0 +1,108 @@
+"""CPU: the oracle restatement (oracle/must3r_ref.py) against fixtures produced by the REAL reference
+(oracle/make_golden.py), and the structural invariants of SURVEY.md section 4."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import must3r_ref as R
+from must3r_amd.config import TINY, SMALL, MUST3R_224
+from must3r_amd import synthetic as S
+from util import load_golden, rel_inf
+
+CASES = {"tiny_48x64_v4": TINY, "small_224_v3": SMALL, "must3r224_v2": MUST3R_224}
+
+
+def _scene(cfg, g):
+    H, W, V, ps, tks = (int(v) for v in g["meta"][:5])
+    mb = [int(v) for v in g["meta"][5:]]
+    sde, sdd = S.make_encoder_state_dict(cfg, 0), S.make_decoder_state_dict(cfg, 0)
+    imgs, ts = S.make_images(V, H, W, 0)
+    with torch.no_grad():
+        x, pos = R.encoder_forward(sde, cfg, imgs, ts, sdpa=True)
+        mem, upd, i = None, [], 0
+        for nb in mb:
+            mem, pm = R.decoder_forward(sdd, cfg, x[i:i + nb].unsqueeze(0), pos[i:i + nb].unsqueeze(0), ts[i:i + nb].unsqueeze(0),
+                                        mem, False, "kv", sdpa=True)
+            upd.append(pm[0])
+            i += nb
+        _, ren = R.decoder_forward(sdd, cfg, x.unsqueeze(0), pos.unsqueeze(0), ts.unsqueeze(0), mem, True, "kv", sdpa=True)
+    return x, pos, torch.cat(upd, 0), ren[0], mem, ps, tks
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_oracle_matches_reference_fixture(name):
+    torch.set_num_threads(8)
+    g = load_golden(name)
+    x, pos, upd, ren, mem, ps, tks = _scene(CASES[name], g)
+    tol = 2e-5  # fp32 round-off (different summation order / SDPA backend), observed ~1e-6
+    assert rel_inf(x[:, ::tks, ::tks], g["x"]) < tol
+    assert abs(x.double().abs().sum().item() - float(g["x_abs"])) / float(g["x_abs"]) < 1e-5
+    assert np.array_equal(pos[:, ::tks].numpy(), g["pos"])
+    assert rel_inf(upd[:, ::ps, ::ps], g["update"]) < tol
+    assert rel_inf(ren[:, ::ps, ::ps], g["render"]) < tol
+    assert abs(ren.double().abs().sum().item() - float(g["render_abs"])) / float(g["render_abs"]) < 1e-5
+    assert rel_inf(mem[0][0][0, ::tks, ::tks], g["mem_first"]) < tol
+    assert rel_inf(mem[0][-1][0, ::tks, ::tks], g["mem_last"]) < tol
+    assert np.array_equal(mem[1].numpy(), g["labels"])          # invariant 4: labels
+    assert [int(v) for v in mem[2:]] == [int(v) for v in g["tail"]]
+
+
+def test_oracle_mixed_aspect_ratio_list_path():
+    g = load_golden("tiny_mixed_ar")
+    cfg = TINY
+    sde, sdd = S.make_encoder_state_dict(cfg, 0), S.make_decoder_state_dict(cfg, 0)
+    ia, ta = S.make_images(2, 48, 64, 1)
+    ib, tb = S.make_images(1, 32, 64, 2)
+    L = lambda *t: [v.unsqueeze(0) for v in t]  # noqa: E731
+    with torch.no_grad():
+        xa, pa = R.encoder_forward(sde, cfg, ia, ta)
+        xb, pb = R.encoder_forward(sde, cfg, ib, tb)
+        mem, pm0 = R.decoder_forward(sdd, cfg, L(xa, xb), L(pa, pb), L(ta, tb), None)
+        mem2, pm1 = R.decoder_forward(sdd, cfg, L(xb, xa), L(pb, pa), L(tb, ta), mem)
+        _, pm2 = R.decoder_forward(sdd, cfg, L(xb, xa), L(pb, pa), L(tb, ta), mem2, render=True)
+    for got, key in ((pm0[0], "init_a"), (pm0[1], "init_b"), (pm1[0], "upd_b"), (pm1[1], "upd_a"), (pm2[0], "ren_b"),
+                     (pm2[1], "ren_a")):
+        assert rel_inf(got[0], g[key]) < 2e-5, key
+    assert rel_inf(mem2[0][-1][0], g["mem_last"]) < 2e-5
+    assert np.array_equal(mem2[1].numpy(), g["labels"])
+    assert [int(v) for v in mem2[2:]] == [int(v) for v in g["tail"]]
+
+
+def test_invariants_memory_modes_and_render():
+    """(1) norm_y == kv == raw, (2) forward_list([x]) == forward(x), (3) render leaves the
+    memory tuple unchanged, (5) zero-initialised feedback is a no-op, (6) per-view independence of the encoder."""
+    cfg = TINY
+    sde, sdd = S.make_encoder_state_dict(cfg, 0), S.make_decoder_state_dict(cfg, 0)
+    imgs, ts = S.make_images(3, 48, 64, 0)
+    with torch.no_grad():
+        x, pos = R.encoder_forward(sde, cfg, imgs, ts)
+        x1, _ = R.encoder_forward(sde, cfg, imgs[1:2], ts[1:2])
+        assert rel_inf(x1, x[1:2]) < 1e-5
+        outs = {}
+        for mode in ("kv", "norm_y", "raw"):
+            mem, _ = R.decoder_forward(sdd, cfg, x[:2].unsqueeze(0), pos[:2].unsqueeze(0), ts[:2].unsqueeze(0), None, False, mode)
+            mem, _ = R.decoder_forward(sdd, cfg, x[2:].unsqueeze(0), pos[2:].unsqueeze(0), ts[2:].unsqueeze(0), mem, False, mode)
+            mem_r, pm = R.decoder_forward(sdd, cfg, x.unsqueeze(0), pos.unsqueeze(0), ts.unsqueeze(0), mem, True, mode)
+            assert mem_r[0] is not None and all(a is b or torch.equal(a, b) for a, b in zip(mem_r[0], mem[0]))
+            assert mem_r[2:] == mem[2:]
+            outs[mode] = pm
+        assert rel_inf(outs["norm_y"], outs["kv"]) < 1e-5 and rel_inf(outs["raw"], outs["kv"]) < 1e-5
+        mem_t, pm_t = R.decoder_forward(sdd, cfg, x[:2].unsqueeze(0), pos[:2].unsqueeze(0), ts[:2].unsqueeze(0), None)
+        mem_l, pm_l = R.decoder_forward(sdd, cfg, [x[:2].unsqueeze(0)], [pos[:2].unsqueeze(0)], [ts[:2].unsqueeze(0)], None)
+        assert torch.equal(pm_t, pm_l[0]) and all(torch.equal(a, b) for a, b in zip(mem_t[0], mem_l[0]))
+        # zero feedback fc2 -> stored memory == prepare_y(layer inputs) == what the views attended
+        sd0 = dict(sdd)
+        sd0["feedback_layer.fc2.weight"] = torch.zeros_like(sdd["feedback_layer.fc2.weight"])
+        sd0["feedback_layer.fc2.bias"] = torch.zeros_like(sdd["feedback_layer.fc2.bias"])
+        mem_a, _, feats = R.decoder_forward(sd0, cfg, x[:2].unsqueeze(0), pos[:2].unsqueeze(0), ts[:2].unsqueeze(0), None,
+                                            return_feats=True)
+        y0 = R.prepare_y(sd0, "blocks_dec.1", feats[0][1].reshape(1, -1, cfg.dec_dim), "kv")
+        assert rel_inf(mem_a[0][1], y0) < 1e-6
+
+
+def test_postprocess_matches_formula():
+    pm = torch.randn(2, 5, 6, 7)
+    o = R.postprocess(pm)
+    d = pm[..., :3].norm(dim=-1, keepdim=True)
+    assert torch.allclose(o["pts3d"], pm[..., :3] / d * torch.expm1(d), atol=1e-6)
+    assert torch.allclose(o["conf"], 1 + pm[..., 6].exp())

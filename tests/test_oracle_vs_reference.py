@@ -1,0 +1,62 @@
+"""CPU, build container only: re-run the REAL reference (verbatim must3r/model on leaf shims) against the oracle
+restatement.  Skipped where /root/reference does not exist (the GPU box) -- there the committed fixtures stand in."""
+import pytest
+import torch
+
+from conftest import HAS_REFERENCE
+from must3r_amd.config import TINY
+from must3r_amd import synthetic as S
+from util import rel_inf
+
+pytestmark = pytest.mark.skipif(not HAS_REFERENCE, reason="/root/reference not present")
+
+
+@pytest.mark.parametrize("mode", ["kv", "norm_y", "raw"])
+def test_restatement_equals_reference(mode):
+    from oracle import ref_shims, must3r_ref as R
+    cfg = TINY
+    sde, sdd = S.make_encoder_state_dict(cfg, 3), S.make_decoder_state_dict(cfg, 3)
+    imgs, ts = S.make_images(4, 64, 48, 3)  # portrait-shaped grid, 3 x 4 tokens
+    enc, dec = ref_shims.build_reference(cfg, sde, sdd, mode)  # strict load == state-dict key contract
+    with torch.no_grad():
+        xr, pr = enc(imgs, ts)
+        xo, po = R.encoder_forward(sde, cfg, imgs, ts)
+        assert rel_inf(xo, xr) < 2e-5 and torch.equal(pr, po)
+        memr = memo = None
+        i = 0
+        for nb in (2, 1, 1):
+            sl = slice(i, i + nb)
+            memr, pmr = dec(xr[sl].unsqueeze(0), pr[sl].unsqueeze(0), ts[sl].unsqueeze(0), memr)
+            memo, pmo = R.decoder_forward(sdd, cfg, xr[sl].unsqueeze(0), pr[sl].unsqueeze(0), ts[sl].unsqueeze(0), memo, False, mode)
+            assert rel_inf(pmo, pmr) < 2e-5
+            assert max(rel_inf(a, b) for a, b in zip(memo[0], memr[0])) < 2e-5
+            assert torch.equal(memo[1], memr[1]) and tuple(memo[2:]) == tuple(memr[2:])
+            i += nb
+        _, pmr = dec(xr.unsqueeze(0), pr.unsqueeze(0), ts.unsqueeze(0), memr, render=True)
+        _, pmo = R.decoder_forward(sdd, cfg, xr.unsqueeze(0), pr.unsqueeze(0), ts.unsqueeze(0), memo, True, mode)
+        assert rel_inf(pmo, pmr) < 2e-5
+
+
+def test_postprocess_equals_reference_geometry():
+    from oracle import ref_shims, must3r_ref as R
+    ref_shims.install()
+    import must3r.tools.geometry as G
+    pm = torch.randn(3, 8, 8, 7)
+    o = R.postprocess(pm)
+    assert torch.equal(o["pts3d"], G.apply_exp_to_norm(pm[..., :3]))
+    assert torch.equal(o["pts3d_local"], G.apply_exp_to_norm(pm[..., 3:6]))
+
+
+def test_arg_rewriting_equals_reference():
+    from oracle import ref_shims
+    ref = ref_shims.import_reference_model()
+    import must3r_amd.model as M
+    train_str = ("CausalMUSt3R(img_size=(512, 512), feedback_type='single_mlp', memory_mode=\"kv\", mem_dropout=0.1, "
+                 "dropout_mode='temporary', use_xformers_mask=True, use_mem_mask=True)")  # README.md:242
+    assert M.convert_decoder_args(train_str) == ref.convert_decoder_args(train_str)
+    for s in ("Dust3rEncoder(img_size=(512,512),patch_embed='ManyAR_PatchEmbed')",
+              "MUSt3R(img_size=(224, 224), pos_embed='RoPE100')",
+              "MUSt3R(img_size=(224,224),pos_embed='RoPE100_224:512')"):
+        for size in (224, 512, 768):
+            assert M.set_image_size_in_args(s, size, verbose=False) == ref.set_image_size_in_args(s, size, verbose=False)
+    assert M.get_dtype("bf16") == torch.bfloat16 and M.get_dtype(False) == torch.float32

@@ -1,0 +1,82 @@
+"""CPU, world_size 2, gloo: the multi-GPU scene driver (must3r_amd/parallel.py) with the oracle standing in for the
+two forwards -- the sharded result must equal the single-process result bit for bit (the replicated memory update
+is deterministic), and the variable-length all-gather must keep rank order."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from must3r_amd.config import TINY
+from must3r_amd import synthetic as S
+from must3r_amd.parallel import all_gather_varlen, run_scene_sharded, shard_range
+
+V, H, W = 6, 48, 64
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _oracle_pair():
+    from oracle import must3r_ref as R
+    cfg = TINY
+    sde, sdd = S.make_encoder_state_dict(cfg, 0), S.make_decoder_state_dict(cfg, 0)
+    enc = lambda img, ts: R.encoder_forward(sde, cfg, img, ts)  # noqa: E731
+    dec = lambda x, pos, ts, mem=None, render=False: R.decoder_forward(sdd, cfg, x, pos, ts, mem, render, "kv")  # noqa: E731
+    return enc, dec
+
+
+def _keyframes():
+    return torch.tensor([True, False, True, True, False, True])  # 4 keyframes, unevenly spread over the 2 shards
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    try:
+        # varlen gather keeps rank order, handles empty shards
+        t = torch.arange(rank * 10, rank * 10 + (3 if rank == 0 else 1)).float().view(-1, 1)
+        g = all_gather_varlen(t)
+        assert g.flatten().tolist() == [0.0, 1.0, 2.0, 10.0]
+        e = all_gather_varlen(torch.zeros((0, 2)) if rank == 1 else torch.ones((2, 2)))
+        assert e.shape == (2, 2)
+        imgs, ts = S.make_images(V, H, W, 0)
+        lo, hi = shard_range(V, rank, world)
+        enc, dec = _oracle_pair()
+        with torch.no_grad():
+            out = run_scene_sharded(enc, dec, imgs[lo:hi], ts[lo:hi], _keyframes()[lo:hi], gather_outputs=True)
+        torch.save({"render_all": out["render_all"], "mem_last": out["mem"][0][-1], "labels": out["mem"][1], "K": out["n_keyframes"]},
+                   os.path.join(out_dir, f"r{rank}.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_shard_range_covers_everything():
+    for n in (0, 1, 5, 20, 21):
+        for w in (1, 2, 3, 8):
+            spans = [shard_range(n, r, w) for r in range(w)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            assert max(h - l for l, h in spans) - min(h - l for l, h in spans) <= 1
+
+
+def test_sharded_scene_equals_single_process(tmp_path):
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    r0 = torch.load(tmp_path / "r0.pt")
+    r1 = torch.load(tmp_path / "r1.pt")
+    assert r0["K"] == 4 and torch.equal(r0["render_all"], r1["render_all"]) and torch.equal(r0["mem_last"], r1["mem_last"])
+    # single process reference: same keyframes in global order, then render everything
+    imgs, ts = S.make_images(V, H, W, 0)
+    enc, dec = _oracle_pair()
+    torch.set_num_threads(2)
+    with torch.no_grad():
+        one = run_scene_sharded(enc, dec, imgs, ts, _keyframes())
+    assert torch.allclose(one["render"], r0["render_all"], atol=1e-6)
+    assert torch.allclose(one["mem"][0][-1], r0["mem_last"], atol=1e-6) and torch.equal(one["mem"][1], r0["labels"])
