@@ -128,17 +128,16 @@ __global__ void __launch_bounds__(256) attn_kernel(const AttnArgs p, const int n
         // ---- exclusion / tail mask: s_[kf][f][r] is key k0 + 16 kf + 4 fg + r
         const int k0 = t * ATT_KT;
         const bool need_mask = (k0 + ATT_KT > nk) || (k0 < shi && k0 + ATT_KT > slo);
-        if (need_mask) {
+        if (need_mask) {  // wave-uniform branch; inside, a branch-free per-lane select
 #pragma unroll
             for (int kf = 0; kf < 4; ++kf)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int key = k0 + kf * 16 + fg * 4 + r;
-                    const bool bad = key >= nk || (key >= slo && key < shi);
-                    if (bad) {
+                    const bool bad = (key >= nk) | ((key >= slo) & (key < shi));
+                    const float pen = bad ? -INFINITY : 0.f;
 #pragma unroll
-                        for (int f = 0; f < QF; ++f) s_[kf][f][r] = -INFINITY;
-                    }
+                    for (int f = 0; f < QF; ++f) s_[kf][f][r] += pen;   // finite + (-inf) = -inf
                 }
         }
         // ---- online softmax (base 2), per query = per lane column; keys of a query live in lanes fr+16*g
