@@ -32,7 +32,10 @@ extern "C" {
 typedef struct must3r_hip_ctx must3r_hip_ctx;
 
 /* MFMA operand type (accumulation, softmax, LayerNorm and the residual stream are always fp32) */
-enum { MUST3R_BF16 = 0, MUST3R_F16 = 1 };
+/* MUST3R_F16_W2: fp16 operands with every weight matrix split as W_hi + W_lo (two MFMA passes per GEMM, fp32
+ * accumulation): removes the weight-rounding term that dominates the fp16 error (precision). Only valid
+ * for must3r_hip_encode / must3r_hip_decode; buffers are fp16. */
+enum { MUST3R_BF16 = 0, MUST3R_F16 = 1, MUST3R_F16_W2 = 2 };
 
 /* layout of the caller-visible memory tensors; CachedDecoderBlock MEMORY_MODES, must3r/model/blocks/layers.py:9 */
 enum { MUST3R_MEM_KV = 0, MUST3R_MEM_NORM_Y = 1, MUST3R_MEM_RAW = 2 };
@@ -114,15 +117,20 @@ int must3r_hip_op_gemm(int dtype, int epi, const void* A, const void* W, const f
                        const int64_t* pos, const float* rope_tab, int rope_cols, int rope_npos, /* QKV_ROPE */
                        const float* bias2, int row_start2, int accumulate,                      /* F32 / HEAD */
                        int ntok, int gw, int H, int W_img,                                      /* HEAD */
+                       int wsplit, /* 2: W is [N, 2K] = [W_hi | W_lo], out = A W_hi^T + A W_lo^T; else 0 */
                        void* stream);
 /* cos/sin table fp32 [npos][16][2] for RoPE2D(freq, F0) with head dim 64 (host pointer) */
 int must3r_hip_rope_table(float freq, float f0, int npos, float* out_host);
 
 /* softmax(Q K^T / 8) V per head of 64; views: int32 [n_views][6] = q_row0, nq, kv_row0, nk, skip_lo, skip_hi
- * (DEVICE pointer).  Q/K/V/O 16-bit with row strides in elements. */
+ * (DEVICE pointer).  Q/K/V/O 16-bit with row strides in elements.
+ * nsplit > 1 selects split-KV (flash-decoding) with `scratch` of must3r_hip_attention_scratch_bytes() bytes and
+ * total_q_rows = max(q_row0 + nq); nsplit <= 1 needs neither. */
+size_t must3r_hip_attention_scratch_bytes(int nsplit, int total_q_rows, int heads);
 int must3r_hip_op_attention(int dtype, const void* Q, const void* K, const void* V, void* O,
                             int ldq, int ldk, int ldv, int ldo, int heads,
-                            const int32_t* views_dev, int n_views, int max_nq, void* stream);
+                            const int32_t* views_dev, int n_views, int max_nq,
+                            int nsplit, void* scratch, int total_q_rows, void* stream);
 
 /* y = LN(x (+ add)) * w + b over rows of C; optional outputs may be NULL */
 int must3r_hip_op_layernorm(int dtype, const float* x, const float* add, const float* w, const float* b,

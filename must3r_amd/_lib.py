@@ -10,7 +10,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmust3r_hip.so")
 
-BF16, F16 = 0, 1
+BF16, F16, F16_W2 = 0, 1, 2
 MEM_KV, MEM_NORM_Y, MEM_RAW = 0, 1, 2
 PART_ENCODER, PART_DECODER = 1, 2
 EPI_STORE16, EPI_STORE16_GELU, EPI_QKV_ROPE, EPI_RESID_F32, EPI_F32, EPI_HEAD = range(6)
@@ -22,7 +22,7 @@ EXPORTS = (
     "must3r_hip_load_weight", "must3r_hip_finalize_weights", "must3r_hip_encode", "must3r_hip_decode",
     "must3r_hip_postprocess", "must3r_hip_op_gemm", "must3r_hip_rope_table", "must3r_hip_op_attention",
     "must3r_hip_op_layernorm", "must3r_hip_op_im2col", "must3r_hip_op_cast", "must3r_hip_set_profiling",
-    "must3r_hip_get_profile", "must3r_hip_debug_tr_probe",
+    "must3r_hip_get_profile", "must3r_hip_debug_tr_probe", "must3r_hip_attention_scratch_bytes",
 )
 
 
@@ -78,9 +78,11 @@ def load():
     lib.must3r_hip_decode.argtypes = [vp, C.POINTER(DecodeArgs), vp]
     lib.must3r_hip_postprocess.argtypes = [vp, vp, vp, vp, C.c_size_t, vp]
     lib.must3r_hip_op_gemm.argtypes = [i32, i32, vp, vp, vp, vp, i32, i32, i32, i32, i32,
-                                       vp, vp, i32, i32, vp, i32, i32, i32, i32, i32, i32, vp]
+                                       vp, vp, i32, i32, vp, i32, i32, i32, i32, i32, i32, i32, vp]
     lib.must3r_hip_rope_table.argtypes = [fp, fp, i32, vp]
-    lib.must3r_hip_op_attention.argtypes = [i32, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, i32, i32, vp]
+    lib.must3r_hip_op_attention.argtypes = [i32, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, i32, i32, i32, vp, i32, vp]
+    lib.must3r_hip_attention_scratch_bytes.argtypes = [i32, i32, i32]
+    lib.must3r_hip_attention_scratch_bytes.restype = C.c_size_t
     lib.must3r_hip_op_layernorm.argtypes = [i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, fp, vp]
     lib.must3r_hip_op_im2col.argtypes = [i32, vp, vp, i32, i32, i32, vp]
     lib.must3r_hip_op_cast.argtypes = [i32, vp, vp, vp, C.c_size_t, vp]
@@ -89,7 +91,7 @@ def load():
     lib.must3r_hip_get_profile.argtypes = [vp, C.POINTER(ProfRecord), i32, i32]
     for name in EXPORTS:
         fn = getattr(lib, name)
-        if fn.restype is C.c_int and name not in ("must3r_hip_abi_version",):
+        if fn.restype is C.c_int and name not in ("must3r_hip_abi_version", "must3r_hip_attention_scratch_bytes"):
             fn.restype = i32
     if lib.must3r_hip_abi_version() != ABI_VERSION:
         raise ImportError(f"{LIB_PATH}: ABI version {lib.must3r_hip_abi_version()} != {ABI_VERSION}; rebuild")

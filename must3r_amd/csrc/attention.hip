@@ -21,7 +21,7 @@ constexpr int ATT_QB = 4 * ATT_QW;       // per block
 constexpr int ATT_KT = 64;               // keys per tile
 
 template <class T>
-__global__ void __launch_bounds__(256) attn_kernel(const AttnArgs p, const int nqb, const int ngrp) {
+__global__ void __launch_bounds__(256) attn_kernel(const AttnArgs p, const int nqb, const int ngrp, const int nsplit) {
     typedef typename Vec<T>::v8 v8;
     typedef typename Vec<T>::v4 v4;
     constexpr int QF = ATT_QW / 16;
@@ -34,7 +34,10 @@ __global__ void __launch_bounds__(256) attn_kernel(const AttnArgs p, const int n
     const int fr = lane & 15, fg = lane >> 4;
 
     // blocks of one (view, head) group stay on one XCD (blockIdx % 8) so its K/V tiles are L2 hits
-    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int xcd = blockIdx.x & 7;
+    int slot = blockIdx.x >> 3;
+    const int split = slot % nsplit;
+    slot /= nsplit;
     const int grp = (slot / nqb) * 8 + xcd;
     const int qb = slot % nqb;
     if (grp >= ngrp) return;
@@ -65,9 +68,13 @@ __global__ void __launch_bounds__(256) attn_kernel(const AttnArgs p, const int n
         const int k1 = (k0 + ATT_KT < nk) ? k0 + ATT_KT : nk;
         return k0 >= slo && k1 <= shi;
     };
+    // this block's share of the key tiles
+    const int tps = (ntiles + nsplit - 1) / nsplit;
+    const int t_begin = split * tps;
+    const int t_end = (t_begin + tps < ntiles) ? t_begin + tps : ntiles;
     auto advance = [&](int t) {
         ++t;
-        while (t < ntiles && fully_skipped(t)) ++t;
+        while (t < t_end && fully_skipped(t)) ++t;
         return t;
     };
 
@@ -97,15 +104,15 @@ __global__ void __launch_bounds__(256) attn_kernel(const AttnArgs p, const int n
     }
     const float c = p.scale * 1.44269504088896340736f;  // softmax in base 2
 
-    int t = -1;
+    int t = t_begin - 1;
     t = advance(t);
-    if (t < ntiles) stage(t, 0);
+    if (t < t_end) stage(t, 0);
     int buf = 0;
-    while (t < ntiles) {
+    while (t < t_end) {
         __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0)
         __syncthreads();
         const int tn = advance(t);
-        if (tn < ntiles) stage(tn, buf ^ 1);
+        if (tn < t_end) stage(tn, buf ^ 1);
 
         const T* k_ = sK[buf];
         const T* v_ = sV[buf];
@@ -205,14 +212,77 @@ __global__ void __launch_bounds__(256) attn_kernel(const AttnArgs p, const int n
         float l = l_[f];
         l += __shfl_xor(l, 16, 64);
         l += __shfl_xor(l, 32, 64);
-        const float inv = l > 0.f ? 1.0f / l : 0.f;
         const int q = qr0 + f * 16 + fr;
-        if (q < vw.nq) {
-            T* dst = O + (size_t)(vw.q_row0 + q) * p.ldo + head * 64 + fg * 4;
+        if (q >= vw.nq) continue;
+        const size_t row = (size_t)(vw.q_row0 + q);
+        if (nsplit <= 1) {
+            const float inv = l > 0.f ? 1.0f / l : 0.f;
+            T* dst = O + row * p.ldo + head * 64 + fg * 4;
 #pragma unroll
             for (int d = 0; d < 4; ++d) *reinterpret_cast<v4*>(dst + d * 16) = cvt4<T>(o_[d][f] * inv);
+        } else {
+            const size_t D = (size_t)p.heads * 64;
+            float* po = p.part_o + ((size_t)split * p.total_q_rows + row) * D + head * 64 + fg * 4;
+#pragma unroll
+            for (int d = 0; d < 4; ++d) *reinterpret_cast<f32x4*>(po + d * 16) = o_[d][f];
+            if (fg == 0) {
+                float* pm = p.part_ml + (((size_t)split * p.total_q_rows + row) * p.heads + head) * 2;
+                pm[0] = m_[f];
+                pm[1] = l;
+            }
         }
     }
+}
+
+// merge of the split-KV partials: O = sum_s 2^(m_s - m*) O_s / sum_s 2^(m_s - m*) l_s ; one thread = 4 columns
+template <class T>
+__global__ void attn_combine_kernel(const AttnArgs p, const int nsplit) {
+    typedef typename Vec<T>::v4 v4;
+    const size_t D = (size_t)p.heads * 64;
+    const size_t total = (size_t)p.total_q_rows * (D / 4);
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const size_t row = idx / (D / 4);
+        const int col = (int)(idx % (D / 4)) * 4;
+        const int head = col >> 6;
+        float mstar = -INFINITY;
+        for (int s = 0; s < nsplit; ++s)
+            mstar = fmaxf(mstar, p.part_ml[(((size_t)s * p.total_q_rows + row) * p.heads + head) * 2]);
+        if (mstar == -INFINITY) continue;  // row not produced by any view of this launch
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        float L = 0.f;
+        for (int s = 0; s < nsplit; ++s) {
+            const float* ml = p.part_ml + (((size_t)s * p.total_q_rows + row) * p.heads + head) * 2;
+            const float w = __builtin_amdgcn_exp2f(ml[0] - mstar);
+            L += w * ml[1];
+            acc += *reinterpret_cast<const f32x4*>(p.part_o + ((size_t)s * p.total_q_rows + row) * D + col) * w;
+        }
+        const float inv = L > 0.f ? 1.0f / L : 0.f;
+        *reinterpret_cast<v4*>(reinterpret_cast<T*>(p.O) + row * p.ldo + col) = cvt4<T>(acc * inv);
+    }
+}
+
+// fills (m, l) = (-inf, 0) so rows no block writes are recognisable by the combine pass
+__global__ void attn_ml_init_kernel(float* ml, size_t n2) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += (size_t)gridDim.x * blockDim.x) {
+        ml[i * 2] = -INFINITY;
+        ml[i * 2 + 1] = 0.f;
+    }
+}
+
+size_t attention_split_scratch_bytes(int nsplit, int total_q_rows, int heads) {
+    if (nsplit <= 1) return 0;
+    return (size_t)nsplit * total_q_rows * ((size_t)heads * 64 * 4 + (size_t)heads * 8) + 512;
+}
+
+int attention_pick_split(int nviews, int heads, int max_nq, int max_nk) {
+    const int nqb = (max_nq + ATT_QB - 1) / ATT_QB;
+    const long base = (long)nviews * heads * nqb;
+    const int ntiles = (max_nk + ATT_KT - 1) / ATT_KT;
+    if (base >= 384 || ntiles < 8) return 1;
+    int s = (int)((768 + base - 1) / base);  // aim at ~3 blocks per CU
+    if (s > ntiles / 4) s = ntiles / 4;       // at least 4 key tiles per block
+    if (s > 16) s = 16;
+    return s < 2 ? 1 : s;
 }
 
 // hardware-semantics probe used by the tests: LDS holds element index e at position e; every lane issues the
@@ -233,11 +303,24 @@ int launch_tr_probe(short* out, hipStream_t s) {
 int launch_attention(DType dt, const AttnArgs& a, hipStream_t s, const char** err) {
     if (a.nviews <= 0 || a.max_nq <= 0) return 0;
     if ((a.ldq % 8) || (a.ldk % 8) || (a.ldv % 8) || (a.ldo % 4)) { *err = "attention: row strides must be 16-byte aligned"; return 1; }
+    const int nsplit = a.nsplit > 1 ? a.nsplit : 1;
+    if (nsplit > 1 && (!a.part_o || !a.part_ml || a.total_q_rows <= 0)) { *err = "attention: split-KV needs scratch"; return 1; }
     const int nqb = (a.max_nq + ATT_QB - 1) / ATT_QB;
     const int ngrp = a.nviews * a.heads;
-    const int grid = ((ngrp + 7) / 8) * 8 * nqb;
-    if (dt == DT_BF16) hipLaunchKernelGGL(attn_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, a, nqb, ngrp);
-    else hipLaunchKernelGGL(attn_kernel<f16_t>, dim3(grid), dim3(256), 0, s, a, nqb, ngrp);
+    const int grid = ((ngrp + 7) / 8) * 8 * nqb * nsplit;
+    if (nsplit > 1) {
+        const size_t n2 = (size_t)nsplit * a.total_q_rows * a.heads;
+        hipLaunchKernelGGL(attn_ml_init_kernel, dim3((unsigned)((n2 + 255) / 256 < 1024 ? (n2 + 255) / 256 : 1024)), dim3(256), 0, s,
+                           a.part_ml, n2);
+    }
+    if (dt == DT_BF16) hipLaunchKernelGGL(attn_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, a, nqb, ngrp, nsplit);
+    else hipLaunchKernelGGL(attn_kernel<f16_t>, dim3(grid), dim3(256), 0, s, a, nqb, ngrp, nsplit);
+    if (nsplit > 1) {
+        const size_t total = (size_t)a.total_q_rows * a.heads * 16;
+        const unsigned g2 = (unsigned)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+        if (dt == DT_BF16) hipLaunchKernelGGL(attn_combine_kernel<bf16_t>, dim3(g2), dim3(256), 0, s, a, nsplit);
+        else hipLaunchKernelGGL(attn_combine_kernel<f16_t>, dim3(g2), dim3(256), 0, s, a, nsplit);
+    }
     if (hipGetLastError() != hipSuccess) { *err = "attention: kernel launch failed"; return 1; }
     return 0;
 }

@@ -50,6 +50,8 @@ __global__ void __launch_bounds__(256) gemm_kernel(const GemmArgs p) {
     const T* __restrict__ W = reinterpret_cast<const T*>(p.W);
 
     // ---- staging: one wave instruction moves 8 rows x 128 B
+    const int wsp = p.wsplit > 1 ? p.wsplit : 1;
+    const int nka = p.K / BK;          // k-tiles of A; the W' = [W_hi | W_lo] sequence is wsp times longer
     const int srow = lane >> 3;
     const int pch = lane & 7;
     const T* a_src[BM / 32];
@@ -66,12 +68,12 @@ __global__ void __launch_bounds__(256) gemm_kernel(const GemmArgs p) {
         const int r = (wave * (BN / 32) + t) * 8 + srow;
         int gr = n0 + r;
         gr = gr < p.N ? gr : p.N - 1;
-        w_src[t] = W + (size_t)gr * p.K + swz(r, pch) * 8;
+        w_src[t] = W + (size_t)gr * (size_t)(p.K * wsp) + swz(r, pch) * 8;
     }
     auto stage = [&](int kt, int buf) {
 #pragma unroll
         for (int t = 0; t < BM / 32; ++t)
-            glds16(a_src[t] + kt * BK, sA + (buf * BM + (wave * (BM / 32) + t) * 8) * BK);
+            glds16(a_src[t] + (kt >= nka ? kt - nka : kt) * BK, sA + (buf * BM + (wave * (BM / 32) + t) * 8) * BK);
 #pragma unroll
         for (int t = 0; t < BN / 32; ++t)
             glds16(w_src[t] + kt * BK, sW + (buf * BN + (wave * (BN / 32) + t) * 8) * BK);
@@ -85,7 +87,7 @@ __global__ void __launch_bounds__(256) gemm_kernel(const GemmArgs p) {
 
     const int fr = lane & 15;   // fragment row supplied by this lane
     const int fg = lane >> 4;   // k-group (16-byte chunk) supplied by this lane
-    const int nk = p.K / BK;
+    const int nk = nka * wsp;
 
     stage(0, 0);
     for (int kt = 0; kt < nk; ++kt) {

@@ -26,6 +26,9 @@ struct GemmArgs {
     const float* bias;
     void* out;
     int M, N, K, lda, ldc;
+    // split-weight mode: W is [N, wsplit*K] = [W_hi | W_lo] (both 16-bit); the A tile sequence wraps after K.
+    // out = A.W_hi^T + A.W_lo^T accumulated in fp32 -> weight rounding error drops from 2^-11 to ~2^-22.
+    int wsplit;              // 0/1 = plain, 2 = [hi|lo]
     // EPI_QKV_ROPE
     const int64_t* pos;      // [M,2] (y,x)
     const float* rope_tab;   // [npos][16][2] (cos,sin)
@@ -62,7 +65,17 @@ struct AttnArgs {
     int nviews;
     int max_nq;                                               // max over views of nq
     float scale;                                              // 1/sqrt(64)
+    // split-KV (flash-decoding): when a launch has too few (view, head, q-block) groups to fill 256 CUs the key range
+    // is cut into nsplit chunks, each block writes un-normalised fp32 partials + (m, l) and a second kernel merges.
+    int nsplit;            // <= 1: single pass
+    float* part_o;         // [nsplit][total_q_rows][heads*64] fp32
+    float* part_ml;        // [nsplit][total_q_rows][heads][2] fp32 (running max in log2 domain, row sum)
+    int total_q_rows;      // max over views of q_row0 + nq
 };
+// bytes of scratch launch_attention needs for a given split factor
+size_t attention_split_scratch_bytes(int nsplit, int total_q_rows, int heads);
+// heuristic split factor for a launch
+int attention_pick_split(int nviews, int heads, int max_nq, int max_nk);
 int launch_attention(DType dt, const AttnArgs& a, hipStream_t s, const char** err);
 
 // ---------------------------------------------------------------------------------------------

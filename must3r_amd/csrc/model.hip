@@ -50,6 +50,7 @@ struct Param {
     float* d = nullptr;       // fp32 master on device
     void* h16[2] = {nullptr, nullptr};   // packed 16-bit copy per dtype (lazy)
     void* l16[2] = {nullptr, nullptr};   // low part (split precision), lazy, only where needed
+    void* x2[2] = {nullptr, nullptr};    // [rows][hi(K) | lo(K)] layout for the split-weight GEMM, lazy
     bool loaded = false;
     bool derived = false;     // built by finalize, not loaded
 };
@@ -63,6 +64,7 @@ struct must3r_hip_ctx {
     int device = 0;
     std::map<std::string, Param> params;
     bool fin_enc = false, fin_dec = false;
+    int wsplit = 0;            // 2 while a forward runs in MUST3R_F16_W2 mode
     float* rope_tab = nullptr;
     int rope_npos = 0;
     // workspace arena (grow-only)
@@ -161,6 +163,7 @@ static int gemm(must3r_hip_ctx* c, DType dt, Epi epi, GemmArgs a, hipStream_t s)
     const char* err = "";
     const long tiles128 = (long)((a.M + 127) / 128) * (a.N / 128);
     const int cat = (a.N % 128 == 0 && tiles128 >= 192) ? PC_GEMM128 : PC_GEMM64;
+    if (c && epi != EPI_HEAD) a.wsplit = c->wsplit;
     ProfScope ps(c, s, cat, 2.0 * a.M * a.N * a.K);
     if (launch_gemm(dt, epi, a, s, &err)) return fail("%s (M=%d N=%d K=%d epi=%d)", err, a.M, a.N, a.K, (int)epi);
     return 0;
@@ -265,7 +268,19 @@ static int p16(must3r_hip_ctx* c, const std::string& name, DType dt, bool want_l
     return 0;
 }
 static int w16(must3r_hip_ctx* c, const std::string& name, DType dt, const void** hi, hipStream_t s) {
-    return p16(c, name, dt, false, hi, nullptr, s);
+    if (c->wsplit != 2) return p16(c, name, dt, false, hi, nullptr, s);
+    // split-weight mode: rows of [W_hi | W_lo] so the GEMM's K loop simply runs twice as long
+    Param& p = c->params.at(name);
+    if (!p.x2[dt]) {
+        const void *h, *l;
+        M3R_OK(p16(c, name, dt, true, &h, &l, s));
+        const size_t rows = (size_t)p.shape[0], K = p.n / rows;
+        HIP_OK(hipMalloc(&p.x2[dt], p.n * 4));
+        HIP_OK(hipMemcpy2DAsync(p.x2[dt], K * 4, h, K * 2, K * 2, rows, hipMemcpyDeviceToDevice, s));
+        HIP_OK(hipMemcpy2DAsync(reinterpret_cast<char*>(p.x2[dt]) + K * 2, K * 4, l, K * 2, K * 2, rows, hipMemcpyDeviceToDevice, s));
+    }
+    *hi = p.x2[dt];
+    return 0;
 }
 
 extern "C" int must3r_hip_rope_table(float freq, float f0, int npos, float* out) {
@@ -329,6 +344,7 @@ extern "C" void must3r_hip_destroy(must3r_hip_ctx* c) {
         for (int i = 0; i < 2; ++i) {
             if (p.h16[i]) (void)hipFree(p.h16[i]);
             if (p.l16[i]) (void)hipFree(p.l16[i]);
+            if (p.x2[i]) (void)hipFree(p.x2[i]);
         }
     }
     if (c->rope_tab) (void)hipFree(c->rope_tab);
@@ -355,6 +371,7 @@ extern "C" int must3r_hip_load_weight(must3r_hip_ctx* c, const char* name, const
     for (int i = 0; i < 2; ++i) {  // invalidate packed copies
         if (p->h16[i]) { (void)hipFree(p->h16[i]); p->h16[i] = nullptr; }
         if (p->l16[i]) { (void)hipFree(p->l16[i]); p->l16[i] = nullptr; }
+        if (p->x2[i]) { (void)hipFree(p->x2[i]); p->x2[i] = nullptr; }
     }
     p->loaded = true;
     if (strncmp(name, "encoder.", 8) == 0) c->fin_enc = false; else c->fin_dec = false;
@@ -367,6 +384,7 @@ static int derive(must3r_hip_ctx* c, const std::string& name, std::vector<int64_
     for (int i = 0; i < 2; ++i) {
         if (p.h16[i]) { (void)hipFree(p.h16[i]); p.h16[i] = nullptr; }
         if (p.l16[i]) { (void)hipFree(p.l16[i]); p.l16[i] = nullptr; }
+        if (p.x2[i]) { (void)hipFree(p.x2[i]); p.x2[i] = nullptr; }
     }
     p.shape = shape;
     p.n = host.size();
@@ -505,7 +523,9 @@ extern "C" int must3r_hip_encode(must3r_hip_ctx* c, int dtype, const float* img,
                                  float* out_tokens, int64_t* out_pos, void* stream) {
     if (!c || !img || !out_tokens || !out_pos) return fail("encode: null argument");
     if (!c->fin_enc) return fail("encode: encoder weights not finalized");
-    if (dtype != MUST3R_BF16 && dtype != MUST3R_F16) return fail("encode: bad dtype %d", dtype);
+    if (dtype != MUST3R_BF16 && dtype != MUST3R_F16 && dtype != MUST3R_F16_W2) return fail("encode: bad dtype %d", dtype);
+    c->wsplit = dtype == MUST3R_F16_W2 ? 2 : 0;
+    if (dtype == MUST3R_F16_W2) dtype = MUST3R_F16;
     if (n_views <= 0) return 0;
     if (H <= 0 || W <= 0 || H % 16 || W % 16) return fail("encode: H=%d W=%d must be positive multiples of 16", H, W);
     if (H / 16 > c->rope_npos || W / 16 > c->rope_npos) return fail("encode: image too large for the RoPE table");
@@ -528,14 +548,15 @@ extern "C" int must3r_hip_encode(must3r_hip_ctx* c, int dtype, const float* img,
 extern "C" int must3r_hip_decode(must3r_hip_ctx* c, const must3r_hip_decode_args* A, void* stream) {
     if (!c || !A || !A->groups || !A->mem) return fail("decode: null argument");
     if (!c->fin_dec) return fail("decode: decoder weights not finalized");
-    if (A->dtype != MUST3R_BF16 && A->dtype != MUST3R_F16) return fail("decode: bad dtype %d", A->dtype);
+    if (A->dtype != MUST3R_BF16 && A->dtype != MUST3R_F16 && A->dtype != MUST3R_F16_W2) return fail("decode: bad dtype %d", A->dtype);
+    c->wsplit = A->dtype == MUST3R_F16_W2 ? 2 : 0;
     if (A->mem_mode != MUST3R_MEM_KV) return fail("decode: only memory_mode 'kv' is implemented natively");
     if (A->n_groups <= 0) return fail("decode: no input group");
     if (A->render && (A->first_call || A->n_mem <= 0)) return fail("decode: render needs a memory (decoder.py:278)");
     if (A->first_call && A->n_mem != 0) return fail("decode: first_call with a non-empty memory");
     HIP_OK(hipSetDevice(c->device));
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    const DType dt = (DType)A->dtype;
+    const DType dt = A->dtype == MUST3R_F16_W2 ? DT_F16 : (DType)A->dtype;
     const must3r_hip_config& g = c->cfg;
     const int C = g.enc_dim, D = g.dec_dim, Hh = g.dec_heads, F = g.mlp_ratio * D, L = g.dec_depth, Nm = A->n_mem;
     const int OUT = g.patch_size * g.patch_size * 7;
@@ -576,6 +597,11 @@ extern "C" int must3r_hip_decode(must3r_hip_ctx* c, const must3r_hip_decode_args
         need = ws_need(need, (size_t)L * R * D, 4);   // memorised layer inputs
         need = ws_need(need, (size_t)R * D, 4);       // feedback offset
     }
+    // split-KV cross attention when the launch cannot fill the chip (sequential memory update: one view per call)
+    const int max_nk_ca = A->render ? Nm : Nm + (lone_view ? 0 : R);
+    const int ca_split = attention_pick_split(total_views, Hh, max_n, max_nk_ca);
+    const size_t split_bytes = attention_split_scratch_bytes(ca_split, R, Hh);
+    need = ws_need(need, split_bytes, 1);
     M3R_OK(ws_reserve(c, need, s));
     uint16_t* t16 = ws_take<uint16_t>(c, (size_t)R * C);
     float* x = ws_take<float>(c, (size_t)R * D);
@@ -587,7 +613,8 @@ extern "C" int must3r_hip_decode(must3r_hip_ctx* c, const must3r_hip_decode_args
     uint16_t* g16 = ws_take<uint16_t>(c, (size_t)R * F);
     float* newmem = update ? ws_take<float>(c, (size_t)L * R * D) : nullptr;
     float* off32 = update ? ws_take<float>(c, (size_t)R * D) : nullptr;
-    if (!g16 || (update && !off32)) return fail("decode: workspace sizing bug");
+    char* split_ws = split_bytes ? ws_take<char>(c, split_bytes) : nullptr;
+    if (!g16 || (update && !off32) || (split_bytes && !split_ws)) return fail("decode: workspace sizing bug");
 
     // ---- per-view tables: self-attention, cross-attention; positions gathered into one [R,2] array
     std::vector<AttnView> tab(2 * (size_t)total_views);
@@ -684,6 +711,11 @@ extern "C" int must3r_hip_decode(must3r_hip_ctx* c, const must3r_hip_decode_args
         aa.Q = q16; aa.K = mk; aa.V = mk + D; aa.O = a16;
         aa.ldq = D; aa.ldk = aa.ldv = 2 * D; aa.ldo = D; aa.heads = Hh;
         aa.views = ca_views; aa.nviews = total_views; aa.max_nq = max_n; aa.scale = 0.125f;
+        if (ca_split > 1) {
+            aa.nsplit = ca_split; aa.total_q_rows = R;
+            aa.part_o = reinterpret_cast<float*>(split_ws);
+            aa.part_ml = aa.part_o + (size_t)ca_split * R * D;
+        }
         M3R_OK(attention(c, dt, aa, ca_flops, PC_ATTN_CA, s));
         M3R_OK(w16(c, b + ".cross_attn.proj.weight", dt, &w, s));
         M3R_OK(gemm(c, dt, EPI_RESID_F32, gargs(a16, w, p32(c, b + ".cross_attn.proj.bias"), x, R, D, D, D, D), s));
@@ -744,25 +776,36 @@ extern "C" int must3r_hip_postprocess(const float* pm, float* p3, float* pl, flo
 extern "C" int must3r_hip_op_gemm(int dtype, int epi, const void* A, const void* W, const float* bias, void* out, int M, int N,
                                   int K, int lda, int ldc, const int64_t* pos, const float* rope_tab, int rope_cols,
                                   int rope_npos, const float* bias2, int row_start2, int accumulate, int ntok, int gw, int H,
-                                  int W_img, void* stream) {
+                                  int W_img, int wsplit, void* stream) {
     if (dtype != MUST3R_BF16 && dtype != MUST3R_F16) return fail("op_gemm: bad dtype");
     if (epi < 0 || epi >= EPI_COUNT) return fail("op_gemm: bad epilogue");
     GemmArgs a = gargs(A, W, bias, out, M, N, K, lda, ldc);
     a.pos = pos; a.rope_tab = rope_tab; a.rope_cols = rope_cols; a.rope_npos = rope_npos;
     a.bias2 = bias2; a.row_start2 = row_start2; a.accumulate = accumulate;
-    a.ntok = ntok; a.gw = gw; a.H = H; a.Wimg = W_img;
+    a.ntok = ntok; a.gw = gw; a.H = H; a.Wimg = W_img; a.wsplit = wsplit;
     const char* err = "";
     if (launch_gemm((DType)dtype, (Epi)epi, a, reinterpret_cast<hipStream_t>(stream), &err)) return fail("%s", err);
     return 0;
 }
 
+extern "C" size_t must3r_hip_attention_scratch_bytes(int nsplit, int total_q_rows, int heads) {
+    return attention_split_scratch_bytes(nsplit, total_q_rows, heads);
+}
+
 extern "C" int must3r_hip_op_attention(int dtype, const void* Q, const void* K, const void* V, void* O, int ldq, int ldk, int ldv,
-                                       int ldo, int heads, const int32_t* views_dev, int n_views, int max_nq, void* stream) {
+                                       int ldo, int heads, const int32_t* views_dev, int n_views, int max_nq, int nsplit,
+                                       void* scratch, int total_q_rows, void* stream) {
     if (dtype != MUST3R_BF16 && dtype != MUST3R_F16) return fail("op_attention: bad dtype");
     AttnArgs a;
     memset(&a, 0, sizeof(a));
     a.Q = Q; a.K = K; a.V = V; a.O = O; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo; a.heads = heads;
     a.views = reinterpret_cast<const AttnView*>(views_dev); a.nviews = n_views; a.max_nq = max_nq; a.scale = 0.125f;
+    if (nsplit > 1) {
+        if (!scratch || total_q_rows <= 0) return fail("op_attention: split-KV needs scratch and total_q_rows");
+        a.nsplit = nsplit; a.total_q_rows = total_q_rows;
+        a.part_o = reinterpret_cast<float*>(scratch);
+        a.part_ml = a.part_o + (size_t)nsplit * total_q_rows * heads * 64;
+    }
     const char* err = "";
     if (launch_attention((DType)dtype, a, reinterpret_cast<hipStream_t>(stream), &err)) return fail("%s", err);
     return 0;

@@ -5,13 +5,15 @@ import torch.nn as nn
 
 from .. import _lib
 
-_DT = {"bf16": _lib.BF16, "fp16": _lib.F16, torch.bfloat16: _lib.BF16, torch.float16: _lib.F16}
-_TORCH_DT = {_lib.BF16: torch.bfloat16, _lib.F16: torch.float16}
+# 'fp16w2' = fp16 operands with split weights (W_hi + W_lo): the mode that meets the 1e-3 parity target with margin
+_DT = {"bf16": _lib.BF16, "fp16": _lib.F16, "fp16w2": _lib.F16_W2, torch.bfloat16: _lib.BF16, torch.float16: _lib.F16}
+_TORCH_DT = {_lib.BF16: torch.bfloat16, _lib.F16: torch.float16, _lib.F16_W2: torch.float16}
+PRECISIONS = ("bf16", "fp16", "fp16w2")
 
 
 def operand_dtype(precision):
     if precision not in _DT:
-        raise ValueError(f"precision must be 'bf16' or 'fp16', got {precision!r}")
+        raise ValueError(f"precision must be one of {PRECISIONS}, got {precision!r}")
     return _DT[precision]
 
 

@@ -115,9 +115,11 @@ class MUSt3R(HipModule):
 
     def _operand(self):
         ac = autocast_dtype()
-        if ac in (torch.bfloat16, torch.float16):
-            return _DT[ac]
-        return operand_dtype(self.precision)
+        if ac == torch.bfloat16:
+            return _lib.BF16
+        if ac == torch.float16 and self.precision == "bf16":
+            return _lib.F16
+        return operand_dtype(self.precision)  # no autocast, or fp16 autocast with an fp16-family precision
 
     # -- memory management ---------------------------------------------------------------------
     def _writable_memory(self, mem_vals, Nm, R, tdt, device):

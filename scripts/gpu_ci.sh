@@ -4,20 +4,19 @@
 set -u
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 mkdir -p gpurun_out
-rm -f gpurun_out/test_metrics.jsonl
 export PYTHONDONTWRITEBYTECODE=1
 STAGE=${1:-all}
 echo "== rocminfo"; /opt/rocm/bin/rocminfo 2>/dev/null | grep -E "gfx950|Compute Unit" | head -4
 nproc
 if [ "$STAGE" = "all" ] || [ "$STAGE" = "ops" ]; then
   echo "== ops"
-  timeout 900 python -m pytest tests/test_ops_gpu.py -m gpu -q -p no:cacheprovider --timeout=300 2>&1 | tail -60 | tee gpurun_out/ops.log
-  rc=${PIPESTATUS[0]}
+  timeout 900 python -m pytest tests/test_ops_gpu.py -m gpu -q -p no:cacheprovider --timeout=300 > gpurun_out/ops.log 2>&1; tail -40 gpurun_out/ops.log
+  rc=$?
   if [ $rc -ne 0 ] && [ "$STAGE" = "all" ]; then echo "ops failed (rc=$rc): stopping"; exit 1; fi
 fi
 if [ "$STAGE" = "all" ] || [ "$STAGE" = "model" ]; then
   echo "== model"
-  timeout 1500 python -m pytest tests/test_model_gpu.py -m gpu -q -p no:cacheprovider --timeout=900 2>&1 | tail -60 | tee gpurun_out/model.log
+  timeout 1500 python -m pytest tests/test_model_gpu.py -m gpu -q -p no:cacheprovider --timeout=900 > gpurun_out/model.log 2>&1; tail -40 gpurun_out/model.log
   echo "== smoke"
   timeout 600 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -20 | tee gpurun_out/smoke.log
 fi

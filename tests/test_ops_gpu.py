@@ -37,13 +37,13 @@ def P(t):
 
 
 def run_gemm(lib, dt, epi, A, W, bias, out, ldc=None, pos=None, tab=None, rope_cols=0, npos=0, bias2=None, row2=0, acc=0,
-             ntok=0, gw=0, H=0, Wimg=0):
+             ntok=0, gw=0, H=0, Wimg=0, wsplit=0):
     M, K = A.shape
     N = W.shape[0]
     L = lib.load()
     lib.check(L.must3r_hip_op_gemm(DT[dt][0], epi, P(A), P(W), P(bias), P(out), M, N, K, A.stride(0),
                                    ldc if ldc is not None else N, P(pos), P(tab), rope_cols, npos, P(bias2), row2, acc,
-                                   ntok, gw, H, Wimg, stream()))
+                                   ntok, gw, H, Wimg, wsplit, stream()))
     torch.cuda.synchronize()
 
 
@@ -106,8 +106,32 @@ def test_gemm_store_gelu_resid_f32(lib, dt, shape):
     record("gemm", dt=dt, shape=shape, store=e1, gelu=e2, resid=e3, f32=e4)
 
 
+@pytest.mark.parametrize("shape", [(768, 768, 768), (3072, 1024, 512), (200, 128, 64)])
+def test_gemm_split_weights(lib, shape):
+    """W = W_hi + W_lo in fp16, two MFMA passes: the weight rounding term must vanish (error -> activation rounding
+    + fp32 accumulation only) and the result must equal the explicit two-GEMM sum."""
+    M, N, K = shape
+    g = torch.Generator(device="cuda").manual_seed(21)
+    A = torch.randn((M, K), device="cuda", generator=g).half()
+    Wf = torch.randn((N, K), device="cuda", generator=g) / math.sqrt(K)
+    hi = Wf.half()
+    lo = (Wf - hi.float()).half()
+    W2 = torch.cat((hi, lo), dim=1).contiguous()
+    bias = torch.randn((N,), device="cuda", generator=g)
+    out = torch.empty((M, N), device="cuda")
+    L = lib.load()
+    lib.check(L.must3r_hip_op_gemm(1, lib.EPI_F32, P(A), P(W2), P(bias), P(out), M, N, K, K, N, None, None, 0, 0, None, 0, 0,
+                                   0, 0, 0, 0, 2, stream()))
+    torch.cuda.synchronize()
+    ref = A.double() @ Wf.double().t() + bias.double()
+    plain = A.double() @ hi.double().t() + bias.double()
+    e_split, e_plain = rel_inf(out, ref), rel_inf(plain, ref)
+    record("gemm_split", shape=shape, split=e_split, plain_fp16_weights=e_plain)
+    assert e_split < 2e-6 and e_split < e_plain / 20, (e_split, e_plain)
+
+
 @pytest.mark.parametrize("dt", ["bf16", "fp16"])
-@pytest.mark.parametrize("geom", [(2, 14, 14, 128), (1, 24, 32, 768), (3, 3, 4, 1024)])
+@pytest.mark.parametrize("geom", [(2, 14, 14, 128), (1, 24, 32, 768), (3, 3, 4, 1024), (4, 24, 32, 256)])
 def test_gemm_qkv_rope(lib, dt, geom):
     from oracle import must3r_ref as R
     V, gh, gw, Cdim = geom
@@ -205,13 +229,26 @@ def test_attention(lib, dt, case):
     o = torch.full((Rq, D), float("nan"), device="cuda", dtype=tdt)
     tab = torch.tensor(views, dtype=torch.int32, device="cuda")
     lib.check(lib.load().must3r_hip_op_attention(DT[dt][0], P(q), P(k), P(v), P(o), q.stride(0), k.stride(0), v.stride(0),
-                                                 o.stride(0), heads, P(tab), len(views), max(vw[1] for vw in views), stream()))
+                                                 o.stride(0), heads, P(tab), len(views), max(vw[1] for vw in views), 0, None, 0,
+                                                 stream()))
     torch.cuda.synchronize()
     ref = attn_ref(q.cpu(), k.cpu(), v.cpu(), views, heads)
     e = rel_inf(o.cpu(), ref)
-    record("attention", dt=dt, case=case, err=e)
     assert torch.isfinite(o.float()).all()
     assert e < 8 * u, e  # P and O are rounded to 16 bit; everything else is fp32
+    # split-KV (flash-decoding) variants of the same problem must agree with the single-pass result
+    es = {}
+    for ns in (2, 3, 5):
+        o2 = torch.full((Rq, D), float("nan"), device="cuda", dtype=tdt)
+        nb = lib.load().must3r_hip_attention_scratch_bytes(ns, Rq, heads)
+        ws = torch.empty((nb,), dtype=torch.uint8, device="cuda")
+        lib.check(lib.load().must3r_hip_op_attention(DT[dt][0], P(q), P(k), P(v), P(o2), q.stride(0), k.stride(0), v.stride(0),
+                                                     o2.stride(0), heads, P(tab), len(views), max(vw[1] for vw in views), ns,
+                                                     P(ws), Rq, stream()))
+        torch.cuda.synchronize()
+        es[ns] = rel_inf(o2.cpu(), ref)
+        assert torch.isfinite(o2.float()).all() and es[ns] < 8 * u, (ns, es[ns])
+    record("attention", dt=dt, case=case, err=e, split_err=es)
 
 
 @pytest.mark.parametrize("dt", ["bf16", "fp16"])
@@ -228,7 +265,7 @@ def test_attention_running_max_jump(lib, dt):
     o = torch.empty((nq, 64), device="cuda", dtype=tdt)
     tab = torch.tensor(views, dtype=torch.int32, device="cuda")
     lib.check(lib.load().must3r_hip_op_attention(DT[dt][0], P(q), P(kv), P(kv[:, 64:]), P(o), 64, 128, 128, 64, heads, P(tab), 1, nq,
-                                                 stream()))
+                                                 0, None, 0, stream()))
     torch.cuda.synchronize()
     ref = attn_ref(q.cpu(), kv[:, :64].cpu(), kv[:, 64:].cpu(), views, heads)
     e = rel_inf(o.cpu(), ref)
