@@ -25,8 +25,9 @@ __global__ void __launch_bounds__(256) attn_kernel(const AttnArgs p, const int n
     typedef typename Vec<T>::v8 v8;
     typedef typename Vec<T>::v4 v4;
     constexpr int QF = ATT_QW / 16;
-    __shared__ __attribute__((aligned(16))) T sK[2][ATT_KT * 64];
-    __shared__ __attribute__((aligned(16))) T sV[2][ATT_KT * 64];
+    // ONE __shared__ object: with two, hipcc drains the in-flight LDS-DMA (vmcnt(0)) before every first ds_read of a
+    // tile, which serialises prefetch and compute (cdna_hip_programming.md, ".s-level traps" (a)).
+    __shared__ __attribute__((aligned(16))) T smem_kv[2][2][ATT_KT * 64];   // [buffer][K|V][64 keys x 64]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -88,8 +89,8 @@ __global__ void __launch_bounds__(256) attn_kernel(const AttnArgs p, const int n
             int key = t * ATT_KT + r;
             key = key < nk ? key : nk - 1;
             const int lc = swz(r, pch);
-            glds16(K + (size_t)key * p.ldk + lc * 8, &sK[buf][piece * 8 * 64]);
-            glds16(V + (size_t)key * p.ldv + lc * 8, &sV[buf][piece * 8 * 64]);
+            glds16(K + (size_t)key * p.ldk + lc * 8, &smem_kv[buf][0][piece * 8 * 64]);
+            glds16(V + (size_t)key * p.ldv + lc * 8, &smem_kv[buf][1][piece * 8 * 64]);
         }
     };
 
@@ -114,8 +115,8 @@ __global__ void __launch_bounds__(256) attn_kernel(const AttnArgs p, const int n
         const int tn = advance(t);
         if (tn < t_end) stage(tn, buf ^ 1);
 
-        const T* k_ = sK[buf];
-        const T* v_ = sV[buf];
+        const T* k_ = smem_kv[buf][0];
+        const T* v_ = smem_kv[buf][1];
         // ---- S^T = K Q^T
         f32x4 s_[4][QF];
 #pragma unroll
@@ -171,8 +172,10 @@ __global__ void __launch_bounds__(256) attn_kernel(const AttnArgs p, const int n
                     ps += e;
                 }
             l_[f] = l_[f] * alpha + ps;
+            if (!__all(alpha == 1.0f)) {  // wave-uniform: once the running max has settled the O rescale is skipped
 #pragma unroll
-            for (int d = 0; d < 4; ++d) o_[d][f] *= alpha;
+                for (int d = 0; d < 4; ++d) o_[d][f] *= alpha;
+            }
         }
         // ---- O^T += V^T P^T ; k-slot e of lane group g <-> keys {4g+e (e<4), 16+4g+e-4 (e>=4)} of the 32-key slot
 #pragma unroll
@@ -188,15 +191,23 @@ __global__ void __launch_bounds__(256) attn_kernel(const AttnArgs p, const int n
                 }
                 pb[f] = cvt8<T>(pv);
             }
+            // transposing reads: chunk m = fr of the 16-lane group = row (m>>2), d-columns 4*(m&3)..+3
+            v4 tr[8];
+            {
+                const int r0 = ks * 32 + fg * 4 + (fr >> 2), r1 = r0 + 16;
+                const int c0 = (fr & 3) * 4;                       // d = 16*dd + c0
+                const T* a[8];
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    const int dc = d * 16 + c0;
+                    a[2 * d] = v_ + r0 * 64 + swz(r0, dc >> 3) * 8 + (dc & 7);
+                    a[2 * d + 1] = v_ + r1 * 64 + swz(r1, dc >> 3) * 8 + (dc & 7);
+                }
+                lds_read_tr4_x8<T>(a[0], a[1], a[2], a[3], a[4], a[5], a[6], a[7], tr);
+            }
 #pragma unroll
             for (int d = 0; d < 4; ++d) {
-                // transposing read: chunk m = fr of the 16-lane group = row (m>>2), d-columns 4*(m&3)..+3
-                const int r0 = ks * 32 + fg * 4 + (fr >> 2);
-                const int dc = d * 16 + (fr & 3) * 4;
-                const int r1 = r0 + 16;
-                const v4 lo = lds_read_tr4<T>(v_ + r0 * 64 + swz(r0, dc >> 3) * 8 + (dc & 7));
-                const v4 hi = lds_read_tr4<T>(v_ + r1 * 64 + swz(r1, dc >> 3) * 8 + (dc & 7));
-                const v8 vfrag = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                const v8 vfrag = __builtin_shufflevector(tr[2 * d], tr[2 * d + 1], 0, 1, 2, 3, 4, 5, 6, 7);
 #pragma unroll
                 for (int f = 0; f < QF; ++f) o_[d][f] = mfma16(vfrag, pb[f], o_[d][f]);
             }

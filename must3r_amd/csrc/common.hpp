@@ -49,6 +49,36 @@ template <class T> __device__ __forceinline__ typename Vec<T>::v4 lds_read_tr4(c
     return o;
 }
 
+// Eight transposing reads (one 32-key slot of V^T: 4 d-fragments x {keys 0-15, keys 16-31}) issued from inline asm
+// together with their own lgkmcnt(0).  hipcc orders the builtin form behind every in-flight LDS-DMA (it emits
+// s_waitcnt vmcnt(0) before it), which would drain the next tile's prefetch in the middle of the current tile; the
+// asm form is invisible to that bookkeeping.  The reads only touch the tile buffer whose DMA was already waited for.
+typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+template <class T>
+__device__ __forceinline__ void lds_read_tr4_x8(const T* p0, const T* p1, const T* p2, const T* p3, const T* p4, const T* p5,
+                                                const T* p6, const T* p7, typename Vec<T>::v4 (&out)[8]) {
+    u32x2 r0, r1, r2, r3, r4, r5, r6, r7;
+#define M3R_LDS_ADDR(p) ((unsigned)(size_t)(__attribute__((address_space(3))) const T*)(p))
+    asm volatile(
+        "ds_read_b64_tr_b16 %0, %8\n\t"
+        "ds_read_b64_tr_b16 %1, %9\n\t"
+        "ds_read_b64_tr_b16 %2, %10\n\t"
+        "ds_read_b64_tr_b16 %3, %11\n\t"
+        "ds_read_b64_tr_b16 %4, %12\n\t"
+        "ds_read_b64_tr_b16 %5, %13\n\t"
+        "ds_read_b64_tr_b16 %6, %14\n\t"
+        "ds_read_b64_tr_b16 %7, %15\n\t"
+        "s_waitcnt lgkmcnt(0)"
+        : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3), "=&v"(r4), "=&v"(r5), "=&v"(r6), "=&v"(r7)
+        : "v"(M3R_LDS_ADDR(p0)), "v"(M3R_LDS_ADDR(p1)), "v"(M3R_LDS_ADDR(p2)), "v"(M3R_LDS_ADDR(p3)), "v"(M3R_LDS_ADDR(p4)),
+          "v"(M3R_LDS_ADDR(p5)), "v"(M3R_LDS_ADDR(p6)), "v"(M3R_LDS_ADDR(p7))
+        : "memory");
+#undef M3R_LDS_ADDR
+    const u32x2 r[8] = {r0, r1, r2, r3, r4, r5, r6, r7};
+#pragma unroll
+    for (int i = 0; i < 8; ++i) __builtin_memcpy(&out[i], &r[i], 8);
+}
+
 // async global -> LDS, 16 bytes per lane; LDS destination = (wave-uniform) lds_base + lane*16.
 __device__ __forceinline__ void glds16(const void* gptr, void* lds_base_uniform) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gptr,

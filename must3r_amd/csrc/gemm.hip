@@ -17,7 +17,7 @@
 
 namespace m3r {
 
-template <class T, int BM, int BN, int EPI>
+template <class T, int BM, int BN, int EPI, int NST>
 __global__ void __launch_bounds__(256) gemm_kernel(const GemmArgs p) {
     typedef typename Vec<T>::v8 v8;
     typedef typename Vec<T>::v4 v4;
@@ -25,8 +25,8 @@ __global__ void __launch_bounds__(256) gemm_kernel(const GemmArgs p) {
     constexpr int WM = BM / 2, WN = BN / 2;
     constexpr int MF = WM / 16, NF = WN / 16;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    T* sA = reinterpret_cast<T*>(smem);   // [2][BM][BK]
-    T* sW = sA + 2 * BM * BK;             // [2][BN][BK]
+    T* sA = reinterpret_cast<T*>(smem);   // [NST][BM][BK]
+    T* sW = sA + NST * BM * BK;           // [NST][BN][BK]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -89,12 +89,7 @@ __global__ void __launch_bounds__(256) gemm_kernel(const GemmArgs p) {
     const int fg = lane >> 4;   // k-group (16-byte chunk) supplied by this lane
     const int nk = nka * wsp;
 
-    stage(0, 0);
-    for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
-        __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): this wave's DMA for tile kt has landed
-        __syncthreads();                     // ... everyone's has, and tile kt-1 is no longer being read
-        if (kt + 1 < nk) stage(kt + 1, buf ^ 1);
+    auto compute = [&](int buf) {
         const T* a = sA + buf * BM * BK;
         const T* w = sW + buf * BN * BK;
 #pragma unroll
@@ -115,6 +110,43 @@ __global__ void __launch_bounds__(256) gemm_kernel(const GemmArgs p) {
             for (int i = 0; i < MF; ++i)
 #pragma unroll
                 for (int j = 0; j < NF; ++j) acc[i][j] = mfma16(wf[j], af[i], acc[i][j]);
+        }
+    };
+
+    if constexpr (NST == 2) {
+        // double buffer: the DMA of tile kt+1 is in flight while tile kt is multiplied
+        stage(0, 0);
+        for (int kt = 0; kt < nk; ++kt) {
+            const int buf = kt & 1;
+            __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): this wave's DMA for tile kt has landed
+            __syncthreads();                     // ... everyone's has, and tile kt-1 is no longer being read
+            if (kt + 1 < nk) stage(kt + 1, buf ^ 1);
+            compute(buf);
+        }
+    } else {
+        // NST-deep ring with COUNTED waits: NST-1 tiles of DMA in flight per block.  Small-M GEMMs run ~1 block per CU,
+        // so the per-tile L2/HBM round trip (not MFMA time) sets the pace unless several tiles overlap.
+        // Each wave issues IPT global_load_lds per tile; before tile kt is read only the (NST-2) younger tiles may
+        // still be outstanding -> s_waitcnt vmcnt((NST-2)*IPT), then a raw s_barrier (no vmcnt(0) drain).
+        constexpr int IPT = BM / 32 + BN / 32;
+        constexpr int PEND = (NST - 2) * IPT;
+        static_assert(PEND < 64, "vmcnt field");
+#pragma unroll
+        for (int t = 0; t < NST - 1; ++t)
+            if (t < nk) stage(t, t);
+        int buf = 0;
+        for (int kt = 0; kt < nk; ++kt) {
+            if (kt + NST - 2 < nk) __builtin_amdgcn_s_waitcnt(0x0f70 | (PEND & 15) | ((PEND >> 4) << 14));
+            else __builtin_amdgcn_s_waitcnt(0x0f70);   // tail: fewer tiles behind this one, drain
+            __builtin_amdgcn_s_barrier();
+            const int nt = kt + NST - 1;
+            if (nt < nk) {
+                int nb = buf + NST - 1;
+                nb = nb >= NST ? nb - NST : nb;
+                stage(nt, nb);                         // overwrites the buffer read in iteration kt-1
+            }
+            compute(buf);
+            buf = buf + 1 == NST ? 0 : buf + 1;
         }
     }
 
@@ -196,17 +228,17 @@ __global__ void __launch_bounds__(256) gemm_kernel(const GemmArgs p) {
     }
 }
 
-template <class T, int BM, int BN, int EPI>
+template <class T, int BM, int BN, int EPI, int NST>
 static int launch_cfg(const GemmArgs& a, hipStream_t s) {
     const int nbn = a.N / BN, nbm = (a.M + BM - 1) / BM;
-    const size_t lds = (size_t)2 * (BM + BN) * 64 * sizeof(T);
+    const size_t lds = (size_t)NST * (BM + BN) * 64 * sizeof(T);
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<T, BM, BN, EPI>),
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<T, BM, BN, EPI, NST>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm_kernel<T, BM, BN, EPI>), dim3(nbm * nbn), dim3(256), lds, s, a);
+    hipLaunchKernelGGL((gemm_kernel<T, BM, BN, EPI, NST>), dim3(nbm * nbn), dim3(256), lds, s, a);
     return hipGetLastError() == hipSuccess ? 0 : 1;
 }
 
@@ -215,8 +247,8 @@ static int launch_epi(const GemmArgs& a, hipStream_t s, const char** err) {
     const bool n128 = (a.N % 128) == 0;
     const long tiles128 = (long)((a.M + 127) / 128) * (a.N / 128);
     int rc;
-    if (n128 && tiles128 >= 192) rc = launch_cfg<T, 128, 128, EPI>(a, s);
-    else rc = launch_cfg<T, 64, 64, EPI>(a, s);
+    if (n128 && tiles128 >= 192) rc = launch_cfg<T, 128, 128, EPI, 2>(a, s);
+    else rc = launch_cfg<T, 64, 64, EPI, 4>(a, s);
     if (rc) *err = "gemm: kernel launch failed";
     return rc;
 }

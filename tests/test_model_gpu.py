@@ -161,7 +161,11 @@ def test_baseline_geometry_vs_oracle_and_properties(precision):
     mem_r, ren = dec(x.unsqueeze(0), pos.unsqueeze(0), ts_c.unsqueeze(0), mem, render=True)
     assert mem_r[0] is mem[0] and all(torch.equal(a, b) for a, b in zip(mem[0], snap))
     _, ren1 = dec(x[2:3].unsqueeze(0), pos[2:3].unsqueeze(0), ts_c[2:3].unsqueeze(0), mem, render=True)
-    assert torch.equal(ren1[0, 0], ren[0, 2]), "render pass is not per-view independent"
+    # per-view independence of the render pass (invariant 6).  Not bitwise: the split-KV factor of
+    # the cross attention depends on how many views share the launch, which changes the fp32 summation order.
+    e_ind = rel_inf(ren1[0, 0].cpu(), ren[0, 2].cpu())
+    record("render_independence", precision=precision, err=e_ind)
+    assert e_ind < 0.5 * TOL[precision], e_ind
     assert torch.isfinite(ren).all()
     # oracle on the first two views (init call + render)
     torch.set_num_threads(max(1, torch.get_num_threads()))
