@@ -21,7 +21,7 @@ constexpr int ATT_QB = 4 * ATT_QW;       // per block
 constexpr int ATT_KT = 64;               // keys per tile
 
 template <class T>
-__global__ void __launch_bounds__(256) attn_kernel(const AttnArgs p, const int nqb, const int ngrp, const int nsplit) {
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) attn_kernel(const AttnArgs p, const int nqb, const int ngrp, const int nsplit) {
     typedef typename Vec<T>::v8 v8;
     typedef typename Vec<T>::v4 v4;
     constexpr int QF = ATT_QW / 16;
@@ -88,9 +88,8 @@ __global__ void __launch_bounds__(256) attn_kernel(const AttnArgs p, const int n
             const int r = piece * 8 + srow;
             int key = t * ATT_KT + r;
             key = key < nk ? key : nk - 1;
-            const int lc = swz(r, pch);
-            glds16(K + (size_t)key * p.ldk + lc * 8, &smem_kv[buf][0][piece * 8 * 64]);
-            glds16(V + (size_t)key * p.ldv + lc * 8, &smem_kv[buf][1][piece * 8 * 64]);
+            glds16(K + (size_t)key * p.ldk + swz(r, pch) * 8, &smem_kv[buf][0][piece * 8 * 64]);
+            glds16(V + (size_t)key * p.ldv + swz_v(r, pch) * 8, &smem_kv[buf][1][piece * 8 * 64]);
         }
     };
 
@@ -103,7 +102,8 @@ __global__ void __launch_bounds__(256) attn_kernel(const AttnArgs p, const int n
 #pragma unroll
         for (int d = 0; d < 4; ++d) o_[d][f] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    const float c = p.scale * 1.44269504088896340736f;  // softmax in base 2
+    // softmax in base 2; when the q projection already folded scale*log2(e) into Q the scores need no multiply
+    const float c = p.q_prescaled ? 1.0f : p.scale * 1.44269504088896340736f;
 
     int t = t_begin - 1;
     t = advance(t);
@@ -200,8 +200,8 @@ __global__ void __launch_bounds__(256) attn_kernel(const AttnArgs p, const int n
 #pragma unroll
                 for (int d = 0; d < 4; ++d) {
                     const int dc = d * 16 + c0;
-                    a[2 * d] = v_ + r0 * 64 + swz(r0, dc >> 3) * 8 + (dc & 7);
-                    a[2 * d + 1] = v_ + r1 * 64 + swz(r1, dc >> 3) * 8 + (dc & 7);
+                    a[2 * d] = v_ + r0 * 64 + swz_v(r0, dc >> 3) * 8 + (dc & 7);
+                    a[2 * d + 1] = v_ + r1 * 64 + swz_v(r1, dc >> 3) * 8 + (dc & 7);
                 }
                 lds_read_tr4_x8<T>(a[0], a[1], a[2], a[3], a[4], a[5], a[6], a[7], tr);
             }

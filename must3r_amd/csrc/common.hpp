@@ -95,6 +95,10 @@ __device__ __forceinline__ float wave_sum(float v) {
 // physical chunk = logical chunk ^ ((row >> 1) & 7).  Rows r, r+1 sit in different halves of the 256-byte
 // bank row, so 16 consecutive rows reading the same logical chunk hit 16 distinct 16-byte slots.
 __device__ __forceinline__ int swz(int row, int chunk) { return chunk ^ ((row >> 1) & 7); }
+// V tiles are consumed by ds_read_b64_tr_b16: a 32-lane half reads 8 consecutive rows x one aligned 32-byte pair of
+// chunks.  XOR on the PAIR index (bits 1-2 of the chunk) with (row>>1)&3 puts the 8 rows on 8 distinct 32-byte slots
+// of the 256-byte bank row (rows r, r+1 already sit in different halves); swz() would alias rows r and r+2.
+__device__ __forceinline__ int swz_v(int row, int chunk) { return chunk ^ (((row >> 1) & 3) << 1); }
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 

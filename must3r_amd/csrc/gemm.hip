@@ -191,6 +191,12 @@ __global__ void __launch_bounds__(256) gemm_kernel(const GemmArgs p) {
                 }
             }
         }
+        if constexpr (EPI == EPI_STORE16 || EPI == EPI_QKV_ROPE) {
+            if (p.out_scale != 0.f && n0 + wn * WN < p.scale_cols) {   // scale_cols is a multiple of 64: wave-uniform
+#pragma unroll
+                for (int j = 0; j < NF; ++j) v[j] *= p.out_scale;
+            }
+        }
 #pragma unroll
         for (int j = 0; j < NF; ++j) {
             const int n = nb + j * 16;

@@ -29,6 +29,10 @@ struct GemmArgs {
     // split-weight mode: W is [N, wsplit*K] = [W_hi | W_lo] (both 16-bit); the A tile sequence wraps after K.
     // out = A.W_hi^T + A.W_lo^T accumulated in fp32 -> weight rounding error drops from 2^-11 to ~2^-22.
     int wsplit;              // 0/1 = plain, 2 = [hi|lo]
+    // 16-bit-store epilogues: columns < scale_cols are multiplied by out_scale before rounding (the softmax scale
+    // 1/sqrt(64) * log2(e) is folded into q here so the attention kernel works in the exp2 domain for free)
+    float out_scale;         // 0 -> no scaling
+    int scale_cols;
     // EPI_QKV_ROPE
     const int64_t* pos;      // [M,2] (y,x)
     const float* rope_tab;   // [npos][16][2] (cos,sin)
@@ -64,7 +68,8 @@ struct AttnArgs {
     const AttnView* views;                                    // device pointer
     int nviews;
     int max_nq;                                               // max over views of nq
-    float scale;                                              // 1/sqrt(64)
+    float scale;                                              // 1/sqrt(64); ignored when q_prescaled
+    int q_prescaled;                                          // Q already carries scale*log2(e)
     // split-KV (flash-decoding): when a launch has too few (view, head, q-block) groups to fill 256 CUs the key range
     // is cut into nsplit chunks, each block writes un-normalised fp32 partials + (m, l) and a second kernel merges.
     int nsplit;            // <= 1: single pass

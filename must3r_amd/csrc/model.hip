@@ -55,6 +55,9 @@ struct Param {
     bool derived = false;     // built by finalize, not loaded
 };
 
+// softmax scale folded into q by the projection epilogues: 1/sqrt(64) * log2(e)
+static const float kQScale = 0.125f * 1.44269504088896340736f;
+
 struct ProfEntry { hipEvent_t a, b; int cat; double flops; };
 enum ProfCat { PC_GEMM128 = 0, PC_GEMM64, PC_ATTN_SA, PC_ATTN_CA, PC_LN, PC_MISC, PC_COUNT };
 static const char* kProfNames[PC_COUNT] = {"gemm128", "gemm64", "attn_self", "attn_cross", "layernorm", "misc"};
@@ -498,12 +501,14 @@ static int encode_chunk(must3r_hip_ctx* c, DType dt, const float* img, int V, in
         M3R_OK(w16(c, b + ".attn.qkv.weight", dt, &w, s));
         GemmArgs ga = gargs(h16, w, p32(c, b + ".attn.qkv.bias"), qkv, R, 3 * C, C, C, 3 * C);
         ga.pos = out_pos; ga.rope_tab = c->rope_tab; ga.rope_cols = 2 * C; ga.rope_npos = c->rope_npos;
+        ga.out_scale = kQScale; ga.scale_cols = C;   // q *= 1/sqrt(64) * log2(e)
         M3R_OK(gemm(c, dt, EPI_QKV_ROPE, ga, s));
         AttnArgs aa;
         memset(&aa, 0, sizeof(aa));
         aa.Q = qkv; aa.K = qkv + C; aa.V = qkv + 2 * C; aa.O = a16;
         aa.ldq = aa.ldk = aa.ldv = 3 * C; aa.ldo = C; aa.heads = Hh;
         aa.views = reinterpret_cast<const AttnView*>(views_dev); aa.nviews = V; aa.max_nq = N; aa.scale = 0.125f;
+        aa.q_prescaled = 1;
         M3R_OK(attention(c, dt, aa, 4.0 * V * (double)N * N * C, PC_ATTN_SA, s));
         M3R_OK(w16(c, b + ".attn.proj.weight", dt, &w, s));
         M3R_OK(gemm(c, dt, EPI_RESID_F32, gargs(a16, w, p32(c, b + ".attn.proj.bias"), x, R, C, C, C, C), s));
@@ -692,12 +697,13 @@ extern "C" int must3r_hip_decode(must3r_hip_ctx* c, const must3r_hip_decode_args
         M3R_OK(w16(c, b + ".attn.qkv.weight", dt, &w, s));
         GemmArgs ga = gargs(h16, w, p32(c, b + ".attn.qkv.bias"), qkv, R, 3 * D, D, D, 3 * D);
         ga.pos = pos_all; ga.rope_tab = c->rope_tab; ga.rope_cols = 2 * D; ga.rope_npos = c->rope_npos;
+        ga.out_scale = kQScale; ga.scale_cols = D;
         M3R_OK(gemm(c, dt, EPI_QKV_ROPE, ga, s));
         AttnArgs aa;
         memset(&aa, 0, sizeof(aa));
         aa.Q = qkv; aa.K = qkv + D; aa.V = qkv + 2 * D; aa.O = a16;
         aa.ldq = aa.ldk = aa.ldv = 3 * D; aa.ldo = D; aa.heads = Hh;
-        aa.views = sa_views; aa.nviews = total_views; aa.max_nq = max_n; aa.scale = 0.125f;
+        aa.views = sa_views; aa.nviews = total_views; aa.max_nq = max_n; aa.scale = 0.125f; aa.q_prescaled = 1;
         M3R_OK(attention(c, dt, aa, sa_flops, PC_ATTN_SA, s));
         M3R_OK(w16(c, b + ".attn.proj.weight", dt, &w, s));
         M3R_OK(gemm(c, dt, EPI_RESID_F32, gargs(a16, w, p32(c, b + ".attn.proj.bias"), x, R, D, D, D, D), s));
@@ -705,12 +711,16 @@ extern "C" int must3r_hip_decode(must3r_hip_ctx* c, const must3r_hip_decode_args
         M3R_OK(layernorm(c, dt, x, nullptr, p32(c, b + ".norm2.weight"), p32(c, b + ".norm2.bias"), h16, nullptr, nullptr, nullptr,
                          R, D, 1e-6f, s));
         M3R_OK(w16(c, b + ".cross_attn.projq.weight", dt, &w, s));
-        M3R_OK(gemm(c, dt, EPI_STORE16, gargs(h16, w, p32(c, b + ".cross_attn.projq.bias"), q16, R, D, D, D, D), s));
+        {
+            GemmArgs gq = gargs(h16, w, p32(c, b + ".cross_attn.projq.bias"), q16, R, D, D, D, D);
+            gq.out_scale = kQScale; gq.scale_cols = D;
+            M3R_OK(gemm(c, dt, EPI_STORE16, gq, s));
+        }
         const uint16_t* mk = reinterpret_cast<const uint16_t*>(A->mem[l]);
         memset(&aa, 0, sizeof(aa));
         aa.Q = q16; aa.K = mk; aa.V = mk + D; aa.O = a16;
         aa.ldq = D; aa.ldk = aa.ldv = 2 * D; aa.ldo = D; aa.heads = Hh;
-        aa.views = ca_views; aa.nviews = total_views; aa.max_nq = max_n; aa.scale = 0.125f;
+        aa.views = ca_views; aa.nviews = total_views; aa.max_nq = max_n; aa.scale = 0.125f; aa.q_prescaled = 1;
         if (ca_split > 1) {
             aa.nsplit = ca_split; aa.total_q_rows = R;
             aa.part_o = reinterpret_cast<float*>(split_ws);
