@@ -311,7 +311,8 @@ int launch_tr_probe(short* out, hipStream_t s) {
     return hipGetLastError() == hipSuccess ? 0 : 1;
 }
 
-int launch_attention(DType dt, const AttnArgs& a, hipStream_t s, const char** err) {
+// phase 0: (m,l) pre-fill (split-KV with holes only), 1: main kernel, 2: combine (split-KV only)
+int launch_attention_phase(DType dt, const AttnArgs& a, int phase, hipStream_t s, const char** err) {
     if (a.nviews <= 0 || a.max_nq <= 0) return 0;
     if ((a.ldq % 8) || (a.ldk % 8) || (a.ldv % 8) || (a.ldo % 4)) { *err = "attention: row strides must be 16-byte aligned"; return 1; }
     const int nsplit = a.nsplit > 1 ? a.nsplit : 1;
@@ -319,20 +320,28 @@ int launch_attention(DType dt, const AttnArgs& a, hipStream_t s, const char** er
     const int nqb = (a.max_nq + ATT_QB - 1) / ATT_QB;
     const int ngrp = a.nviews * a.heads;
     const int grid = ((ngrp + 7) / 8) * 8 * nqb * nsplit;
-    if (nsplit > 1) {
-        const size_t n2 = (size_t)nsplit * a.total_q_rows * a.heads;
-        hipLaunchKernelGGL(attn_ml_init_kernel, dim3((unsigned)((n2 + 255) / 256 < 1024 ? (n2 + 255) / 256 : 1024)), dim3(256), 0, s,
-                           a.part_ml, n2);
-    }
-    if (dt == DT_BF16) hipLaunchKernelGGL(attn_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, a, nqb, ngrp, nsplit);
-    else hipLaunchKernelGGL(attn_kernel<f16_t>, dim3(grid), dim3(256), 0, s, a, nqb, ngrp, nsplit);
-    if (nsplit > 1) {
+    if (phase == 0) {
+        if (nsplit > 1 && !a.dense_rows) {
+            const size_t n2 = (size_t)nsplit * a.total_q_rows * a.heads;
+            hipLaunchKernelGGL(attn_ml_init_kernel, dim3((unsigned)((n2 + 255) / 256 < 1024 ? (n2 + 255) / 256 : 1024)), dim3(256), 0, s,
+                               a.part_ml, n2);
+        }
+    } else if (phase == 1) {
+        if (dt == DT_BF16) hipLaunchKernelGGL(attn_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, a, nqb, ngrp, nsplit);
+        else hipLaunchKernelGGL(attn_kernel<f16_t>, dim3(grid), dim3(256), 0, s, a, nqb, ngrp, nsplit);
+    } else if (nsplit > 1) {
         const size_t total = (size_t)a.total_q_rows * a.heads * 16;
         const unsigned g2 = (unsigned)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
         if (dt == DT_BF16) hipLaunchKernelGGL(attn_combine_kernel<bf16_t>, dim3(g2), dim3(256), 0, s, a, nsplit);
         else hipLaunchKernelGGL(attn_combine_kernel<f16_t>, dim3(g2), dim3(256), 0, s, a, nsplit);
     }
     if (hipGetLastError() != hipSuccess) { *err = "attention: kernel launch failed"; return 1; }
+    return 0;
+}
+
+int launch_attention(DType dt, const AttnArgs& a, hipStream_t s, const char** err) {
+    for (int ph = 0; ph < 3; ++ph)
+        if (launch_attention_phase(dt, a, ph, s, err)) return 1;
     return 0;
 }
 

@@ -76,12 +76,15 @@ struct AttnArgs {
     float* part_o;         // [nsplit][total_q_rows][heads*64] fp32
     float* part_ml;        // [nsplit][total_q_rows][heads][2] fp32 (running max in log2 domain, row sum)
     int total_q_rows;      // max over views of q_row0 + nq
+    int dense_rows;        // every row < total_q_rows belongs to a view of this launch (no (m,l) pre-fill needed)
 };
 // bytes of scratch launch_attention needs for a given split factor
 size_t attention_split_scratch_bytes(int nsplit, int total_q_rows, int heads);
 // heuristic split factor for a launch
 int attention_pick_split(int nviews, int heads, int max_nq, int max_nk);
 int launch_attention(DType dt, const AttnArgs& a, hipStream_t s, const char** err);
+// the three launches of a split-KV attention, separately (profiling): (m,l) pre-fill, main kernel, combine
+int launch_attention_phase(DType dt, const AttnArgs& a, int phase, hipStream_t s, const char** err);
 
 // ---------------------------------------------------------------------------------------------
 // row / elementwise kernels

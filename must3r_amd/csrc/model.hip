@@ -59,8 +59,8 @@ struct Param {
 static const float kQScale = 0.125f * 1.44269504088896340736f;
 
 struct ProfEntry { hipEvent_t a, b; int cat; double flops; };
-enum ProfCat { PC_GEMM128 = 0, PC_GEMM64, PC_ATTN_SA, PC_ATTN_CA, PC_LN, PC_MISC, PC_COUNT };
-static const char* kProfNames[PC_COUNT] = {"gemm128", "gemm64", "attn_self", "attn_cross", "layernorm", "misc"};
+enum ProfCat { PC_GEMM128 = 0, PC_GEMM64, PC_ATTN_SA, PC_ATTN_CA, PC_ATTN_COMBINE, PC_LN, PC_MISC, PC_COUNT };
+static const char* kProfNames[PC_COUNT] = {"gemm128", "gemm64", "attn_self", "attn_cross", "attn_combine", "layernorm", "misc"};
 
 struct must3r_hip_ctx {
     must3r_hip_config cfg;
@@ -187,8 +187,18 @@ static int layernorm(must3r_hip_ctx* c, DType dt, const float* x, const float* a
 }
 static int attention(must3r_hip_ctx* c, DType dt, const AttnArgs& a, double flops, int cat, hipStream_t s) {
     const char* err = "";
-    ProfScope ps(c, s, cat, flops);
-    if (launch_attention(dt, a, s, &err)) return fail("%s", err);
+    if (a.nsplit > 1 && !a.dense_rows) {
+        ProfScope ps(c, s, PC_ATTN_COMBINE, 0.0);
+        if (launch_attention_phase(dt, a, 0, s, &err)) return fail("%s", err);
+    }
+    {
+        ProfScope ps(c, s, cat, flops);   // attn_kernel alone: what rocprofv3 reports under that symbol
+        if (launch_attention_phase(dt, a, 1, s, &err)) return fail("%s", err);
+    }
+    if (a.nsplit > 1) {
+        ProfScope ps(c, s, PC_ATTN_COMBINE, 0.0);
+        if (launch_attention_phase(dt, a, 2, s, &err)) return fail("%s", err);
+    }
     return 0;
 }
 
@@ -722,7 +732,7 @@ extern "C" int must3r_hip_decode(must3r_hip_ctx* c, const must3r_hip_decode_args
         aa.ldq = D; aa.ldk = aa.ldv = 2 * D; aa.ldo = D; aa.heads = Hh;
         aa.views = ca_views; aa.nviews = total_views; aa.max_nq = max_n; aa.scale = 0.125f; aa.q_prescaled = 1;
         if (ca_split > 1) {
-            aa.nsplit = ca_split; aa.total_q_rows = R;
+            aa.nsplit = ca_split; aa.total_q_rows = R; aa.dense_rows = 1;
             aa.part_o = reinterpret_cast<float*>(split_ws);
             aa.part_ml = aa.part_o + (size_t)ca_split * R * D;
         }
