@@ -46,8 +46,11 @@ __global__ void __launch_bounds__(256) gemm_kernel(const GemmArgs p) {
     const int m0 = (bid / nbn) * BM;
     const int n0 = (bid % nbn) * BN;
 
-    const T* __restrict__ A = reinterpret_cast<const T*>(p.A);
-    const T* __restrict__ W = reinterpret_cast<const T*>(p.W);
+    const int grp = blockIdx.y;   // grouped launch: independent problems of equal shape
+    const T* __restrict__ A = reinterpret_cast<const T*>(p.A) + (size_t)grp * p.strideA;
+    const T* __restrict__ W = reinterpret_cast<const T*>(p.W) + (size_t)grp * p.strideW;
+    const float* __restrict__ bias = p.bias ? p.bias + (size_t)grp * p.strideB : nullptr;
+    void* const outp = p.out_table ? p.out_table[grp] : p.out;
 
     // ---- staging: one wave instruction moves 8 rows x 128 B
     const int wsp = p.wsplit > 1 ? p.wsplit : 1;
@@ -161,8 +164,8 @@ __global__ void __launch_bounds__(256) gemm_kernel(const GemmArgs p) {
         for (int j = 0; j < NF; ++j) {
             v[j] = acc[i][j];
             const bool nobias = (EPI == EPI_F32 || EPI == EPI_HEAD) && p.accumulate;
-            if (p.bias != nullptr && !nobias) {
-                const f32x4 b = *reinterpret_cast<const f32x4*>(p.bias + nb + j * 16);
+            if (bias != nullptr && !nobias) {
+                const f32x4 b = *reinterpret_cast<const f32x4*>(bias + nb + j * 16);
                 v[j] += b;
             }
         }
@@ -201,17 +204,17 @@ __global__ void __launch_bounds__(256) gemm_kernel(const GemmArgs p) {
         for (int j = 0; j < NF; ++j) {
             const int n = nb + j * 16;
             if constexpr (EPI == EPI_STORE16 || EPI == EPI_QKV_ROPE) {
-                *reinterpret_cast<v4*>(reinterpret_cast<T*>(p.out) + (size_t)m * p.ldc + n) = cvt4<T>(v[j]);
+                *reinterpret_cast<v4*>(reinterpret_cast<T*>(outp) + (size_t)m * p.ldc + n) = cvt4<T>(v[j]);
             } else if constexpr (EPI == EPI_STORE16_GELU) {
                 f32x4 g;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) g[r] = gelu_erf(v[j][r]);
-                *reinterpret_cast<v4*>(reinterpret_cast<T*>(p.out) + (size_t)m * p.ldc + n) = cvt4<T>(g);
+                *reinterpret_cast<v4*>(reinterpret_cast<T*>(outp) + (size_t)m * p.ldc + n) = cvt4<T>(g);
             } else if constexpr (EPI == EPI_RESID_F32) {
-                f32x4* o = reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + (size_t)m * p.ldc + n);
+                f32x4* o = reinterpret_cast<f32x4*>(reinterpret_cast<float*>(outp) + (size_t)m * p.ldc + n);
                 *o = *o + v[j];
             } else if constexpr (EPI == EPI_F32) {
-                f32x4* o = reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + (size_t)m * p.ldc + n);
+                f32x4* o = reinterpret_cast<f32x4*>(reinterpret_cast<float*>(outp) + (size_t)m * p.ldc + n);
                 f32x4 x = v[j];
                 if (p.accumulate) {
                     x += *o;
@@ -225,7 +228,7 @@ __global__ void __launch_bounds__(256) gemm_kernel(const GemmArgs p) {
                 const int gy = t / p.gw, gx = t - gy * p.gw;
                 const int pi = n / 112, rem = n - pi * 112;
                 const size_t off = ((size_t)(vv * p.H + gy * 16 + pi) * p.Wimg + gx * 16) * 7 + rem;
-                f32x4* o = reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + off);
+                f32x4* o = reinterpret_cast<f32x4*>(reinterpret_cast<float*>(outp) + off);
                 f32x4 x = v[j];
                 if (p.accumulate) x += *o;
                 *o = x;
@@ -244,14 +247,14 @@ static int launch_cfg(const GemmArgs& a, hipStream_t s) {
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm_kernel<T, BM, BN, EPI, NST>), dim3(nbm * nbn), dim3(256), lds, s, a);
+    hipLaunchKernelGGL((gemm_kernel<T, BM, BN, EPI, NST>), dim3(nbm * nbn, a.batch > 1 ? a.batch : 1), dim3(256), lds, s, a);
     return hipGetLastError() == hipSuccess ? 0 : 1;
 }
 
 template <class T, int EPI>
 static int launch_epi(const GemmArgs& a, hipStream_t s, const char** err) {
     const bool n128 = (a.N % 128) == 0;
-    const long tiles128 = (long)((a.M + 127) / 128) * (a.N / 128);
+    const long tiles128 = (long)((a.M + 127) / 128) * (a.N / 128) * (a.batch > 1 ? a.batch : 1);
     int rc;
     if (n128 && tiles128 >= 192) rc = launch_cfg<T, 128, 128, EPI, 2>(a, s);
     else rc = launch_cfg<T, 64, 64, EPI, 4>(a, s);

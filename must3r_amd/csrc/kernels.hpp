@@ -33,6 +33,11 @@ struct GemmArgs {
     // 1/sqrt(64) * log2(e) is folded into q here so the attention kernel works in the exp2 domain for free)
     float out_scale;         // 0 -> no scaling
     int scale_cols;
+    // grouped launch: blockIdx.y = g selects A + g*strideA, W + g*strideW, bias + g*strideB and out_table[g]
+    // (independent problems of equal shape, e.g. the per-layer K|V projections of one memory update)
+    int batch;               // 0/1 = single problem
+    long long strideA, strideW, strideB;   // in elements
+    void* const* out_table;  // device array of `batch` output base pointers
     // EPI_QKV_ROPE
     const int64_t* pos;      // [M,2] (y,x)
     const float* rope_tab;   // [npos][16][2] (cos,sin)
@@ -90,7 +95,9 @@ int launch_attention_phase(DType dt, const AttnArgs& a, int phase, hipStream_t s
 // row / elementwise kernels
 // ---------------------------------------------------------------------------------------------
 struct LnArgs {
-    const float* x;      // [M,C]
+    const float* x;      // [M,C] fp32 input, or nullptr to read x16 instead
+    const void* x16;     // optional 16-bit input [M,C] (memory_mode 'raw': LayerNorm of stored 16-bit tokens)
+    void* raw16;         // optional 16-bit copy of x (+add) before normalisation (memory_mode 'raw' rows)
     const float* add;    // optional [M,C] added to x before the statistics (feedback offset)
     const float* w; const float* b;
     void* out16;         // optional 16-bit [M,C]
@@ -99,6 +106,10 @@ struct LnArgs {
     float* copy32;       // optional raw copy of x (+add) (memorised layer input, decoder.py:304-305)
     int M, C;
     float eps;
+    // grouped rows: row r belongs to group g = r / rows_per_group: affine parameters w + g*C, b + g*C; `add` (shape
+    // [rows_per_group, C]) is applied to groups < add_groups only (feedback offset: all layers but the last)
+    int rows_per_group;      // 0 = ungrouped
+    int add_groups;
 };
 int launch_layernorm(DType dt, const LnArgs& a, hipStream_t s, const char** err);
 

@@ -15,7 +15,15 @@ __global__ void __launch_bounds__(256) ln_kernel(const LnArgs p) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= p.M) return;
-    const float* x = p.x + (size_t)row * p.C;
+    const float* wp = p.w;
+    const float* bp = p.b;
+    const float* addp = p.add ? p.add + (size_t)row * p.C : nullptr;
+    if (p.rows_per_group > 0) {
+        const int g = row / p.rows_per_group;
+        wp += (size_t)g * p.C;
+        bp += (size_t)g * p.C;
+        addp = (p.add && g < p.add_groups) ? p.add + (size_t)(row - g * p.rows_per_group) * p.C : nullptr;
+    }
     f32x4 v[4];
     float s = 0.f;
 #pragma unroll
@@ -23,9 +31,11 @@ __global__ void __launch_bounds__(256) ln_kernel(const LnArgs p) {
         const int c = (i * 64 + lane) * 4;
         v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
         if (c < p.C) {
-            v[i] = *reinterpret_cast<const f32x4*>(x + c);
-            if (p.add) v[i] += *reinterpret_cast<const f32x4*>(p.add + (size_t)row * p.C + c);
+            if (p.x) v[i] = *reinterpret_cast<const f32x4*>(p.x + (size_t)row * p.C + c);
+            else v[i] = __builtin_convertvector(*reinterpret_cast<const v4*>(reinterpret_cast<const T*>(p.x16) + (size_t)row * p.C + c), f32x4);
+            if (addp) v[i] += *reinterpret_cast<const f32x4*>(addp + c);
             if (p.copy32) *reinterpret_cast<f32x4*>(p.copy32 + (size_t)row * p.C + c) = v[i];
+            if (p.raw16) *reinterpret_cast<v4*>(reinterpret_cast<T*>(p.raw16) + (size_t)row * p.C + c) = cvt4<T>(v[i]);
             s += v[i][0] + v[i][1] + v[i][2] + v[i][3];
         }
     }
@@ -44,8 +54,8 @@ __global__ void __launch_bounds__(256) ln_kernel(const LnArgs p) {
     for (int i = 0; i < 4; ++i) {
         const int c = (i * 64 + lane) * 4;
         if (c < p.C) {
-            const f32x4 w = *reinterpret_cast<const f32x4*>(p.w + c);
-            const f32x4 b = *reinterpret_cast<const f32x4*>(p.b + c);
+            const f32x4 w = *reinterpret_cast<const f32x4*>(wp + c);
+            const f32x4 b = *reinterpret_cast<const f32x4*>(bp + c);
             const f32x4 y = v[i] * rstd * w + b;
             if (p.out32) *reinterpret_cast<f32x4*>(p.out32 + (size_t)row * p.C + c) = y;
             if (p.out16) {

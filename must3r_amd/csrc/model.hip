@@ -164,10 +164,10 @@ static void prof_flush(must3r_hip_ctx* c) {
 // ------------------------------------------------------------------------------------------------
 static int gemm(must3r_hip_ctx* c, DType dt, Epi epi, GemmArgs a, hipStream_t s) {
     const char* err = "";
-    const long tiles128 = (long)((a.M + 127) / 128) * (a.N / 128);
+    const long tiles128 = (long)((a.M + 127) / 128) * (a.N / 128) * (a.batch > 1 ? a.batch : 1);
     const int cat = (a.N % 128 == 0 && tiles128 >= 192) ? PC_GEMM128 : PC_GEMM64;
     if (c && epi != EPI_HEAD) a.wsplit = c->wsplit;
-    ProfScope ps(c, s, cat, 2.0 * a.M * a.N * a.K);
+    ProfScope ps(c, s, cat, 2.0 * a.M * a.N * a.K * (a.batch > 1 ? a.batch : 1));
     if (launch_gemm(dt, epi, a, s, &err)) return fail("%s (M=%d N=%d K=%d epi=%d)", err, a.M, a.N, a.K, (int)epi);
     return 0;
 }
@@ -177,13 +177,23 @@ static GemmArgs gargs(const void* A, const void* W, const float* bias, void* out
     a.A = A; a.W = W; a.bias = bias; a.out = out; a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldc = ldc;
     return a;
 }
-static int layernorm(must3r_hip_ctx* c, DType dt, const float* x, const float* add, const float* w, const float* b,
-                     void* o16, void* o16lo, float* o32, float* copy, int M, int C, float eps, hipStream_t s) {
+static LnArgs lnargs(const float* x, const float* add, const float* w, const float* b, void* o16, void* o16lo, float* o32,
+                     float* copy, int M, int C, float eps) {
+    LnArgs a;
+    memset(&a, 0, sizeof(a));
+    a.x = x; a.add = add; a.w = w; a.b = b; a.out16 = o16; a.out16_lo = o16lo; a.out32 = o32; a.copy32 = copy;
+    a.M = M; a.C = C; a.eps = eps;
+    return a;
+}
+static int layernorm_a(must3r_hip_ctx* c, DType dt, const LnArgs& a, hipStream_t s) {
     const char* err = "";
-    LnArgs a{x, add, w, b, o16, o16lo, o32, copy, M, C, eps};
     ProfScope ps(c, s, PC_LN, 0.0);
     if (launch_layernorm(dt, a, s, &err)) return fail("%s", err);
     return 0;
+}
+static int layernorm(must3r_hip_ctx* c, DType dt, const float* x, const float* add, const float* w, const float* b,
+                     void* o16, void* o16lo, float* o32, float* copy, int M, int C, float eps, hipStream_t s) {
+    return layernorm_a(c, dt, lnargs(x, add, w, b, o16, o16lo, o32, copy, M, C, eps), s);
 }
 static int attention(must3r_hip_ctx* c, DType dt, const AttnArgs& a, double flops, int cat, hipStream_t s) {
     const char* err = "";
@@ -448,6 +458,21 @@ extern "C" int must3r_hip_finalize_weights(must3r_hip_ctx* c, int parts) {
         o = a; o.insert(o.end(), b.begin(), b.end());
         M3R_OK(derive(c, pb + "projkv.bias", {2 * D}, o));
     }
+    // all layers' K|V projections and norm_y affine parameters stacked, for the grouped post-feedback projection
+    {
+        std::vector<float> wall, ball, nw, nb;
+        for (int l = 0; l < g.dec_depth; ++l) {
+            const std::string pb = "decoder.blocks_dec." + std::to_string(l);
+            M3R_OK(fetch(c, pb + ".cross_attn.projkv.weight", a)); wall.insert(wall.end(), a.begin(), a.end());
+            M3R_OK(fetch(c, pb + ".cross_attn.projkv.bias", a)); ball.insert(ball.end(), a.begin(), a.end());
+            M3R_OK(fetch(c, pb + ".norm_y.weight", a)); nw.insert(nw.end(), a.begin(), a.end());
+            M3R_OK(fetch(c, pb + ".norm_y.bias", a)); nb.insert(nb.end(), a.begin(), a.end());
+        }
+        M3R_OK(derive(c, "decoder.projkv_all.weight", {(int64_t)g.dec_depth * 2 * D, D}, wall));
+        M3R_OK(derive(c, "decoder.projkv_all.bias", {(int64_t)g.dec_depth * 2 * D}, ball));
+        M3R_OK(derive(c, "decoder.norm_y_all.weight", {(int64_t)g.dec_depth * D}, nw));
+        M3R_OK(derive(c, "decoder.norm_y_all.bias", {(int64_t)g.dec_depth * D}, nb));
+    }
     // pixel-shuffled head: new row (i*16+j)*7 + ch <- old row ch*256 + i*16 + j  (tools/image.py:9-14)
     {
         M3R_OK(fetch(c, "decoder.head_dec.proj.weight", a));
@@ -565,7 +590,8 @@ extern "C" int must3r_hip_decode(must3r_hip_ctx* c, const must3r_hip_decode_args
     if (!c->fin_dec) return fail("decode: decoder weights not finalized");
     if (A->dtype != MUST3R_BF16 && A->dtype != MUST3R_F16 && A->dtype != MUST3R_F16_W2) return fail("decode: bad dtype %d", A->dtype);
     c->wsplit = A->dtype == MUST3R_F16_W2 ? 2 : 0;
-    if (A->mem_mode != MUST3R_MEM_KV) return fail("decode: only memory_mode 'kv' is implemented natively");
+    if (A->mem_mode != MUST3R_MEM_KV && A->mem_mode != MUST3R_MEM_NORM_Y && A->mem_mode != MUST3R_MEM_RAW)
+        return fail("decode: bad mem_mode %d", A->mem_mode);
     if (A->n_groups <= 0) return fail("decode: no input group");
     if (A->render && (A->first_call || A->n_mem <= 0)) return fail("decode: render needs a memory (decoder.py:278)");
     if (A->first_call && A->n_mem != 0) return fail("decode: first_call with a non-empty memory");
@@ -611,12 +637,20 @@ extern "C" int must3r_hip_decode(must3r_hip_ctx* c, const must3r_hip_decode_args
     if (update) {
         need = ws_need(need, (size_t)L * R * D, 4);   // memorised layer inputs
         need = ws_need(need, (size_t)R * D, 4);       // feedback offset
+        need = ws_need(need, (size_t)L * R * D, 2);   // norm_y of all layers (grouped K|V projection)
     }
     // split-KV cross attention when the launch cannot fill the chip (sequential memory update: one view per call)
     const int max_nk_ca = A->render ? Nm : Nm + (lone_view ? 0 : R);
     const int ca_split = attention_pick_split(total_views, Hh, max_n, max_nk_ca);
     const size_t split_bytes = attention_split_scratch_bytes(ca_split, R, Hh);
     need = ws_need(need, split_bytes, 1);
+    // memory_mode 'norm_y' / 'raw': the memory holds (normalised / raw) tokens, K|V of ALL attended rows are projected
+    // per layer per call into scratch (the reference re-projects them per query view, layers.py:92-96)
+    const int mode = A->mem_mode;
+    const int memD = mode == MUST3R_MEM_KV ? 2 * D : D;
+    const size_t kvs_rows = mode == MUST3R_MEM_KV ? 0 : (size_t)max_nk_ca;
+    need = ws_need(need, kvs_rows * 2 * D, 2);
+    need = ws_need(need, mode == MUST3R_MEM_RAW ? kvs_rows * D : 0, 2);
     M3R_OK(ws_reserve(c, need, s));
     uint16_t* t16 = ws_take<uint16_t>(c, (size_t)R * C);
     float* x = ws_take<float>(c, (size_t)R * D);
@@ -628,7 +662,10 @@ extern "C" int must3r_hip_decode(must3r_hip_ctx* c, const must3r_hip_decode_args
     uint16_t* g16 = ws_take<uint16_t>(c, (size_t)R * F);
     float* newmem = update ? ws_take<float>(c, (size_t)L * R * D) : nullptr;
     float* off32 = update ? ws_take<float>(c, (size_t)R * D) : nullptr;
+    uint16_t* yall = update ? ws_take<uint16_t>(c, (size_t)L * R * D) : nullptr;
     char* split_ws = split_bytes ? ws_take<char>(c, split_bytes) : nullptr;
+    uint16_t* kvs = kvs_rows ? ws_take<uint16_t>(c, kvs_rows * 2 * D) : nullptr;
+    uint16_t* ytmp = (mode == MUST3R_MEM_RAW && kvs_rows) ? ws_take<uint16_t>(c, kvs_rows * D) : nullptr;
     if (!g16 || (update && !off32) || (split_bytes && !split_ws)) return fail("decode: workspace sizing bug");
 
     // ---- per-view tables: self-attention, cross-attention; positions gathered into one [R,2] array
@@ -686,15 +723,38 @@ extern "C" int must3r_hip_decode(must3r_hip_ctx* c, const must3r_hip_decode_args
         pos_all = pos_ws;
     }
 
+    // prepare_y (layers.py:81-88) of the R new token rows, written to memory rows [Nm, Nm+R) in the caller's mode:
+    //   'kv'     LN(norm_y) -> [projk | projv]       'norm_y'  LN(norm_y)        'raw'  the tokens themselves
     auto kv_project = [&](int l, const float* src, const float* add, float* copy, hipStream_t st) -> int {
-        // prepare_y in 'kv' mode (layers.py:81-88): LN(norm_y) -> [projk | projv] -> memory rows [Nm, Nm+R)
         const std::string b = "decoder.blocks_dec." + std::to_string(l);
-        M3R_OK(layernorm(c, dt, src, add, p32(c, b + ".norm_y.weight"), p32(c, b + ".norm_y.bias"), h16, nullptr, nullptr, copy,
-                         R, D, 1e-6f, st));
+        uint16_t* dst = reinterpret_cast<uint16_t*>(A->mem[l]) + (size_t)Nm * memD;
+        LnArgs la = lnargs(src, add, p32(c, b + ".norm_y.weight"), p32(c, b + ".norm_y.bias"), h16, nullptr, nullptr, copy, R, D, 1e-6f);
+        if (mode == MUST3R_MEM_NORM_Y) la.out16 = dst;
+        if (mode == MUST3R_MEM_RAW) { la.out16 = nullptr; la.raw16 = dst; }
+        M3R_OK(layernorm_a(c, dt, la, st));
+        if (mode != MUST3R_MEM_KV) return 0;
         const void* wk;
         M3R_OK(w16(c, b + ".cross_attn.projkv.weight", dt, &wk, st));
-        uint16_t* dst = reinterpret_cast<uint16_t*>(A->mem[l]) + (size_t)Nm * 2 * D;
         M3R_OK(gemm(c, dt, EPI_STORE16, gargs(h16, wk, p32(c, b + ".cross_attn.projkv.bias"), dst, R, 2 * D, D, D, 2 * D), st));
+        return 0;
+    };
+    // K|V rows the cross attention of layer l reads: the memory itself ('kv') or a projection of it into scratch
+    auto kv_source = [&](int l, const uint16_t** kptr, hipStream_t st) -> int {
+        if (mode == MUST3R_MEM_KV) { *kptr = reinterpret_cast<const uint16_t*>(A->mem[l]); return 0; }
+        const std::string b = "decoder.blocks_dec." + std::to_string(l);
+        const uint16_t* src = reinterpret_cast<const uint16_t*>(A->mem[l]);
+        const int rows = (int)kvs_rows;
+        if (mode == MUST3R_MEM_RAW) {  // y_ = norm_y(y) on the stored tokens (layers.py:92)
+            LnArgs la = lnargs(nullptr, nullptr, p32(c, b + ".norm_y.weight"), p32(c, b + ".norm_y.bias"), ytmp, nullptr, nullptr, nullptr,
+                               rows, D, 1e-6f);
+            la.x16 = src;
+            M3R_OK(layernorm_a(c, dt, la, st));
+            src = ytmp;
+        }
+        const void* wk;
+        M3R_OK(w16(c, b + ".cross_attn.projkv.weight", dt, &wk, st));
+        M3R_OK(gemm(c, dt, EPI_STORE16, gargs(src, wk, p32(c, b + ".cross_attn.projkv.bias"), kvs, rows, 2 * D, D, D, 2 * D), st));
+        *kptr = kvs;
         return 0;
     };
 
@@ -726,7 +786,8 @@ extern "C" int must3r_hip_decode(must3r_hip_ctx* c, const must3r_hip_decode_args
             gq.out_scale = kQScale; gq.scale_cols = D;
             M3R_OK(gemm(c, dt, EPI_STORE16, gq, s));
         }
-        const uint16_t* mk = reinterpret_cast<const uint16_t*>(A->mem[l]);
+        const uint16_t* mk = nullptr;
+        M3R_OK(kv_source(l, &mk, s));
         memset(&aa, 0, sizeof(aa));
         aa.Q = q16; aa.K = mk; aa.V = mk + D; aa.O = a16;
         aa.ldq = D; aa.ldk = aa.ldv = 2 * D; aa.ldo = D; aa.heads = Hh;
@@ -757,8 +818,27 @@ extern "C" int must3r_hip_decode(must3r_hip_ctx* c, const must3r_hip_decode_args
         M3R_OK(w16(c, "decoder.feedback_layer.fc2.weight", dt, &w, s));
         M3R_OK(gemm(c, dt, EPI_F32, gargs(g16, w, p32(c, "decoder.feedback_layer.fc2.bias"), off32, R, D, 4 * D, 4 * D, D), s));
         // --- stored memory = prepare_y(new_mem + offset) (decoder.py:236-239 / :327-330)
-        for (int l = 0; l < L; ++l)
-            M3R_OK(kv_project(l, newmem + (size_t)l * R * D, l < L - 1 ? off32 : nullptr, nullptr, s));
+        if (mode == MUST3R_MEM_KV) {
+            // the L projections are independent: ONE grouped LayerNorm over [L*R, D] (per-layer affine, offset on layers
+            // < L-1) and ONE grouped GEMM writing each layer's K|V rows into its own memory buffer
+            LnArgs la = lnargs(newmem, off32, p32(c, "decoder.norm_y_all.weight"), p32(c, "decoder.norm_y_all.bias"), yall, nullptr,
+                               nullptr, nullptr, L * R, D, 1e-6f);
+            la.rows_per_group = R; la.add_groups = L - 1;
+            M3R_OK(layernorm_a(c, dt, la, s));
+            std::vector<void*> outs(L);
+            for (int l = 0; l < L; ++l) outs[l] = reinterpret_cast<uint16_t*>(A->mem[l]) + (size_t)Nm * 2 * D;
+            void* outs_dev = nullptr;
+            M3R_OK(upload_table(c, outs.data(), sizeof(void*) * L, &outs_dev, s));
+            const void* wk;
+            M3R_OK(w16(c, "decoder.projkv_all.weight", dt, &wk, s));
+            GemmArgs gk = gargs(yall, wk, p32(c, "decoder.projkv_all.bias"), nullptr, R, 2 * D, D, D, 2 * D);
+            gk.batch = L; gk.strideA = (long long)R * D; gk.strideW = (long long)2 * D * D * (c->wsplit == 2 ? 2 : 1);
+            gk.strideB = 2 * D; gk.out_table = reinterpret_cast<void* const*>(outs_dev);
+            M3R_OK(gemm(c, dt, EPI_STORE16, gk, s));
+        } else {
+            for (int l = 0; l < L; ++l)
+                M3R_OK(kv_project(l, newmem + (size_t)l * R * D, l < L - 1 ? off32 : nullptr, nullptr, s));
+        }
     }
 
     // --- prediction head in split precision (fp32-equivalent; decoder.py:149-156 runs it in fp32):
@@ -834,7 +914,7 @@ extern "C" int must3r_hip_op_attention(int dtype, const void* Q, const void* K, 
 extern "C" int must3r_hip_op_layernorm(int dtype, const float* x, const float* add, const float* w, const float* b, void* out16,
                                        void* out16_lo, float* out32, float* copy32, int M, int C, float eps, void* stream) {
     if (dtype != MUST3R_BF16 && dtype != MUST3R_F16) return fail("op_layernorm: bad dtype");
-    LnArgs a{x, add, w, b, out16, out16_lo, out32, copy32, M, C, eps};
+    LnArgs a = lnargs(x, add, w, b, out16, out16_lo, out32, copy32, M, C, eps);
     const char* err = "";
     if (launch_layernorm((DType)dtype, a, reinterpret_cast<hipStream_t>(stream), &err)) return fail("%s", err);
     return 0;

@@ -153,10 +153,6 @@ class MUSt3R(HipModule):
             # intermediate features are never materialised by the fused native path (inference callers do not ask:
             # engine/inference.py:190; the reference's list path silently ignores the flag, decoder.py:270)
             raise NotImplementedError("return_feats=True is not available on the HIP path")
-        if self.memory_mode != "kv":
-            raise NotImplementedError(
-                f"memory_mode={self.memory_mode!r}: the native decoder keeps the memory as projected K|V "
-                "(memory_mode='kv', what the released 512 checkpoints use); call change_memory_mode('kv')")
         xs = list(x) if is_list else [x]
         poss = list(pos) if is_list else [pos]
         shapes = list(true_shape) if is_list else [true_shape]

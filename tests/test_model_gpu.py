@@ -192,9 +192,45 @@ def test_autocast_selects_operand_dtype():
     assert mem[0][0].dtype == torch.bfloat16       # memory dtype follows autocast like decoder.py:142 / blocks/__init__.py:5
     mem, _ = dec(x.unsqueeze(0), pos.unsqueeze(0), ts.cuda().unsqueeze(0), None)
     assert mem[0][0].dtype == torch.float16
-    with pytest.raises(NotImplementedError):
-        dec.change_memory_mode("norm_y")
-        try:
-            dec(x.unsqueeze(0), pos.unsqueeze(0), ts.cuda().unsqueeze(0), None)
-        finally:
-            dec.change_memory_mode("kv")
+
+
+@pytest.mark.parametrize("precision", ["fp16w2", "bf16"])
+def test_memory_modes_norm_y_raw_kv(precision):
+    """SURVEY.md section 4 invariant 1: 'norm_y', 'kv' and 'raw' differ only in WHAT is cached (layers.py:81-99).
+    Natively: 'norm_y' stores the same 16-bit LayerNorm output the 'kv' projection consumes, so its pointmaps are
+    bit-identical to 'kv'; 'raw' stores the 16-bit tokens and normalises them again at use (tolerance)."""
+    from oracle import must3r_ref as R
+    cfg = TINY
+    enc, dec = build(cfg, precision)
+    sdd = S.make_decoder_state_dict(cfg, 0)
+    imgs, ts = S.make_images(4, 48, 64, 5)
+    x, pos = enc(imgs.cuda(), ts.cuda())
+    tsc = ts.cuda()
+    outs, mems = {}, {}
+    try:
+        for mode in ("kv", "norm_y", "raw"):
+            dec.change_memory_mode(mode)
+            mem = None
+            pms = []
+            for a, b in ((0, 2), (2, 3), (3, 4)):
+                mem, pm = dec(x[a:b].unsqueeze(0), pos[a:b].unsqueeze(0), tsc[a:b].unsqueeze(0), mem)
+                pms.append(pm[0])
+            _, ren = dec(x.unsqueeze(0), pos.unsqueeze(0), tsc.unsqueeze(0), mem, render=True)
+            outs[mode] = torch.cat(pms + [ren[0]], 0).cpu()
+            mems[mode] = mem
+            assert mem[0][0].shape == (1, 48, 2 * cfg.dec_dim if mode == "kv" else cfg.dec_dim)
+    finally:
+        dec.change_memory_mode("kv")
+    assert torch.equal(outs["norm_y"], outs["kv"])
+    e_raw = rel_inf(outs["raw"], outs["kv"])
+    # oracle memories in the two token modes
+    xo, po = x.cpu(), pos.cpu()
+    errs = {"raw_vs_kv": e_raw}
+    for mode in ("norm_y", "raw"):
+        memo = None
+        for a, b in ((0, 2), (2, 3), (3, 4)):
+            memo, _ = R.decoder_forward(sdd, cfg, xo[a:b].unsqueeze(0), po[a:b].unsqueeze(0), ts[a:b].unsqueeze(0), memo, False, mode)
+        errs["mem_" + mode] = max(rel_inf(a.float().cpu(), b) for a, b in zip(mems[mode][0], memo[0]))
+    record("memory_modes", precision=precision, **errs)
+    u = 2.0 ** -8 if precision == "bf16" else 2.0 ** -11
+    assert e_raw < TOL[precision] and errs["mem_norm_y"] < TOL[precision] + u and errs["mem_raw"] < TOL[precision] + u, errs
