@@ -148,6 +148,20 @@ def main():
                 "frac": round(ach / PEAK_TFLOPS[args.precision], 4), "traffic": None,
                 "avg_launch_us": round(agg[dom]["ms"] * 1e3 / max(1, agg[dom]["calls"]), 2), "launches": int(agg[dom]["calls"]),
                 "algorithmic_flops_per_launch": round(agg[dom]["flops"] / max(1, agg[dom]["calls"]) / 1e9, 3), "flops_unit": "GFLOP"}
+    # HBM bytes per launch of that kernel from the committed PMC passes of this same command (FETCH_SIZE / WRITE_SIZE
+    # cannot be read from inside the process; scripts/gpu_pmc.sh + scripts/pmc_summary.py produce the file)
+    try:
+        import glob
+        pmc = json.load(open(sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))[-1]))
+        sym = {"attn_kernel": "attn_kernel", "gemm_kernel<128x128>": "Li128ELi128E", "gemm_kernel<64x64>": "Li64ELi64E"}[dom]
+        want = "DF16b" if args.precision == "bf16" else "DF16_"
+        rows = [v for k, v in pmc["kernels"].items() if sym in k and want in k]
+        if rows:
+            n = sum(r["launches"] for r in rows)
+            roofline["traffic"] = int(sum(r["hbm_bytes_per_launch_corrected"] * r["launches"] for r in rows) / max(1, n))
+            roofline["traffic_unit"] = "bytes/launch (PMC, corrected; profiles/)"
+    except Exception:
+        pass
     # stage split (untimed extra step, single GPU only)
     if world == 1:
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
