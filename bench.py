@@ -72,6 +72,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    # host threads: the CPU only generates the synthetic weights; never let N ranks x all cores oversubscribe the box
+    torch.set_num_threads(max(1, min(16, (os.cpu_count() or 8) // max(1, world))))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
