@@ -61,6 +61,8 @@ def main():
     ap.add_argument("--no-alt", action="store_true")
     ap.add_argument("--cpu-timeout", type=float, default=240.0)
     ap.add_argument("--no-overlap", action="store_true", help="encode everything before the memory update (no 2nd stream)")
+    ap.add_argument("--inflight", type=int, default=1, help="scenes in flight: consecutive steps alternate over this many independent "
+                    "contexts/streams (software pipelining across steps; every step still does all of its work)")
     args = ap.parse_args()
 
     import torch.distributed as dist
@@ -93,10 +95,25 @@ def main():
         keyframes = (gidx % world == 0)                    # 20 keyframes spread over all ranks
     n_key = V
 
+    # optional software pipelining across steps: step k runs on context/stream k % inflight
+    lanes = [(enc, dec, None)]
+    if world == 1 and args.inflight > 1:
+        lanes = [(enc, dec, torch.cuda.Stream(device=device))]
+        for _ in range(args.inflight - 1):
+            e2, d2, _, _ = build_models(cfg, args.precision, device)
+            lanes.append((e2, d2, torch.cuda.Stream(device=device)))
+    step_no = [0]
+
     def step():
-        if world == 1:
-            return run_scene(enc, dec, imgs, ts, overlap=not args.no_overlap)
-        return run_scene_sharded(enc, dec, imgs, ts, keyframes, comm_dtype=tdt)
+        if world > 1:
+            return run_scene_sharded(enc, dec, imgs, ts, keyframes, comm_dtype=tdt)
+        e_, d_, st = lanes[step_no[0] % len(lanes)]
+        step_no[0] += 1
+        if st is None:
+            return run_scene(e_, d_, imgs, ts, overlap=not args.no_overlap)
+        st.wait_stream(torch.cuda.current_stream(device))
+        with torch.cuda.stream(st):
+            return run_scene(e_, d_, imgs, ts, overlap=False)
 
     def sync():
         torch.cuda.synchronize(device)
@@ -117,7 +134,7 @@ def main():
             dt = float(t.item())
         return dt
 
-    for _ in range(args.warmup):
+    for _ in range(max(args.warmup, len(lanes))):
         step()
     dt = timed(args.steps)
     views_per_step = V * world
@@ -187,11 +204,14 @@ def main():
         for other in ("bf16", "fp16", "fp16w2"):
             if other == args.precision:
                 continue
-            enc.precision = dec.precision = other
-            step()
+            for e_, d_, _ in lanes:
+                e_.precision = d_.precision = other
+            for _ in range(len(lanes)):
+                step()
             dta = timed(args.steps)
             alt.append({"dtype": other, "value": round(views_per_step * args.steps / dta, 2)})
-        enc.precision = dec.precision = args.precision
+        for e_, d_, _ in lanes:
+            e_.precision = d_.precision = args.precision
 
     cpu_baseline, parity = None, None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -235,7 +255,7 @@ def main():
             "dtype": dtype_label, "data": "synthetic",
             "config": {"workload": f"MUSt3R_512 ViT-L/ViT-B random-init, {V}-view memory, {V * world} views/step 384x512 "
                                    f"(encode+update[2,1..]+render+activation)", "views_per_step": V * world, "keyframes": n_key,
-                       "H": H, "W": W, "parallelism": "single" if world == 1 else f"view-sharded x{world} + all-gather(keyframe tokens)"},
+                       "H": H, "W": W, "scenes_in_flight": len(lanes), "parallelism": "single" if world == 1 else f"view-sharded x{world} + all-gather(keyframe tokens)"},
             "roofline": roofline, "cpu_baseline": cpu_baseline, "parity_vs_cpu_oracle": parity,
             "kernel_classes": classes, "stages_ms": stages, "alt": alt,
             "scene_tflop": round(flops / 1e12, 2) if flops else None,
