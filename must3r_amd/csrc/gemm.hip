@@ -12,26 +12,33 @@
 //   ds_read_b128 side (same involution).
 // * blockIdx -> tile mapping is XCD-aware: each XCD (blockIdx % 8) walks a contiguous chunk of the tile grid in
 //   grouped order (8 row-blocks x all column-blocks) so the panels its resident blocks share stay in its L2.
+#include <cstdlib>
+#include <type_traits>
 #include "common.hpp"
 #include "kernels.hpp"
 
 namespace m3r {
 
-template <class T, int BM, int BN, int EPI, int NST>
-__global__ void __launch_bounds__(256) gemm_kernel(const GemmArgs p) {
+// WS = 2: split-weight mode, W is [N, 2K] = [W_hi | W_lo]; every K-tile stages the activation tile once plus BOTH weight
+// tiles, and each activation fragment feeds two MFMAs (acc += W_hi.a ; acc += W_lo.a).
+template <class T, int BM, int BN, int WGM, int WGN, int EPI, int NST, int WS>
+__global__ void __launch_bounds__(64 * WGM * WGN) gemm_kernel(const GemmArgs p) {
     typedef typename Vec<T>::v8 v8;
     typedef typename Vec<T>::v4 v4;
     constexpr int BK = 64;
-    constexpr int WM = BM / 2, WN = BN / 2;
+    constexpr int NW = WGM * WGN;               // waves per block
+    constexpr int WM = BM / WGM, WN = BN / WGN;  // wave tile
+    constexpr int PA = BM / (8 * NW), PW = BN / (8 * NW);  // 8-row DMA pieces per wave and tile
+    static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0 && WM % 16 == 0 && (WN == 32 || WN == 64), "tile geometry");
     constexpr int MF = WM / 16, NF = WN / 16;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     T* sA = reinterpret_cast<T*>(smem);   // [NST][BM][BK]
-    T* sW = sA + NST * BM * BK;           // [NST][BN][BK]
+    T* sW = sA + NST * BM * BK;           // [NST][WS][BN][BK]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WGN, wn = wave % WGN;
 
     // ---- XCD-aware bijective remap of the linear block id
     const int nbn = p.N / BN;
@@ -62,33 +69,34 @@ __global__ void __launch_bounds__(256) gemm_kernel(const GemmArgs p) {
     void* const outp = p.out_table ? p.out_table[grp] : p.out;
 
     // ---- staging: one wave instruction moves 8 rows x 128 B
-    const int wsp = p.wsplit > 1 ? p.wsplit : 1;
-    const int nka = p.K / BK;          // k-tiles of A; the W' = [W_hi | W_lo] sequence is wsp times longer
+    const int nka = p.K / BK;
     const int srow = lane >> 3;
     const int pch = lane & 7;
-    const T* a_src[BM / 32];
-    const T* w_src[BN / 32];
+    const T* a_src[PA];
+    const T* w_src[PW];
 #pragma unroll
-    for (int t = 0; t < BM / 32; ++t) {
-        const int r = (wave * (BM / 32) + t) * 8 + srow;
+    for (int t = 0; t < PA; ++t) {
+        const int r = (wave * PA + t) * 8 + srow;
         int gr = m0 + r;
         gr = gr < p.M ? gr : p.M - 1;
         a_src[t] = A + (size_t)gr * p.lda + swz(r, pch) * 8;
     }
 #pragma unroll
-    for (int t = 0; t < BN / 32; ++t) {
-        const int r = (wave * (BN / 32) + t) * 8 + srow;
+    for (int t = 0; t < PW; ++t) {
+        const int r = (wave * PW + t) * 8 + srow;
         int gr = n0 + r;
         gr = gr < p.N ? gr : p.N - 1;
-        w_src[t] = W + (size_t)gr * (size_t)(p.K * wsp) + swz(r, pch) * 8;
+        w_src[t] = W + (size_t)gr * (size_t)(p.K * WS) + swz(r, pch) * 8;
     }
     auto stage = [&](int kt, int buf) {
 #pragma unroll
-        for (int t = 0; t < BM / 32; ++t)
-            glds16(a_src[t] + (kt >= nka ? kt - nka : kt) * BK, sA + (buf * BM + (wave * (BM / 32) + t) * 8) * BK);
+        for (int t = 0; t < PA; ++t)
+            glds16(a_src[t] + kt * BK, sA + (buf * BM + (wave * PA + t) * 8) * BK);
 #pragma unroll
-        for (int t = 0; t < BN / 32; ++t)
-            glds16(w_src[t] + kt * BK, sW + (buf * BN + (wave * (BN / 32) + t) * 8) * BK);
+        for (int part = 0; part < WS; ++part)
+#pragma unroll
+            for (int t = 0; t < PW; ++t)
+                glds16(w_src[t] + part * p.K + kt * BK, sW + ((buf * WS + part) * BN + (wave * PW + t) * 8) * BK);
     };
 
     f32x4 acc[MF][NF];
@@ -99,29 +107,33 @@ __global__ void __launch_bounds__(256) gemm_kernel(const GemmArgs p) {
 
     const int fr = lane & 15;   // fragment row supplied by this lane
     const int fg = lane >> 4;   // k-group (16-byte chunk) supplied by this lane
-    const int nk = nka * wsp;
+    const int nk = nka;
 
     auto compute = [&](int buf) {
         const T* a = sA + buf * BM * BK;
-        const T* w = sW + buf * BN * BK;
+        const T* w = sW + buf * WS * BN * BK;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            v8 wf[NF], af[MF];
+            v8 wf[WS][NF], af[MF];
             const int lc = ks * 4 + fg;
 #pragma unroll
-            for (int j = 0; j < NF; ++j) {
-                const int r = wn * WN + j * 16 + fr;
-                wf[j] = *reinterpret_cast<const v8*>(w + r * BK + swz(r, lc) * 8);
-            }
+            for (int part = 0; part < WS; ++part)
+#pragma unroll
+                for (int j = 0; j < NF; ++j) {
+                    const int r = wn * WN + j * 16 + fr;
+                    wf[part][j] = *reinterpret_cast<const v8*>(w + (part * BN + r) * BK + swz(r, lc) * 8);
+                }
 #pragma unroll
             for (int i = 0; i < MF; ++i) {
                 const int r = wm * WM + i * 16 + fr;
                 af[i] = *reinterpret_cast<const v8*>(a + r * BK + swz(r, lc) * 8);
             }
 #pragma unroll
-            for (int i = 0; i < MF; ++i)
+            for (int part = 0; part < WS; ++part)
 #pragma unroll
-                for (int j = 0; j < NF; ++j) acc[i][j] = mfma16(wf[j], af[i], acc[i][j]);
+                for (int i = 0; i < MF; ++i)
+#pragma unroll
+                    for (int j = 0; j < NF; ++j) acc[i][j] = mfma16(wf[part][j], af[i], acc[i][j]);
         }
     };
 
@@ -140,7 +152,7 @@ __global__ void __launch_bounds__(256) gemm_kernel(const GemmArgs p) {
         // so the per-tile L2/HBM round trip (not MFMA time) sets the pace unless several tiles overlap.
         // Each wave issues IPT global_load_lds per tile; before tile kt is read only the (NST-2) younger tiles may
         // still be outstanding -> s_waitcnt vmcnt((NST-2)*IPT), then a raw s_barrier (no vmcnt(0) drain).
-        constexpr int IPT = BM / 32 + BN / 32;
+        constexpr int IPT = PA + WS * PW;
         constexpr int PEND = (NST - 2) * IPT;
         static_assert(PEND < 64, "vmcnt field");
 #pragma unroll
@@ -246,27 +258,44 @@ __global__ void __launch_bounds__(256) gemm_kernel(const GemmArgs p) {
     }
 }
 
-template <class T, int BM, int BN, int EPI, int NST>
+template <class T, int BM, int BN, int WGM, int WGN, int EPI, int NST, int WS>
 static int launch_cfg(const GemmArgs& a, hipStream_t s) {
     const int nbn = a.N / BN, nbm = (a.M + BM - 1) / BM;
-    const size_t lds = (size_t)NST * (BM + BN) * 64 * sizeof(T);
+    const size_t lds = (size_t)NST * (BM + WS * BN) * 64 * sizeof(T);
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<T, BM, BN, EPI, NST>),
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<T, BM, BN, WGM, WGN, EPI, NST, WS>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm_kernel<T, BM, BN, EPI, NST>), dim3(nbm * nbn, a.batch > 1 ? a.batch : 1), dim3(256), lds, s, a);
+    hipLaunchKernelGGL((gemm_kernel<T, BM, BN, WGM, WGN, EPI, NST, WS>), dim3(nbm * nbn, a.batch > 1 ? a.batch : 1),
+                       dim3(64 * WGM * WGN), lds, s, a);
     return hipGetLastError() == hipSuccess ? 0 : 1;
 }
 
+// Tile selection (measured on MI355X, scripts/bench_gemm.py): two resident blocks per CU beat every larger tile that
+// leaves one (128x128 3-stage, 256x128 with 4 or 8 waves: 465-613 TF/s vs 644 TF/s on the scene's big-batch shapes).
+//   plain weights : 128x128x64, 2 stages (64 KB)  for chip-filling grids, 64x64x64 4-stage ring (64 KB) otherwise
+//   split weights : 128x64 (+64 lo) 2 stages (64 KB) / 64x64 (+64 lo) 3-stage ring (72 KB)
 template <class T, int EPI>
 static int launch_epi(const GemmArgs& a, hipStream_t s, const char** err) {
-    const bool n128 = (a.N % 128) == 0;
-    const long tiles128 = (long)((a.M + 127) / 128) * (a.N / 128) * (a.batch > 1 ? a.batch : 1);
+    const long nb = a.batch > 1 ? a.batch : 1;
     int rc;
-    if (n128 && tiles128 >= 192) rc = launch_cfg<T, 128, 128, EPI, 2>(a, s);
-    else rc = launch_cfg<T, 64, 64, EPI, 4>(a, s);
+    if (a.wsplit == 2) {
+        if constexpr (sizeof(T) == 2 && std::is_same<T, f16_t>::value) {
+            const long tiles = (long)((a.M + 127) / 128) * (a.N / 64) * nb;
+            if (tiles >= 384) rc = launch_cfg<T, 128, 64, 2, 2, EPI, 2, 2>(a, s);
+            else rc = launch_cfg<T, 64, 64, 2, 2, EPI, 3, 2>(a, s);
+        } else {
+            *err = "gemm: split weights are only built for fp16";
+            return 1;
+        }
+    } else {
+        const bool n128 = (a.N % 128) == 0;
+        const long tiles128 = (long)((a.M + 127) / 128) * (a.N / 128) * nb;
+        if (n128 && tiles128 >= 192) rc = launch_cfg<T, 128, 128, 2, 2, EPI, 2, 1>(a, s);
+        else rc = launch_cfg<T, 64, 64, 2, 2, EPI, 4, 1>(a, s);
+    }
     if (rc) *err = "gemm: kernel launch failed";
     return rc;
 }

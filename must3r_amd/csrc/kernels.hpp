@@ -26,8 +26,8 @@ struct GemmArgs {
     const float* bias;
     void* out;
     int M, N, K, lda, ldc;
-    // split-weight mode: W is [N, wsplit*K] = [W_hi | W_lo] (both 16-bit); the A tile sequence wraps after K.
-    // out = A.W_hi^T + A.W_lo^T accumulated in fp32 -> weight rounding error drops from 2^-11 to ~2^-22.
+    // split-weight mode: W is [N, 2K] = [W_hi | W_lo] (both fp16); every K-tile multiplies the activation tile with
+    // both halves: out = A.W_hi^T + A.W_lo^T in fp32 -> weight rounding error drops from 2^-11 to ~2^-22.
     int wsplit;              // 0/1 = plain, 2 = [hi|lo]
     // 16-bit-store epilogues: columns < scale_cols are multiplied by out_scale before rounding (the softmax scale
     // 1/sqrt(64) * log2(e) is folded into q here so the attention kernel works in the exp2 domain for free)

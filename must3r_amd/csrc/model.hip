@@ -164,8 +164,11 @@ static void prof_flush(must3r_hip_ctx* c) {
 // ------------------------------------------------------------------------------------------------
 static int gemm(must3r_hip_ctx* c, DType dt, Epi epi, GemmArgs a, hipStream_t s) {
     const char* err = "";
-    const long tiles128 = (long)((a.M + 127) / 128) * (a.N / 128) * (a.batch > 1 ? a.batch : 1);
-    const int cat = (a.N % 128 == 0 && tiles128 >= 192) ? PC_GEMM128 : PC_GEMM64;
+    const long nbat = a.batch > 1 ? a.batch : 1;
+    const int ws = (c && epi != EPI_HEAD) ? c->wsplit : a.wsplit;
+    const long tiles128 = (long)((a.M + 127) / 128) * (a.N / 128) * nbat;
+    const int cat = ws == 2 ? (((long)((a.M + 127) / 128) * (a.N / 64) * nbat >= 384) ? PC_GEMM128 : PC_GEMM64)
+                            : ((a.N % 128 == 0 && tiles128 >= 192) ? PC_GEMM128 : PC_GEMM64);
     if (c && epi != EPI_HEAD) a.wsplit = c->wsplit;
     ProfScope ps(c, s, cat, 2.0 * a.M * a.N * a.K * (a.batch > 1 ? a.batch : 1));
     if (launch_gemm(dt, epi, a, s, &err)) return fail("%s (M=%d N=%d K=%d epi=%d)", err, a.M, a.N, a.K, (int)epi);
