@@ -19,6 +19,7 @@ namespace m3r {
 constexpr int ATT_QW = 32;               // query rows per wave
 constexpr int ATT_QB = 4 * ATT_QW;       // per block
 constexpr int ATT_KT = 64;               // keys per tile
+constexpr float ATT_THR = 6.0f;          // lazy-rescale threshold in log2 units (P <= 64)
 
 template <class T>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) attn_kernel(const AttnArgs p, const int nqb, const int ngrp, const int nsplit) {
@@ -93,17 +94,28 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) a
         }
     };
 
-    f32x4 o_[4][QF];
-    float m_[QF], l_[QF];
+    // Online softmax state, all per query = per lane column (base-2 domain):
+    //   m_  reference exponent (-inf until a valid key has been seen); P = 2^(S - m_)
+    //   o_  un-normalised O^T accumulators; ol_ accumulates the row sums through one extra MFMA whose A operand is a row
+    //       of ones (sum_k P[q][k] lands in every row of ol_) -- 4 MFMAs per tile instead of 32 VALU adds + shuffles.
+    // The softmax is VALU/exp-bound at head dim 64, so the steady state is kept to {max, exp2, cvt}: the S accumulators
+    // are INITIALISED with -m_ (the MFMA then delivers S - m_ for free) and m_ only moves when the tile maximum exceeds
+    // it by more than ATT_THR (lazy rescale: P <= 2^ATT_THR, harmless in fp32 accumulators and in fp16/bf16 P).
+    f32x4 o_[4][QF], ol_[QF];
+    float m_[QF];
 #pragma unroll
     for (int f = 0; f < QF; ++f) {
         m_[f] = -INFINITY;
-        l_[f] = 0.f;
+        ol_[f] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int d = 0; d < 4; ++d) o_[d][f] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    // softmax in base 2; when the q projection already folded scale*log2(e) into Q the scores need no multiply
+    // when the q projection already folded scale*log2(e) into Q the scores need no multiply
     const float c = p.q_prescaled ? 1.0f : p.scale * 1.44269504088896340736f;
+    const float inv_c = 1.0f / c;
+    v8 ones;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ones[e] = (T)1.0f;
 
     int t = t_begin - 1;
     t = advance(t);
@@ -119,10 +131,14 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) a
         const T* v_ = smem_kv[buf][1];
         // ---- S^T = K Q^T
         f32x4 s_[4][QF];
+        float mref[QF];
 #pragma unroll
-        for (int kf = 0; kf < 4; ++kf)
+        for (int f = 0; f < QF; ++f) {
+            mref[f] = (m_[f] == -INFINITY) ? 0.f : m_[f];
+            const float ini = -mref[f] * inv_c;
 #pragma unroll
-            for (int f = 0; f < QF; ++f) s_[kf][f] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int kf = 0; kf < 4; ++kf) s_[kf][f] = f32x4{ini, ini, ini, ini};
+        }
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
@@ -132,6 +148,12 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) a
 #pragma unroll
                 for (int f = 0; f < QF; ++f) s_[kf][f] = mfma16(kfrag, qf_[f][ks], s_[kf][f]);
             }
+        }
+        if (!p.q_prescaled) {   // generic entry (operator tests): bring (S/c - m/c) to the base-2 domain
+#pragma unroll
+            for (int kf = 0; kf < 4; ++kf)
+#pragma unroll
+                for (int f = 0; f < QF; ++f) s_[kf][f] *= c;
         }
         // ---- exclusion / tail mask: s_[kf][f][r] is key k0 + 16 kf + 4 fg + r
         const int k0 = t * ATT_KT;
@@ -148,7 +170,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) a
                     for (int f = 0; f < QF; ++f) s_[kf][f][r] += pen;   // finite + (-inf) = -inf
                 }
         }
-        // ---- online softmax (base 2), per query = per lane column; keys of a query live in lanes fr+16*g
+        // ---- online softmax: s_ holds S - m_ (base 2); keys of a query live in lanes fr + 16*g
 #pragma unroll
         for (int f = 0; f < QF; ++f) {
             float mx = -INFINITY;
@@ -158,23 +180,30 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) a
                 for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s_[kf][f][r]);
             mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-            const float mnew = fmaxf(m_[f], mx * c);
-            const float msafe = (mnew == -INFINITY) ? 0.f : mnew;
-            const float alpha = __builtin_amdgcn_exp2f(m_[f] - msafe);
-            m_[f] = mnew;
-            float ps = 0.f;
+            const bool first = (m_[f] == -INFINITY);
+            const bool grow = first ? (mx != -INFINITY) : (mx > ATT_THR);
+            if (__any(grow)) {   // wave-uniform slow path: move the reference
+                // first valid tile of this row: shift to its maximum (either sign); later: only upwards
+                float d = first ? mx : fmaxf(mx, 0.f);
+                if (d == -INFINITY) d = 0.f;                      // row still has no valid key
 #pragma unroll
-            for (int kf = 0; kf < 4; ++kf)
+                for (int kf = 0; kf < 4; ++kf)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float e = __builtin_amdgcn_exp2f(s_[kf][f][r] * c - msafe);
-                    s_[kf][f][r] = e;
-                    ps += e;
+                    for (int r = 0; r < 4; ++r) s_[kf][f][r] = __builtin_amdgcn_exp2f(s_[kf][f][r] - d);
+                if (!first) {                                      // O and the row sums are still zero on the first tile
+                    const float alpha = __builtin_amdgcn_exp2f(-d);
+#pragma unroll
+                    for (int dd = 0; dd < 4; ++dd) o_[dd][f] *= alpha;
+                    ol_[f] *= alpha;
+                    m_[f] = mref[f] + d;
+                } else if (mx != -INFINITY) {
+                    m_[f] = d;                                     // mref was 0
                 }
-            l_[f] = l_[f] * alpha + ps;
-            if (!__all(alpha == 1.0f)) {  // wave-uniform: once the running max has settled the O rescale is skipped
+            } else {
 #pragma unroll
-                for (int d = 0; d < 4; ++d) o_[d][f] *= alpha;
+                for (int kf = 0; kf < 4; ++kf)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) s_[kf][f][r] = __builtin_amdgcn_exp2f(s_[kf][f][r]);
             }
         }
         // ---- O^T += V^T P^T ; k-slot e of lane group g <-> keys {4g+e (e<4), 16+4g+e-4 (e>=4)} of the 32-key slot
@@ -190,6 +219,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) a
                     pv[4 + r] = s_[2 * ks + 1][f][r];
                 }
                 pb[f] = cvt8<T>(pv);
+                ol_[f] = mfma16(ones, pb[f], ol_[f]);   // row sums of the (rounded) P actually multiplied into O
             }
             // transposing reads: chunk m = fr of the 16-lane group = row (m>>2), d-columns 4*(m&3)..+3
             v4 tr[8];
@@ -220,9 +250,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) a
     T* __restrict__ O = reinterpret_cast<T*>(p.O);
 #pragma unroll
     for (int f = 0; f < QF; ++f) {
-        float l = l_[f];
-        l += __shfl_xor(l, 16, 64);
-        l += __shfl_xor(l, 32, 64);
+        const float l = ol_[f][0];   // every row of the ones-product holds the full row sum
         const int q = qr0 + f * 16 + fr;
         if (q >= vw.nq) continue;
         const size_t row = (size_t)(vw.q_row0 + q);
