@@ -178,8 +178,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) a
             for (int kf = 0; kf < 4; ++kf)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s_[kf][f][r]);
-            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            mx = quad_row_max(mx);
             const bool first = (m_[f] == -INFINITY);
             const bool grow = first ? (mx != -INFINITY) : (mx > ATT_THR);
             if (__any(grow)) {   // wave-uniform slow path: move the reference

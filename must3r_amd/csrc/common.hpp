@@ -85,6 +85,18 @@ __device__ __forceinline__ void glds16(const void* gptr, void* lds_base_uniform)
                                      (__attribute__((address_space(3))) void*)lds_base_uniform, 16, 0, 0);
 }
 
+// max over the 4 lanes {l, l^16, l^32, l^48} with the gfx950 VALU half/row swaps (no LDS round trip, unlike __shfl_xor =
+// ds_bpermute).  v_permlane32_swap(a, b): a' = {a.lo32, b.lo32}, b' = {a.hi32, b.hi32}; v_permlane16_swap swaps the odd
+// 16-lane rows of a with the even rows of b.  Called with a = b = x both results together hold x[l] and x[l ^ 32 / 16].
+__device__ __forceinline__ float quad_row_max(float x) {
+    unsigned u = __float_as_uint(x);
+    auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    x = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+    u = __float_as_uint(x);
+    auto q = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return fmaxf(__uint_as_float(q[0]), __uint_as_float(q[1]));
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
