@@ -78,11 +78,17 @@ def main():
     # host threads: the CPU only generates the synthetic weights; never let N ranks x all cores oversubscribe the box
     torch.set_num_threads(max(1, min(16, (os.cpu_count() or 8) // max(1, world))))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    ndev = torch.cuda.device_count()
+    backend = os.environ.get("M3R_DIST_BACKEND", "nccl")   # "gloo": ranks may share a GPU (1-GPU box dry run of the N>1 path)
+    dev_index = local_rank if backend == "nccl" else local_rank % max(1, ndev)
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     cfg, H, W, V = MUST3R_512, 384, 512, args.views
     N = (H // 16) * (W // 16)
@@ -256,7 +262,7 @@ def main():
             "dtype": dtype_label, "data": "synthetic",
             "config": {"workload": f"MUSt3R_512 ViT-L/ViT-B random-init, {V}-view memory, {V * world} views/step 384x512 "
                                    f"(encode+update[2,1..]+render+activation)", "views_per_step": V * world, "keyframes": n_key,
-                       "H": H, "W": W, "scenes_in_flight": len(lanes), "parallelism": "single" if world == 1 else f"view-sharded x{world} + all-gather(keyframe tokens)"},
+                       "H": H, "W": W, "scenes_in_flight": len(lanes), "parallelism": "single" if world == 1 else f"view-sharded x{world} + all-gather(keyframe tokens) [{backend}]"},
             "roofline": roofline, "cpu_baseline": cpu_baseline, "parity_vs_cpu_oracle": parity,
             "kernel_classes": classes, "stages_ms": stages, "alt": alt,
             "scene_tflop": round(flops / 1e12, 2) if flops else None,

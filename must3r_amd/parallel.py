@@ -35,6 +35,9 @@ def all_gather_varlen(t, group=None):
     rank, world = _world(group)
     if world == 1:
         return t
+    if t.is_cuda and dist.get_backend(group) == "gloo":
+        # gloo has no CUDA all_gather: stage through the host (only used when ranks share a GPU in tests)
+        return all_gather_varlen(t.cpu(), group).to(t.device)
     counts = [torch.zeros(1, dtype=torch.int64, device=t.device) for _ in range(world)]
     dist.all_gather(counts, torch.tensor([t.shape[0]], dtype=torch.int64, device=t.device), group=group)
     counts = [int(c.item()) for c in counts]
