@@ -166,7 +166,7 @@ def main():
                    "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1) if v["ms"] > 0 and v["flops"] > 0 else None}
                for k, v in prof.items()}
     # roofline of the dominant KERNEL (one symbol in the rocprofv3 trace): attention = self + cross launches of attn_kernel
-    kern = {"attn_kernel": ["attn_self", "attn_cross"], "gemm_kernel<128x128>": ["gemm128"], "gemm_kernel<64x64>": ["gemm64"]}
+    kern = {"attn_kernel": ["attn_self", "attn_cross"], "gemm_kernel<128x128>": ["gemm128"], "gemm_kernel<64x64>": ["gemm64"]}  # <128x128> = the chip-filling tile class (128x64 + lo in split mode)
     agg = {k: {f: sum(prof[c][f] for c in cs if c in prof) for f in ("ms", "flops", "calls")} for k, cs in kern.items()}
     dom = max(agg, key=lambda k: agg[k]["ms"])
     ach = agg[dom]["flops"] / (agg[dom]["ms"] * 1e-3) / 1e12
@@ -179,7 +179,8 @@ def main():
     try:
         import glob
         pmc = json.load(open(sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))[-1]))
-        sym = {"attn_kernel": "attn_kernel", "gemm_kernel<128x128>": "Li128ELi128E", "gemm_kernel<64x64>": "Li64ELi64E"}[dom]
+        big = "Li128ELi64E" if args.precision == "fp16w2" else "Li128ELi128E"   # split weights use a 128x64(+64) tile
+        sym = {"attn_kernel": "attn_kernel", "gemm_kernel<128x128>": big, "gemm_kernel<64x64>": "Li64ELi64E"}[dom]
         want = "DF16b" if args.precision == "bf16" else "DF16_"
         rows = [v for k, v in pmc["kernels"].items() if sym in k and want in k]
         if rows:
