@@ -165,30 +165,38 @@ def main():
     classes = {k: {"ms": round(v["ms"], 3), "calls": int(v["calls"]),
                    "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1) if v["ms"] > 0 and v["flops"] > 0 else None}
                for k, v in prof.items()}
-    # roofline of the dominant KERNEL (one symbol in the rocprofv3 trace): attention = self + cross launches of attn_kernel
-    kern = {"attn_kernel": ["attn_self", "attn_cross"], "gemm_kernel<128x128>": ["gemm128"], "gemm_kernel<64x64>": ["gemm64"]}  # <128x128> = the chip-filling tile class (128x64 + lo in split mode)
-    agg = {k: {f: sum(prof[c][f] for c in cs if c in prof) for f in ("ms", "flops", "calls")} for k, cs in kern.items()}
-    dom = max(agg, key=lambda k: agg[k]["ms"])
-    ach = agg[dom]["flops"] / (agg[dom]["ms"] * 1e-3) / 1e12
-    roofline = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 1), "peak": PEAK_TFLOPS[args.precision], "unit": "TFLOP/s",
-                "frac": round(ach / PEAK_TFLOPS[args.precision], 4), "traffic": None,
-                "avg_launch_us": round(agg[dom]["ms"] * 1e3 / max(1, agg[dom]["calls"]), 2), "launches": int(agg[dom]["calls"]),
-                "algorithmic_flops_per_launch": round(agg[dom]["flops"] / max(1, agg[dom]["calls"]) / 1e9, 3), "flops_unit": "GFLOP"}
-    # HBM bytes per launch of that kernel from the committed PMC passes of this same command (FETCH_SIZE / WRITE_SIZE
-    # cannot be read from inside the process; scripts/gpu_pmc.sh + scripts/pmc_summary.py produce the file)
+    # roofline of the dominant KERNEL = one symbol of the rocprofv3 trace.  attn_kernel (self + cross launches) is the top
+    # symbol in every precision (profiles/r01_bench_kernel_stats.txt: 31-37 %); the GEMM template is spread over one
+    # symbol per epilogue, so its two tile classes are reported next to it under "roofline_gemm".
+    big = "Li128ELi64E" if args.precision == "fp16w2" else "Li128ELi128E"   # split weights use a 128x64(+64 lo) tile
+    kern = {"attn_kernel": (["attn_self", "attn_cross"], "attn_kernel"), "gemm_kernel<big tile>": (["gemm128"], big),
+            "gemm_kernel<64x64 ring>": (["gemm64"], "Li64ELi64E")}
     try:
         import glob
-        pmc = json.load(open(sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))[-1]))
-        big = "Li128ELi64E" if args.precision == "fp16w2" else "Li128ELi128E"   # split weights use a 128x64(+64) tile
-        sym = {"attn_kernel": "attn_kernel", "gemm_kernel<128x128>": big, "gemm_kernel<64x64>": "Li64ELi64E"}[dom]
-        want = "DF16b" if args.precision == "bf16" else "DF16_"
-        rows = [v for k, v in pmc["kernels"].items() if sym in k and want in k]
-        if rows:
-            n = sum(r["launches"] for r in rows)
-            roofline["traffic"] = int(sum(r["hbm_bytes_per_launch_corrected"] * r["launches"] for r in rows) / max(1, n))
-            roofline["traffic_unit"] = "bytes/launch (PMC, corrected; profiles/)"
+        pmc = json.load(open(sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))[-1]))["kernels"]
     except Exception:
-        pass
+        pmc = {}
+    want = "DF16b" if args.precision == "bf16" else "DF16_"
+
+    def roof(name):
+        cs, sym = kern[name]
+        a = {f: sum(prof[c][f] for c in cs if c in prof) for f in ("ms", "flops", "calls")}
+        ach = a["flops"] / (a["ms"] * 1e-3) / 1e12 if a["ms"] > 0 else 0.0
+        r = {"bound": "mfma", "kernel": name, "achieved": round(ach, 1), "peak": PEAK_TFLOPS[args.precision], "unit": "TFLOP/s",
+             "frac": round(ach / PEAK_TFLOPS[args.precision], 4), "traffic": None,
+             "avg_launch_us": round(a["ms"] * 1e3 / max(1, a["calls"]), 2), "launches": int(a["calls"]),
+             "algorithmic_flops_per_launch": round(a["flops"] / max(1, a["calls"]) / 1e9, 3), "flops_unit": "GFLOP"}
+        # HBM bytes per launch from the committed PMC passes of this same command (FETCH_SIZE / WRITE_SIZE cannot be read
+        # from inside the process; scripts/gpu_pmc.sh + scripts/pmc_summary.py produce the file)
+        rows = [v for k, v in pmc.items() if sym in k and want in k]
+        if rows:
+            n = sum(x["launches"] for x in rows)
+            r["traffic"] = int(sum(x["hbm_bytes_per_launch_corrected"] * x["launches"] for x in rows) / max(1, n))
+            r["traffic_unit"] = "bytes/launch (PMC, corrected; profiles/)"
+        return r
+
+    roofline = roof("attn_kernel")
+    roofline_gemm = [roof("gemm_kernel<big tile>"), roof("gemm_kernel<64x64 ring>")]
     # stage split (untimed extra step, single GPU only)
     if world == 1:
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
@@ -264,7 +272,7 @@ def main():
             "config": {"workload": f"MUSt3R_512 ViT-L/ViT-B random-init, {V}-view memory, {V * world} views/step 384x512 "
                                    f"(encode+update[2,1..]+render+activation)", "views_per_step": V * world, "keyframes": n_key,
                        "H": H, "W": W, "scenes_in_flight": len(lanes), "parallelism": "single" if world == 1 else f"view-sharded x{world} + all-gather(keyframe tokens) [{backend}]"},
-            "roofline": roofline, "cpu_baseline": cpu_baseline, "parity_vs_cpu_oracle": parity,
+            "roofline": roofline, "roofline_gemm": roofline_gemm, "cpu_baseline": cpu_baseline, "parity_vs_cpu_oracle": parity,
             "kernel_classes": classes, "stages_ms": stages, "alt": alt,
             "scene_tflop": round(flops / 1e12, 2) if flops else None,
             "end_to_end_mfma_frac": round(flops * args.steps / dt / 1e12 / PEAK_TFLOPS[args.precision], 4) if flops else None,
