@@ -277,6 +277,16 @@ static int launch_cfg(const GemmArgs& a, hipStream_t s) {
 // leaves one (128x128 3-stage, 256x128 with 4 or 8 waves: 465-613 TF/s vs 644 TF/s on the scene's big-batch shapes).
 //   plain weights : 128x128x64, 2 stages (64 KB)  for chip-filling grids, 64x64x64 4-stage ring (64 KB) otherwise
 //   split weights : 128x64 (+64 lo) 2 stages (64 KB) / 64x64 (+64 lo) 3-stage ring (72 KB)
+// minimum number of big tiles for the big-tile kernel (tunable for experiments: M3R_GEMM_MIN_BIG / _MIN_BIG_SPLIT)
+static long min_big(bool split) {
+    static long v[2] = {-1, -1};
+    if (v[split] < 0) {
+        const char* e = getenv(split ? "M3R_GEMM_MIN_BIG_SPLIT" : "M3R_GEMM_MIN_BIG");
+        v[split] = e ? atol(e) : (split ? 384 : 192);
+    }
+    return v[split];
+}
+
 template <class T, int EPI>
 static int launch_epi(const GemmArgs& a, hipStream_t s, const char** err) {
     const long nb = a.batch > 1 ? a.batch : 1;
@@ -284,7 +294,7 @@ static int launch_epi(const GemmArgs& a, hipStream_t s, const char** err) {
     if (a.wsplit == 2) {
         if constexpr (sizeof(T) == 2 && std::is_same<T, f16_t>::value) {
             const long tiles = (long)((a.M + 127) / 128) * (a.N / 64) * nb;
-            if (tiles >= 384) rc = launch_cfg<T, 128, 64, 2, 2, EPI, 2, 2>(a, s);
+            if (tiles >= min_big(true)) rc = launch_cfg<T, 128, 64, 2, 2, EPI, 2, 2>(a, s);
             else rc = launch_cfg<T, 64, 64, 2, 2, EPI, 3, 2>(a, s);
         } else {
             *err = "gemm: split weights are only built for fp16";
@@ -293,7 +303,7 @@ static int launch_epi(const GemmArgs& a, hipStream_t s, const char** err) {
     } else {
         const bool n128 = (a.N % 128) == 0;
         const long tiles128 = (long)((a.M + 127) / 128) * (a.N / 128) * nb;
-        if (n128 && tiles128 >= 192) rc = launch_cfg<T, 128, 128, 2, 2, EPI, 2, 1>(a, s);
+        if (n128 && tiles128 >= min_big(false)) rc = launch_cfg<T, 128, 128, 2, 2, EPI, 2, 1>(a, s);
         else rc = launch_cfg<T, 64, 64, 2, 2, EPI, 4, 1>(a, s);
     }
     if (rc) *err = "gemm: kernel launch failed";

@@ -234,3 +234,36 @@ def test_memory_modes_norm_y_raw_kv(precision):
     record("memory_modes", precision=precision, **errs)
     u = 2.0 ** -8 if precision == "bf16" else 2.0 ** -11
     assert e_raw < TOL[precision] and errs["mem_norm_y"] < TOL[precision] + u and errs["mem_raw"] < TOL[precision] + u, errs
+
+
+def test_baseline_mixed_resolution_forward_list():
+    """BASELINE.json configs[4] geometry: MUSt3R_512 on a mixed-resolution batch 512x{384,336,160} through forward_list
+    (one list entry per aspect ratio, shared memory), update + render, against the fp32 oracle."""
+    from oracle import must3r_ref as R
+    cfg = MUST3R_512
+    enc, dec = build(cfg, "fp16w2")
+    sde, sdd = S.make_encoder_state_dict(cfg, 0), S.make_decoder_state_dict(cfg, 0)
+    sizes = [(384, 512), (336, 512), (160, 512)]
+    imgs = [S.make_images(1, h, w, 10 + i) for i, (h, w) in enumerate(sizes)]
+    xs, ps, ts, xo, po = [], [], [], [], []
+    with torch.no_grad():
+        for im, t in imgs:
+            x, p = enc(im.cuda(), t.cuda())
+            xs.append(x.unsqueeze(0)); ps.append(p.unsqueeze(0)); ts.append(t.cuda().unsqueeze(0))
+            a, b = R.encoder_forward(sde, cfg, im, t, sdpa=True)
+            xo.append(a.unsqueeze(0)); po.append(b.unsqueeze(0))
+    mem, upd = dec(xs, ps, ts, None)
+    _, ren = dec(xs, ps, ts, mem, render=True)
+    tsc = [t.unsqueeze(0) for _, t in imgs]
+    with torch.no_grad():
+        memo, updo = R.decoder_forward(sdd, cfg, xo, po, tsc, None, False, "kv", sdpa=True)
+        _, reno = R.decoder_forward(sdd, cfg, xo, po, tsc, memo, True, "kv", sdpa=True)
+    errs = {}
+    for i, (h, w) in enumerate(sizes):
+        assert upd[i].shape == (1, 1, h, w, 7)
+        errs[f"x_{h}"] = rel_inf(xs[i].cpu(), xo[i])
+        errs[f"update_{h}"] = rel_inf(upd[i].cpu(), updo[i])
+        errs[f"render_{h}"] = rel_inf(ren[i].cpu(), reno[i])
+    record("baseline_mixed_resolution", **errs)
+    assert mem[0][0].shape[1] == sum((h // 16) * (w // 16) for h, w in sizes)
+    assert max(errs.values()) < TOL["fp16w2"], errs
