@@ -20,6 +20,9 @@ def operand_dtype(precision):
 def autocast_dtype():
     """dtype the reference would run a Linear in right now (blocks/__init__.py:5-16 get_current_dtype)."""
     try:
+        if torch.is_autocast_enabled("cuda"):
+            return torch.get_autocast_dtype("cuda")
+    except TypeError:  # older torch: no device argument
         if torch.is_autocast_enabled():
             return torch.get_autocast_gpu_dtype()
     except Exception:
