@@ -107,6 +107,18 @@ __device__ __forceinline__ float wave_sum(float v) {
 // physical chunk = logical chunk ^ ((row >> 1) & 7).  Rows r, r+1 sit in different halves of the 256-byte
 // bank row, so 16 consecutive rows reading the same logical chunk hit 16 distinct 16-byte slots.
 __device__ __forceinline__ int swz(int row, int chunk) { return chunk ^ ((row >> 1) & 7); }
+// The same for [rows][32 x 16-bit] (64-byte rows, 4 chunks): 4 rows share a 256-byte bank row.  The XOR pattern per
+// row quad {0,2,3,1} keeps the hardware's ds_read_b128 service groups ({0-3,12-15,20-27}, {4-11,16-19,28-31}, ...)
+// conflict-free when lanes 0-15 / 16-31 read chunk c / c^1 of rows r0..r0+15.
+__device__ __forceinline__ int swz32(int row, int chunk) {
+    const int q = (row >> 2) & 3;
+    return chunk ^ ((0x1320 >> (q * 4)) & 3);   // q: 0,1,2,3 -> 0,2,3,1
+}
+template <int BK> __device__ __forceinline__ int swzk(int row, int chunk) {
+    if constexpr (BK == 64) return swz(row, chunk);
+    else return swz32(row, chunk);
+}
+
 // V tiles are consumed by ds_read_b64_tr_b16: a 32-lane half reads 8 consecutive rows x one aligned 32-byte pair of
 // chunks.  XOR on the PAIR index (bits 1-2 of the chunk) with (row>>1)&3 puts the 8 rows on 8 distinct 32-byte slots
 // of the 256-byte bank row (rows r, r+1 already sit in different halves); swz() would alias rows r and r+2.

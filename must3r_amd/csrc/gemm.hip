@@ -21,15 +21,17 @@ namespace m3r {
 
 // WS = 2: split-weight mode, W is [N, 2K] = [W_hi | W_lo]; every K-tile stages the activation tile once plus BOTH weight
 // tiles, and each activation fragment feeds two MFMAs (acc += W_hi.a ; acc += W_lo.a).
-template <class T, int BM, int BN, int WGM, int WGN, int EPI, int NST, int WS>
+template <class T, int BM, int BN, int WGM, int WGN, int EPI, int NST, int WS, int BK>
 __global__ void __launch_bounds__(64 * WGM * WGN) gemm_kernel(const GemmArgs p) {
     typedef typename Vec<T>::v8 v8;
     typedef typename Vec<T>::v4 v4;
-    constexpr int BK = 64;
+    static_assert(BK == 64 || BK == 32, "K-tile depth");
     constexpr int NW = WGM * WGN;               // waves per block
     constexpr int WM = BM / WGM, WN = BN / WGN;  // wave tile
-    constexpr int PA = BM / (8 * NW), PW = BN / (8 * NW);  // 8-row DMA pieces per wave and tile
-    static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0 && WM % 16 == 0 && (WN == 32 || WN == 64), "tile geometry");
+    constexpr int CPR = BK / 8;                 // 16-byte chunks per tile row
+    constexpr int RPP = 64 / CPR;               // rows moved by one wave-wide 1 KiB DMA instruction
+    constexpr int PA = BM / (RPP * NW), PW = BN / (RPP * NW);  // DMA pieces per wave and tile
+    static_assert(BM % (RPP * NW) == 0 && BN % (RPP * NW) == 0 && WM % 16 == 0 && (WN == 32 || WN == 64), "tile geometry");
     constexpr int MF = WM / 16, NF = WN / 16;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     T* sA = reinterpret_cast<T*>(smem);   // [NST][BM][BK]
@@ -68,35 +70,35 @@ __global__ void __launch_bounds__(64 * WGM * WGN) gemm_kernel(const GemmArgs p) 
     const float* __restrict__ bias = p.bias ? p.bias + (size_t)grp * p.strideB : nullptr;
     void* const outp = p.out_table ? p.out_table[grp] : p.out;
 
-    // ---- staging: one wave instruction moves 8 rows x 128 B
+    // ---- staging: one wave instruction moves RPP rows x (BK*2) bytes = 1 KiB
     const int nka = p.K / BK;
-    const int srow = lane >> 3;
-    const int pch = lane & 7;
+    const int srow = lane / CPR;
+    const int pch = lane % CPR;
     const T* a_src[PA];
     const T* w_src[PW];
 #pragma unroll
     for (int t = 0; t < PA; ++t) {
-        const int r = (wave * PA + t) * 8 + srow;
+        const int r = (wave * PA + t) * RPP + srow;
         int gr = m0 + r;
         gr = gr < p.M ? gr : p.M - 1;
-        a_src[t] = A + (size_t)gr * p.lda + swz(r, pch) * 8;
+        a_src[t] = A + (size_t)gr * p.lda + swzk<BK>(r, pch) * 8;
     }
 #pragma unroll
     for (int t = 0; t < PW; ++t) {
-        const int r = (wave * PW + t) * 8 + srow;
+        const int r = (wave * PW + t) * RPP + srow;
         int gr = n0 + r;
         gr = gr < p.N ? gr : p.N - 1;
-        w_src[t] = W + (size_t)gr * (size_t)(p.K * WS) + swz(r, pch) * 8;
+        w_src[t] = W + (size_t)gr * (size_t)(p.K * WS) + swzk<BK>(r, pch) * 8;
     }
     auto stage = [&](int kt, int buf) {
 #pragma unroll
         for (int t = 0; t < PA; ++t)
-            glds16(a_src[t] + kt * BK, sA + (buf * BM + (wave * PA + t) * 8) * BK);
+            glds16(a_src[t] + kt * BK, sA + (buf * BM + (wave * PA + t) * RPP) * BK);
 #pragma unroll
         for (int part = 0; part < WS; ++part)
 #pragma unroll
             for (int t = 0; t < PW; ++t)
-                glds16(w_src[t] + part * p.K + kt * BK, sW + ((buf * WS + part) * BN + (wave * PW + t) * 8) * BK);
+                glds16(w_src[t] + part * p.K + kt * BK, sW + ((buf * WS + part) * BN + (wave * PW + t) * RPP) * BK);
     };
 
     f32x4 acc[MF][NF];
@@ -113,7 +115,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN) gemm_kernel(const GemmArgs p) 
         const T* a = sA + buf * BM * BK;
         const T* w = sW + buf * WS * BN * BK;
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
+        for (int ks = 0; ks < BK / 32; ++ks) {
             v8 wf[WS][NF], af[MF];
             const int lc = ks * 4 + fg;
 #pragma unroll
@@ -121,12 +123,12 @@ __global__ void __launch_bounds__(64 * WGM * WGN) gemm_kernel(const GemmArgs p) 
 #pragma unroll
                 for (int j = 0; j < NF; ++j) {
                     const int r = wn * WN + j * 16 + fr;
-                    wf[part][j] = *reinterpret_cast<const v8*>(w + (part * BN + r) * BK + swz(r, lc) * 8);
+                    wf[part][j] = *reinterpret_cast<const v8*>(w + (part * BN + r) * BK + swzk<BK>(r, lc) * 8);
                 }
 #pragma unroll
             for (int i = 0; i < MF; ++i) {
                 const int r = wm * WM + i * 16 + fr;
-                af[i] = *reinterpret_cast<const v8*>(a + r * BK + swz(r, lc) * 8);
+                af[i] = *reinterpret_cast<const v8*>(a + r * BK + swzk<BK>(r, lc) * 8);
             }
 #pragma unroll
             for (int part = 0; part < WS; ++part)
@@ -258,17 +260,17 @@ __global__ void __launch_bounds__(64 * WGM * WGN) gemm_kernel(const GemmArgs p) 
     }
 }
 
-template <class T, int BM, int BN, int WGM, int WGN, int EPI, int NST, int WS>
+template <class T, int BM, int BN, int WGM, int WGN, int EPI, int NST, int WS, int BK = 64>
 static int launch_cfg(const GemmArgs& a, hipStream_t s) {
     const int nbn = a.N / BN, nbm = (a.M + BM - 1) / BM;
-    const size_t lds = (size_t)NST * (BM + WS * BN) * 64 * sizeof(T);
+    const size_t lds = (size_t)NST * (BM + WS * BN) * BK * sizeof(T);
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<T, BM, BN, WGM, WGN, EPI, NST, WS>),
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<T, BM, BN, WGM, WGN, EPI, NST, WS, BK>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm_kernel<T, BM, BN, WGM, WGN, EPI, NST, WS>), dim3(nbm * nbn, a.batch > 1 ? a.batch : 1),
+    hipLaunchKernelGGL((gemm_kernel<T, BM, BN, WGM, WGN, EPI, NST, WS, BK>), dim3(nbm * nbn, a.batch > 1 ? a.batch : 1),
                        dim3(64 * WGM * WGN), lds, s, a);
     return hipGetLastError() == hipSuccess ? 0 : 1;
 }
@@ -277,6 +279,8 @@ static int launch_cfg(const GemmArgs& a, hipStream_t s) {
 // leaves one (128x128 3-stage, 256x128 with 4 or 8 waves: 465-613 TF/s vs 644 TF/s on the scene's big-batch shapes).
 //   plain weights : 128x128x64, 2 stages (64 KB)  for chip-filling grids, 64x64x64 4-stage ring (64 KB) otherwise
 //   split weights : 128x64 (+64 lo) 2 stages (64 KB) / 64x64 (+64 lo) 3-stage ring (72 KB)
+// K-tile depth 32 (the BK template parameter; 3-5 resident blocks per CU) was also measured: 605-626 TF/s plain,
+// 397-419 vs 409 TF/s split -- no gain, so only BK = 64 is instantiated.
 // minimum number of big tiles for the big-tile kernel (tunable for experiments: M3R_GEMM_MIN_BIG / _MIN_BIG_SPLIT)
 static long min_big(bool split) {
     static long v[2] = {-1, -1};

@@ -11,12 +11,25 @@ shapes = [("enc qkv", 15360, 3072, 1024, lib.EPI_STORE16), ("enc proj", 15360, 1
           ("enc6 fc1", 4608, 4096, 1024, lib.EPI_STORE16_GELU)]
 st = torch.cuda.current_stream().cuda_stream
 tot_t = tot_f = 0
+split = int(os.environ.get("SPLIT", "0"))
+tdt, dti = (torch.float16, 1) if split else (torch.bfloat16, 0)
 for name, M, N, K, epi in shapes:
-    A = torch.randn((M, K), device="cuda").bfloat16(); W = (torch.randn((N, K), device="cuda") / math.sqrt(K)).bfloat16()
+    A = torch.randn((M, K), device="cuda").to(tdt)
+    Wf = torch.randn((N, K), device="cuda") / math.sqrt(K)
+    if split:
+        hi = Wf.half(); W = torch.cat((hi, (Wf - hi.float()).half()), dim=1).contiguous()
+    else:
+        W = Wf.to(tdt)
     b = torch.randn((N,), device="cuda")
-    out = torch.zeros((M, N), device="cuda", dtype=torch.float32 if epi == lib.EPI_RESID_F32 else torch.bfloat16)
+    out = torch.zeros((M, N), device="cuda", dtype=torch.float32 if epi == lib.EPI_RESID_F32 else tdt)
     def run():
-        lib.check(L.must3r_hip_op_gemm(0, epi, P(A), P(W), P(b), P(out), M, N, K, K, N, None, None, 0, 0, None, 0, 0, 0, 0, 0, 0, 0, st))
+        lib.check(L.must3r_hip_op_gemm(dti, epi, P(A), P(W), P(b), P(out), M, N, K, K, N, None, None, 0, 0, None, 0, 0, 0, 0, 0, 0, 2 if split else 0, st))
+    if epi == lib.EPI_STORE16:   # correctness of the variant under test
+        run(); torch.cuda.synchronize()
+        ref = A[:512].double() @ (Wf if split else W.float()).double().t() + b.double()
+        err = ((out[:512].double() - ref).abs().max() / ref.abs().max()).item()
+        assert err < 2e-2 if not split else err < 2e-3, (name, err)
+        print(f"  [{name} rel err {err:.2e}]", end="")
     for _ in range(3): run()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
