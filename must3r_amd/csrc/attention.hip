@@ -313,14 +313,26 @@ size_t attention_split_scratch_bytes(int nsplit, int total_q_rows, int heads) {
 }
 
 int attention_pick_split(int nviews, int heads, int max_nq, int max_nk) {
+    // Cost model (256 CUs, up to 3 resident blocks per CU share its pipes): a CU's time ~ (blocks it receives) x (key
+    // tiles per block); the combine pass and the fp32 partials grow with the split factor.  Choosing the factor from
+    // the block count alone put 792 blocks on 256 CUs (3.09 per CU -> a fourth, almost empty round).
     const int nqb = (max_nq + ATT_QB - 1) / ATT_QB;
     const long base = (long)nviews * heads * nqb;
     const int ntiles = (max_nk + ATT_KT - 1) / ATT_KT;
     if (base >= 384 || ntiles < 8) return 1;
-    int s = (int)((768 + base - 1) / base);  // aim at ~3 blocks per CU
-    if (s > ntiles / 4) s = ntiles / 4;       // at least 4 key tiles per block
-    if (s > 16) s = 16;
-    return s < 2 ? 1 : s;
+    int best = 1;
+    double best_cost = 1e30;
+    const int smax = ntiles / 4 < 16 ? ntiles / 4 : 16;   // at least 4 key tiles per block
+    for (int s = 1; s <= smax; ++s) {
+        const long blocks = base * s;
+        const long per_cu = (blocks + 255) / 256;
+        const int tiles = (ntiles + s - 1) / s;
+        double cost = (double)per_cu * tiles;
+        if (blocks < 512) cost *= 1.0 + 0.5 * (512 - blocks) / 512.0;   // under two blocks per CU latencies are exposed
+        cost += (s > 1 ? 3.0 + 0.4 * s : 0.0);                           // combine launch + partial traffic, in tile units
+        if (cost < best_cost) { best_cost = cost; best = s; }
+    }
+    return best;
 }
 
 // hardware-semantics probe used by the tests: LDS holds element index e at position e; every lane issues the
