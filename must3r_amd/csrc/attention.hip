@@ -16,16 +16,17 @@
 
 namespace m3r {
 
-constexpr int ATT_QW = 32;               // query rows per wave
-constexpr int ATT_QB = 4 * ATT_QW;       // per block
+constexpr int ATT_QW = 32;               // query rows per wave (template default); 16 for launches too small to fill the chip
+constexpr int ATT_QB = 4 * ATT_QW;       // per block (default geometry, used by the split heuristic)
 constexpr int ATT_KT = 64;               // keys per tile
 constexpr float ATT_THR = 6.0f;          // lazy-rescale threshold in log2 units (P <= 64)
 
-template <class T>
+template <class T, int QW>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) attn_kernel(const AttnArgs p, const int nqb, const int ngrp, const int nsplit) {
     typedef typename Vec<T>::v8 v8;
     typedef typename Vec<T>::v4 v4;
-    constexpr int QF = ATT_QW / 16;
+    constexpr int QF = QW / 16;
+    constexpr int QB = 4 * QW;               // query rows per block
     // ONE __shared__ object: with two, hipcc drains the in-flight LDS-DMA (vmcnt(0)) before every first ds_read of a
     // tile, which serialises prefetch and compute (cdna_hip_programming.md, ".s-level traps" (a)).
     __shared__ __attribute__((aligned(16))) T smem_kv[2][2][ATT_KT * 64];   // [buffer][K|V][64 keys x 64]
@@ -45,14 +46,14 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) a
     if (grp >= ngrp) return;
     const int view = grp / p.heads, head = grp - view * p.heads;
     const AttnView vw = p.views[view];
-    if (qb * ATT_QB >= vw.nq) return;
+    if (qb * QB >= vw.nq) return;
 
     const T* __restrict__ Q = reinterpret_cast<const T*>(p.Q);
     const T* __restrict__ K = reinterpret_cast<const T*>(p.K) + (size_t)vw.kv_row0 * p.ldk + head * 64;
     const T* __restrict__ V = reinterpret_cast<const T*>(p.V) + (size_t)vw.kv_row0 * p.ldv + head * 64;
 
     // ---- Q fragments (B operand): lane (j = fr, g = fg) holds Q[q = 16 qf + j][d = 32 ks + 8 g ..+7]
-    const int qr0 = qb * ATT_QB + wave * ATT_QW;
+    const int qr0 = qb * QB + wave * QW;
     v8 qf_[QF][2];
 #pragma unroll
     for (int f = 0; f < QF; ++f) {
@@ -316,8 +317,7 @@ int attention_pick_split(int nviews, int heads, int max_nq, int max_nk) {
     // Cost model (256 CUs, up to 3 resident blocks per CU share its pipes): a CU's time ~ (blocks it receives) x (key
     // tiles per block); the combine pass and the fp32 partials grow with the split factor.  Choosing the factor from
     // the block count alone put 792 blocks on 256 CUs (3.09 per CU -> a fourth, almost empty round).
-    const int nqb = (max_nq + ATT_QB - 1) / ATT_QB;
-    const long base = (long)nviews * heads * nqb;
+    const long base = (long)nviews * heads * ((max_nq + ATT_QB - 1) / ATT_QB);
     const int ntiles = (max_nk + ATT_KT - 1) / ATT_KT;
     if (base >= 384 || ntiles < 8) return 1;
     int best = 1;
@@ -356,8 +356,13 @@ int launch_attention_phase(DType dt, const AttnArgs& a, int phase, hipStream_t s
     if ((a.ldq % 8) || (a.ldk % 8) || (a.ldv % 8) || (a.ldo % 4)) { *err = "attention: row strides must be 16-byte aligned"; return 1; }
     const int nsplit = a.nsplit > 1 ? a.nsplit : 1;
     if (nsplit > 1 && (!a.part_o || !a.part_ml || a.total_q_rows <= 0)) { *err = "attention: split-KV needs scratch"; return 1; }
-    const int nqb = (a.max_nq + ATT_QB - 1) / ATT_QB;
+    // Launches that cannot fill 256 CUs even with one block each (a single view's self attention in the memory
+    // update: 12 heads x 6 query blocks) run with 16 query rows per wave: twice the blocks, half the serial work each.
     const int ngrp = a.nviews * a.heads;
+    // (measured: for the split-KV cross attention the 16-row variant is slower, 24.0 vs 22.7 ms per scene)
+    const bool small = nsplit == 1 && (long)ngrp * ((a.max_nq + ATT_QB - 1) / ATT_QB) < 192;
+    const int qb_rows = small ? 64 : ATT_QB;
+    const int nqb = (a.max_nq + qb_rows - 1) / qb_rows;
     const int grid = ((ngrp + 7) / 8) * 8 * nqb * nsplit;
     if (phase == 0) {
         if (nsplit > 1 && !a.dense_rows) {
@@ -366,8 +371,13 @@ int launch_attention_phase(DType dt, const AttnArgs& a, int phase, hipStream_t s
                                a.part_ml, n2);
         }
     } else if (phase == 1) {
-        if (dt == DT_BF16) hipLaunchKernelGGL(attn_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, a, nqb, ngrp, nsplit);
-        else hipLaunchKernelGGL(attn_kernel<f16_t>, dim3(grid), dim3(256), 0, s, a, nqb, ngrp, nsplit);
+        if (small) {
+            if (dt == DT_BF16) hipLaunchKernelGGL((attn_kernel<bf16_t, 16>), dim3(grid), dim3(256), 0, s, a, nqb, ngrp, nsplit);
+            else hipLaunchKernelGGL((attn_kernel<f16_t, 16>), dim3(grid), dim3(256), 0, s, a, nqb, ngrp, nsplit);
+        } else {
+            if (dt == DT_BF16) hipLaunchKernelGGL((attn_kernel<bf16_t, 32>), dim3(grid), dim3(256), 0, s, a, nqb, ngrp, nsplit);
+            else hipLaunchKernelGGL((attn_kernel<f16_t, 32>), dim3(grid), dim3(256), 0, s, a, nqb, ngrp, nsplit);
+        }
     } else if (nsplit > 1) {
         const size_t total = (size_t)a.total_q_rows * a.heads * 16;
         const unsigned g2 = (unsigned)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
