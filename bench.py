@@ -200,15 +200,16 @@ def main():
     # stage split (untimed extra step, single GPU only)
     if world == 1:
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+        ts_host = ts.cpu()
         ev[0].record()
         x, pos = enc(imgs, ts)
         ev[1].record()
         mem, i = None, 0
         for nb in demo_mem_batches(V):
-            mem, _ = dec(x[i:i + nb].unsqueeze(0), pos[i:i + nb].unsqueeze(0), ts[i:i + nb].unsqueeze(0), mem)
+            mem, _ = dec(x[i:i + nb].unsqueeze(0), pos[i:i + nb].unsqueeze(0), ts_host[i:i + nb].unsqueeze(0), mem)
             i += nb
         ev[2].record()
-        dec(x.unsqueeze(0), pos.unsqueeze(0), ts.unsqueeze(0), mem, render=True)
+        dec(x.unsqueeze(0), pos.unsqueeze(0), ts_host.unsqueeze(0), mem, render=True)
         ev[3].record()
         torch.cuda.synchronize(device)
         stages = {"encode": round(ev[0].elapsed_time(ev[1]), 2), "update": round(ev[1].elapsed_time(ev[2]), 2),

@@ -72,6 +72,10 @@ def run_scene(encoder, decoder, imgs, true_shape, mem_batches=None, render_bs=No
     V = imgs.shape[0]
     if mem_batches is None:
         mem_batches = demo_mem_batches(V)
+    # The decoder needs (H, W) as host integers.  Reading them from a CUDA tensor is a device->host sync per call, which
+    # stops the host from queueing ahead of the GPU (the reference does the same: head.py:33 `.cpu().tolist()`); one copy
+    # per scene instead.
+    true_shape = true_shape.cpu() if true_shape.is_cuda else true_shape
     ready = None   # per view: event to wait for before the decoder may read its tokens
     if encoder_tokens is not None:
         x, pos = encoder_tokens

@@ -177,6 +177,8 @@ class MUSt3R(HipModule):
             xi = self._check_input(xi, "x", torch.float32)
             pi = self._check_input(pi, "pos", torch.int64)
             ts = ti.reshape(-1, 2)
+            if ts.is_cuda:  # device->host sync, like the reference's head wrapper (head.py:33); pass it on the host to avoid
+                ts = ts.cpu()
             assert bool((ts[0:1] == ts).all()), "true_shape must be all identical"  # head.py:31
             H, W = (int(v) for v in ts[0].tolist())
             assert (H // 16) * (W // 16) == N, (H, W, N)

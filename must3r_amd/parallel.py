@@ -67,7 +67,7 @@ def run_scene_sharded(encoder, decoder, imgs_local, true_shape_local, keyframe_l
         kx = kx.to(comm_dtype)  # 16-bit on the wire; the decoder rounds its operands to this type anyway
     kx = all_gather_varlen(kx, group).float()
     kpos = all_gather_varlen(pos[kf], group)
-    kts = all_gather_varlen(true_shape_local.to(x.device)[kf], group)
+    kts = all_gather_varlen(true_shape_local.to(x.device)[kf], group).cpu()   # host copy: no per-call sync in the decoder
     K = kx.shape[0]
     if K == 0:
         raise ValueError("run_scene_sharded: no keyframe on any rank")
@@ -78,7 +78,7 @@ def run_scene_sharded(encoder, decoder, imgs_local, true_shape_local, keyframe_l
         i += nb
     out = {"mem": mem, "n_keyframes": K}
     if x.shape[0] > 0:
-        _, pm = decoder(x.unsqueeze(0), pos.unsqueeze(0), true_shape_local.to(x.device).unsqueeze(0), mem, render=True)
+        _, pm = decoder(x.unsqueeze(0), pos.unsqueeze(0), true_shape_local.cpu().unsqueeze(0), mem, render=True)
         out["render"] = pm[0]
     else:
         out["render"] = x.new_zeros((0,))
