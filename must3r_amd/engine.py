@@ -139,3 +139,43 @@ def run_scene(encoder, decoder, imgs, true_shape, mem_batches=None, render_bs=No
     if activate:
         out.update(postprocess(out["render"]))
     return out
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# memory surgery of the L3 engine -- same semantics as the reference helpers
+# engine/inference.py:205-228, but the per-layer buffers are compacted IN PLACE, so the tensors stay prefix views of
+# the decoder's over-allocated K|V buffers and the next memory update appends without copying the whole memory.
+# ------------------------------------------------------------------------------------------------------------------
+def remove_from_mem(mem_values, mem_labels, idx):
+    """``_remove_from_mem`` (engine/inference.py:205-213): drop every token whose label equals ``idx``.
+
+    mem_values: list of [B=1, Nm, D]; mem_labels: int64 [1, Nm].  Returns (mem_values, mem_labels)."""
+    keep = mem_labels != idx
+    B, _, D = mem_values[0].shape
+    owner = getattr(mem_values[0], "_m3r_owner", None)
+    in_place = (B == 1 and owner is not None and owner.valid == mem_values[0].shape[1]
+                and all(getattr(v, "_m3r_owner", None) is owner for v in mem_values))
+    if not in_place:
+        return [v[keep].view(B, -1, D) for v in mem_values], mem_labels[keep].view(B, -1)
+    kept = keep[0].nonzero().flatten()
+    n = int(kept.numel())
+    for b in owner.bufs:
+        b[:, :n] = b[:, kept]          # gather then prefix write: source rows are read before being overwritten
+    owner.valid = n
+    return owner.views(n), mem_labels[keep].view(1, -1)
+
+
+def restore_label_in_mem(mem_labels, old_idx_to_restore, new_idx_to_remove):
+    """``_restore_label_in_mem`` (engine/inference.py:216-219), in place."""
+    mem_labels[mem_labels == new_idx_to_remove] = old_idx_to_restore
+    return mem_labels
+
+
+def update_in_mem(old_values, new_values, old_labels, new_labels, old_idx, new_idx):
+    """``_update_in_mem`` (engine/inference.py:222-228): overwrite the tokens labelled ``old_idx`` in ``old_values`` with
+    the tokens labelled ``new_idx`` of ``new_values`` (in place; views of the decoder's buffers stay valid)."""
+    old_mask = old_labels == old_idx
+    new_mask = new_labels == new_idx
+    for k in range(len(old_values)):
+        old_values[k][old_mask] = new_values[k][new_mask]
+    return old_values

@@ -104,3 +104,47 @@ def test_demo_mem_batches():
     assert demo_mem_batches(20) == [2] + [1] * 18          # demo/inference.py:188-191 defaults
     assert demo_mem_batches(2) == [2] and demo_mem_batches(1) == [1]
     assert demo_mem_batches(7, 2, 2) == [2, 2, 2, 1]
+
+
+def test_memory_surgery_helpers_match_reference_and_keep_buffers():
+    """remove / restore-label / update-in-place helpers against the reference's own
+    engine/inference.py:205-228 (when the tree is present), on CPU tensors; the in-place form must keep buffer ownership."""
+    from must3r_amd.engine import remove_from_mem, restore_label_in_mem, update_in_mem
+    from must3r_amd.model.decoder import _MemBuffers
+    torch.manual_seed(0)
+    depth, N, D = 3, 5, 8
+    labels = torch.arange(4).repeat_interleave(N).view(1, -1)
+    owner = _MemBuffers(depth, 64, D, torch.float32, torch.device("cpu"))
+    for b in owner.bufs:
+        b.normal_()
+    owner.valid = 4 * N
+    vals = owner.views(4 * N)
+    ref_vals = [v.clone() for v in vals]
+
+    def ref_remove(mem_values, mem_labels, idx):       # engine/inference.py:205-213
+        keep = mem_labels != idx
+        B, _, Dd = mem_values[0].shape
+        return [m[keep].view(B, -1, Dd) for m in mem_values], mem_labels[keep].view(B, -1)
+
+    got_v, got_l = remove_from_mem(vals, labels.clone(), 1)
+    exp_v, exp_l = ref_remove(ref_vals, labels.clone(), 1)
+    assert torch.equal(got_l, exp_l) and all(torch.equal(a, b) for a, b in zip(got_v, exp_v))
+    assert owner.valid == 3 * N and all(getattr(v, "_m3r_owner", None) is owner for v in got_v)   # still appendable
+    assert got_v[0].data_ptr() == owner.bufs[0].data_ptr()
+    # foreign tensors (no owner): plain functional behaviour
+    f_v, f_l = remove_from_mem([v.clone() for v in exp_v], exp_l.clone(), 3)
+    e_v, e_l = ref_remove(exp_v, exp_l.clone(), 3)
+    assert torch.equal(f_l, e_l) and all(torch.equal(a, b) for a, b in zip(f_v, e_v))
+    assert torch.equal(restore_label_in_mem(torch.tensor([[0, 7, 7, 2]]), 1, 7), torch.tensor([[0, 1, 1, 2]]))
+    new_vals = [torch.randn(1, 2 * N, D) for _ in range(depth)]
+    new_labels = torch.tensor([[5] * N + [6] * N])
+    upd = update_in_mem(got_v, new_vals, got_l, new_labels, 2, 6)
+    assert torch.equal(upd[1][got_l == 2], new_vals[1][new_labels == 6]) and torch.equal(upd[1][got_l == 0], exp_v[1][exp_l == 0])
+    from conftest import HAS_REFERENCE
+    if HAS_REFERENCE:
+        from oracle import ref_shims
+        ref_shims.install()
+        import must3r.engine.inference as RI
+        r_v, r_l = RI._remove_from_mem([v.clone() for v in ref_vals], labels.clone(), 1)
+        assert torch.equal(r_l, exp_l) and all(torch.equal(a, b) for a, b in zip(r_v, exp_v))
+        assert torch.equal(RI._restore_label_in_mem(torch.tensor([[0, 7, 7, 2]]), 1, 7), torch.tensor([[0, 1, 1, 2]]))

@@ -267,3 +267,31 @@ def test_baseline_mixed_resolution_forward_list():
     record("baseline_mixed_resolution", **errs)
     assert mem[0][0].shape[1] == sum((h // 16) * (w // 16) for h, w in sizes)
     assert max(errs.values()) < TOL["fp16w2"], errs
+
+
+def test_native_memory_surgery_keeps_append_in_place():
+    """must3r_amd.engine.remove_from_mem (the in-place form of engine/inference.py:205-213) on device memory: the
+    surviving tokens equal the reference's boolean-index result, the tensors remain views of the decoder's buffers, and
+    the next update appends behind them without reallocating."""
+    from must3r_amd.engine import remove_from_mem
+    from oracle import must3r_ref as R
+    cfg = TINY
+    enc, dec = build(cfg, "fp16w2")
+    sdd = S.make_decoder_state_dict(cfg, 0)
+    imgs, ts = S.make_images(4, 48, 64, 3)
+    x, pos = enc(imgs.cuda(), ts.cuda())
+    mem, _ = dec(x[:2].unsqueeze(0), pos[:2].unsqueeze(0), ts[:2].unsqueeze(0), None)
+    mem, _ = dec(x[2:3].unsqueeze(0), pos[2:3].unsqueeze(0), ts[2:3].unsqueeze(0), mem)
+    expect = [v[mem[1] != 1].view(1, -1, v.shape[-1]).clone() for v in mem[0]]
+    base_ptr = mem[0][0].data_ptr()
+    vals, labels = remove_from_mem(mem[0], mem[1], 1)
+    assert all(torch.equal(a, b) for a, b in zip(vals, expect)) and vals[0].data_ptr() == base_ptr
+    assert labels.tolist() == [[0] * 12 + [2] * 12]
+    edited = (vals, labels, mem[2], mem[3], mem[4])
+    mem2, _ = dec(x[3:4].unsqueeze(0), pos[3:4].unsqueeze(0), ts[3:4].unsqueeze(0), edited)
+    assert mem2[0][0].data_ptr() == base_ptr and mem2[0][0].shape[1] == 36      # appended in place
+    assert torch.equal(mem2[0][1][:, :24], expect[1])
+    _, pm = dec(x.unsqueeze(0), pos.unsqueeze(0), ts.unsqueeze(0), mem2, render=True)
+    mem_cpu = ([v.float().cpu() for v in mem2[0]], mem2[1].cpu(), mem2[2], mem2[3], mem2[4])
+    _, ref = R.decoder_forward(sdd, cfg, x.cpu().unsqueeze(0), pos.cpu().unsqueeze(0), ts.unsqueeze(0), mem_cpu, True, "kv")
+    assert rel_inf(pm.cpu(), ref) < TOL["fp16w2"]
