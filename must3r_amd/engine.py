@@ -179,3 +179,51 @@ def update_in_mem(old_values, new_values, old_labels, new_labels, old_idx, new_i
     for k in range(len(old_values)):
         old_values[k][old_mask] = new_values[k][new_mask]
     return old_values
+
+
+@torch.no_grad()
+def run_video(encoder, decoder, imgs, true_shape, local_context_size=25, is_keyframe=lambda i: i % 3 == 0,
+              init_num_images=2, encoder_tokens=None):
+    """Online / streaming memory (BASELINE.json configs[3]), single pass, single aspect ratio: the schedule of
+    ``inference_video_multi_ar`` (engine/inference.py:232-366 with num_refinements_iterations=0).
+
+    Every frame updates the memory ([init_num_images, 1, 1, ...]); the frames of the first batch and every frame for
+    which ``is_keyframe(id)`` holds (reference default: every 3rd, :236) stay; other frames are evicted once they leave
+    the window of the last ``local_context_size`` frames (:336-339) and at the end of the pass (:356-361).  Eviction uses
+    ``remove_from_mem`` (in-place compaction of the decoder's buffers when the memory is theirs).
+
+    Returns (mem_tuple, pointmaps_0 [V,H,W,7], keyframe ids)."""
+    from collections import deque
+    V = imgs.shape[0]
+    ts_host = true_shape.cpu() if true_shape.is_cuda else true_shape
+    x, pos = encoder_tokens if encoder_tokens is not None else encoder(imgs, true_shape)
+    mem = None
+    img_labels, keyframes, working = {}, set(), deque()
+    pointmaps_0 = []
+    i = 0
+    for nb in demo_mem_batches(V, init_num_images, 1):
+        ids = list(range(i, i + nb))
+        n_before = 0 if mem is None else mem[2]
+        mem, pm = decoder(x[i:i + nb].unsqueeze(0), pos[i:i + nb].unsqueeze(0), ts_host[i:i + nb].unsqueeze(0), mem)
+        pointmaps_0.append(pm[0])
+        mem = list(mem)
+        new_labels = [n_before + j for j in range(nb)]      # decoder.py:332-334: labels = arange(n) + mem_nimgs
+        first = len(img_labels) == 0
+        for j, vid in enumerate(ids):
+            img_labels[vid] = new_labels[j]
+            working.append(vid)
+            if first or is_keyframe(vid):
+                keyframes.add(vid)
+        while len(working) > local_context_size:              # :336-339
+            old = working.popleft()
+            if old not in keyframes:
+                mem[0], mem[1] = remove_from_mem(mem[0], mem[1], img_labels[old])
+        mem[2] = len(img_labels)                              # :342 restore mem_nimgs
+        mem = tuple(mem)
+        i += nb
+    mem = list(mem)
+    while working:                                            # :356-361
+        old = working.popleft()
+        if old not in keyframes:
+            mem[0], mem[1] = remove_from_mem(mem[0], mem[1], img_labels[old])
+    return tuple(mem), torch.cat(pointmaps_0, dim=0), sorted(keyframes)

@@ -295,3 +295,30 @@ def test_native_memory_surgery_keeps_append_in_place():
     mem_cpu = ([v.float().cpu() for v in mem2[0]], mem2[1].cpu(), mem2[2], mem2[3], mem2[4])
     _, ref = R.decoder_forward(sdd, cfg, x.cpu().unsqueeze(0), pos.cpu().unsqueeze(0), ts.unsqueeze(0), mem_cpu, True, "kv")
     assert rel_inf(pm.cpu(), ref) < TOL["fp16w2"]
+
+
+def test_streaming_memory_schedule_vs_oracle():
+    """BASELINE.json configs[3] semantics at test scale: online memory with a local window and keyframe-only retention
+    (engine/inference.py:232-366), HIP path with in-place eviction vs the oracle driven through the SAME schedule with the
+    reference's functional eviction.  12 frames, window 4, keyframe every 3rd."""
+    from must3r_amd.engine import run_video
+    from oracle import must3r_ref as R
+    cfg = TINY
+    enc, dec = build(cfg, "fp16w2")
+    sde, sdd = S.make_encoder_state_dict(cfg, 0), S.make_decoder_state_dict(cfg, 0)
+    imgs, ts = S.make_images(12, 48, 64, 9)
+    mem, pm0, kf = run_video(enc, dec, imgs.cuda(), ts, local_context_size=4)
+    enc_o = lambda im, t: R.encoder_forward(sde, cfg, im, t)  # noqa: E731
+    dec_o = lambda x, p, t, m=None, render=False: R.decoder_forward(sdd, cfg, x, p, t, m, render, "kv")  # noqa: E731
+    with torch.no_grad():
+        memo, pmo, kfo = run_video(enc_o, dec_o, imgs, ts, local_context_size=4)
+    assert kf == kfo == [0, 1, 3, 6, 9]
+    assert torch.equal(mem[1].cpu(), memo[1]) and mem[2:] == memo[2:]          # surviving labels: keyframes only
+    assert mem[1].unique().tolist() == [0, 1, 3, 6, 9] and mem[0][0].shape[1] == 5 * 12
+    e_pm = rel_inf(pm0.cpu(), pmo)
+    e_mem = max(rel_inf(a.float().cpu(), b) for a, b in zip(mem[0], memo[0]))
+    record("streaming_vs_oracle", pointmaps=e_pm, memory=e_mem)
+    assert e_pm < TOL["fp16w2"] and e_mem < TOL["fp16w2"] + 2.0 ** -11, (e_pm, e_mem)
+    # and the survivors can be rendered against
+    _, ren = dec(*[t.unsqueeze(0) for t in enc(imgs[:2].cuda(), ts[:2])], ts[:2].unsqueeze(0), mem, render=True)
+    assert torch.isfinite(ren).all()

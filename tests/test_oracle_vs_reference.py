@@ -60,3 +60,29 @@ def test_arg_rewriting_equals_reference():
         for size in (224, 512, 768):
             assert M.set_image_size_in_args(s, size, verbose=False) == ref.set_image_size_in_args(s, size, verbose=False)
     assert M.get_dtype("bf16") == torch.bfloat16 and M.get_dtype(False) == torch.float32
+
+
+def test_streaming_schedule_equals_reference_driver():
+    """must3r_amd.engine.run_video restates inference_video_multi_ar (engine/inference.py:232-366).  Run the REAL reference
+    driver with the REAL reference modules and compare the surviving memory / labels / first-pass pointmaps with run_video
+    driven by the oracle forwards."""
+    from oracle import ref_shims, must3r_ref as R
+    from must3r_amd.engine import run_video
+    ref_shims.install()
+    import must3r.engine.inference as RI
+    cfg = TINY
+    sde, sdd = S.make_encoder_state_dict(cfg, 0), S.make_decoder_state_dict(cfg, 0)
+    enc, dec = ref_shims.build_reference(cfg, sde, sdd, "kv")
+    V = 11
+    imgs, ts = S.make_images(V, 48, 64, 4)
+    with torch.no_grad():
+        mem_r, pm_r = RI.inference_video_multi_ar(enc, dec, [im for im in imgs], [t for t in ts], [2] + [1] * (V - 2),
+                                                  return_mem=True, local_context_size=3,
+                                                  device=torch.device("cpu"))
+        enc_o = lambda im, t: R.encoder_forward(sde, cfg, im, t)  # noqa: E731
+        dec_o = lambda x, p, t, m=None, render=False: R.decoder_forward(sdd, cfg, x, p, t, m, render, "kv")  # noqa: E731
+        mem_o, pm_o, kf = run_video(enc_o, dec_o, imgs, ts, local_context_size=3)
+    assert kf == [0, 1, 3, 6, 9]
+    assert torch.equal(mem_r[1], mem_o[1]) and int(mem_r[2]) == int(mem_o[2])
+    assert max(rel_inf(a, b) for a, b in zip(mem_o[0], mem_r[0])) < 2e-5
+    assert rel_inf(pm_o, torch.stack([p["pts3d"] for p in pm_r], dim=0)) < 2e-5
