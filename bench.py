@@ -62,6 +62,9 @@ def main():
     ap.add_argument("--no-alt", action="store_true")
     ap.add_argument("--cpu-timeout", type=float, default=240.0)
     ap.add_argument("--no-overlap", action="store_true", help="encode everything before the memory update (no 2nd stream)")
+    ap.add_argument("--enc-cus", type=int, default=0, help="run the overlapped encoder on a stream restricted to this many CUs")
+    ap.add_argument("--upd-cus", type=int, default=0, help="run the memory update on a stream restricted to this many CUs")
+    ap.add_argument("--enc-chunk", type=int, default=6, help="views per encoder call on the second stream")
     ap.add_argument("--inflight", type=int, default=1, help="scenes in flight: consecutive steps alternate over this many independent "
                     "contexts/streams (software pipelining across steps; every step still does all of its work)")
     args = ap.parse_args()
@@ -117,7 +120,8 @@ def main():
         e_, d_, st = lanes[step_no[0] % len(lanes)]
         step_no[0] += 1
         if st is None:
-            return run_scene(e_, d_, imgs, ts, overlap=not args.no_overlap)
+            return run_scene(e_, d_, imgs, ts, overlap=not args.no_overlap, enc_cus=args.enc_cus, upd_cus=args.upd_cus,
+                             enc_chunk=args.enc_chunk)
         st.wait_stream(torch.cuda.current_stream(device))
         with torch.cuda.stream(st):
             return run_scene(e_, d_, imgs, ts, overlap=False)
@@ -215,6 +219,27 @@ def main():
         stages = {"encode": round(ev[0].elapsed_time(ev[1]), 2), "update": round(ev[1].elapsed_time(ev[2]), 2),
                   "render": round(ev[2].elapsed_time(ev[3]), 2)}
 
+    # postprocess(compute_cam=True) on the scene's 20 rendered pointmaps (HBM-bound:
+    # 28 B read + 28 B written per pixel; the focal iteration and the registration add no HBM pass)
+    cam = None
+    if rank == 0 and world == 1:
+        from must3r_amd.engine import postprocess
+        pmaps = step()["render"]
+        for _ in range(3):
+            postprocess(pmaps, compute_cam=True)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        reps = 20
+        e0.record()
+        for _ in range(reps):
+            postprocess(pmaps, compute_cam=True)
+        e1.record()
+        torch.cuda.synchronize(device)
+        ms = e0.elapsed_time(e1) / reps
+        nbytes = pmaps.numel() // 7 * 56
+        cam = {"op": "postprocess(compute_cam=True): activation + Weiszfeld focal + weighted rigid registration",
+               "views": V, "ms": round(ms, 4), "bound": "hbm", "achieved": round(nbytes / ms / 1e6, 1), "peak": 8000.0,
+               "unit": "GB/s", "frac": round(nbytes / ms / 1e6 / 8000.0, 4), "algorithmic_bytes": nbytes}
+
     alt = None
     if not args.no_alt and world == 1:
         alt = []
@@ -274,7 +299,7 @@ def main():
                                    f"(encode+update[2,1..]+render+activation)", "views_per_step": V * world, "keyframes": n_key,
                        "H": H, "W": W, "scenes_in_flight": len(lanes), "parallelism": "single" if world == 1 else f"view-sharded x{world} + all-gather(keyframe tokens) [{backend}]"},
             "roofline": roofline, "roofline_gemm": roofline_gemm, "cpu_baseline": cpu_baseline, "parity_vs_cpu_oracle": parity,
-            "kernel_classes": classes, "stages_ms": stages, "alt": alt,
+            "kernel_classes": classes, "stages_ms": stages, "alt": alt, "postprocess_cam": cam,
             "scene_tflop": round(flops / 1e12, 2) if flops else None,
             "end_to_end_mfma_frac": round(flops * args.steps / dt / 1e12 / PEAK_TFLOPS[args.precision], 4) if flops else None,
         }

@@ -122,6 +122,10 @@ int launch_fill_pos(int64_t* pos, int V, int gh, int gw, hipStream_t s, const ch
 // pointmaps [npix,7] fp32 -> pts3d [npix,3], pts3d_local [npix,3], conf [npix]
 int launch_postprocess(const float* pm, float* pts3d, float* pts3d_local, float* conf, size_t npix, hipStream_t s,
                        const char** err);
+// postprocess(compute_cam=True): activation + focal (Weiszfeld) + weighted rigid registration, cam.hip
+size_t cam_scratch_bytes(int n_views, int H, int W);
+int launch_postprocess_cam(const float* pm, int n_views, int H, int W, float* pts3d, float* pts3d_local, float* conf,
+                           float* focal, float* c2w, void* scratch, size_t scratch_bytes, hipStream_t s, const char** err);
 // 16-bit weight low part: lo = T(w - float(T(w)))  and hi = T(w), from fp32
 int launch_split16(DType dt, const float* in, void* hi, void* lo, size_t n, hipStream_t s, const char** err);
 

@@ -876,6 +876,22 @@ extern "C" int must3r_hip_postprocess(const float* pm, float* p3, float* pl, flo
     return 0;
 }
 
+extern "C" size_t must3r_hip_postprocess_cam_scratch_bytes(int n_views, int H, int W) {
+    if (n_views <= 0 || H <= 0 || W <= 0) return 0;
+    return cam_scratch_bytes(n_views, H, W);
+}
+
+extern "C" int must3r_hip_postprocess_cam(const float* pm, int n_views, int H, int W, float* p3, float* pl, float* cf,
+                                          float* focal, float* c2w, void* scratch, size_t scratch_bytes, void* stream) {
+    if (n_views < 0 || H <= 0 || W <= 0) return fail("postprocess_cam: bad shape");
+    if (n_views == 0) return 0;
+    if (!pm || !p3 || !pl || !cf || !focal || !c2w || !scratch) return fail("postprocess_cam: null argument");
+    const char* err = nullptr;
+    if (launch_postprocess_cam(pm, n_views, H, W, p3, pl, cf, focal, c2w, scratch, scratch_bytes,
+                               reinterpret_cast<hipStream_t>(stream), &err)) return fail("%s", err);
+    return 0;
+}
+
 extern "C" int must3r_hip_op_gemm(int dtype, int epi, const void* A, const void* W, const float* bias, void* out, int M, int N,
                                   int K, int lda, int ldc, const int64_t* pos, const float* rope_tab, int rope_cols,
                                   int rope_npos, const float* bias2, int row_start2, int accumulate, int ntok, int gw, int H,
@@ -940,6 +956,34 @@ extern "C" int must3r_hip_op_cast(int dtype, const float* in, void* out16, void*
 extern "C" int must3r_hip_debug_tr_probe(void* out256_i16_dev, void* stream) {
     if (!out256_i16_dev) return fail("tr_probe: null argument");
     if (launch_tr_probe(reinterpret_cast<short*>(out256_i16_dev), reinterpret_cast<hipStream_t>(stream))) return fail("tr_probe: launch failed");
+    return 0;
+}
+
+extern "C" int must3r_hip_cu_count(int device) {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return -1;
+    return prop.multiProcessorCount;
+}
+
+extern "C" int must3r_hip_stream_create(int device, int cu_first, int cu_count, void** out_stream) {
+    if (!out_stream) return fail("stream_create: null argument");
+    const int ncu = must3r_hip_cu_count(device);
+    if (ncu <= 0) return fail("stream_create: no such device");
+    if (cu_first < 0 || cu_count <= 0 || cu_first + cu_count > ncu) return fail("stream_create: CU range outside the device");
+    HIP_OK(hipSetDevice(device));
+    std::vector<uint32_t> mask((ncu + 31) / 32, 0u);
+    for (int i = cu_first; i < cu_first + cu_count; ++i) mask[i >> 5] |= 1u << (i & 31);
+    hipStream_t s = nullptr;
+    HIP_OK(hipExtStreamCreateWithCUMask(&s, (uint32_t)mask.size(), mask.data()));
+    *out_stream = s;
+    return 0;
+}
+
+extern "C" int must3r_hip_stream_destroy(int device, void* stream) {
+    if (!stream) return 0;
+    HIP_OK(hipSetDevice(device));
+    HIP_OK(hipStreamSynchronize(reinterpret_cast<hipStream_t>(stream)));
+    HIP_OK(hipStreamDestroy(reinterpret_cast<hipStream_t>(stream)));
     return 0;
 }
 

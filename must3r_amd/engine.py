@@ -15,10 +15,10 @@ from .model import ActivationType
 
 @torch.no_grad()
 def postprocess(pointmaps, pointmaps_activation=ActivationType.NORM_EXP, compute_cam=False):
-    """pointmaps [...,H,W,7] fp32 (cuda) -> dict(pts3d [...,3], pts3d_local [...,3], conf [...])."""
-    if compute_cam:
-        raise NotImplementedError("compute_cam (focal / pose estimation, engine/inference.py:29-47) is outside the "
-                                  "forward path (SURVEY.md section 8f, rank 1)")
+    """pointmaps [...,H,W,7] fp32 (cuda) -> dict(pts3d [...,3], pts3d_local [...,3], conf [...]) and, with
+    ``compute_cam`` (engine/inference.py:29-47), ``focal`` [...] and ``c2w`` [...,4,4]: Weiszfeld focal of
+    ``pts3d_local`` about the principal point (W/2, H/2) and the conf-1 weighted rigid registration
+    ``pts3d_local -> pts3d``, all in the same native call as the activation (``must3r_hip_postprocess_cam``)."""
     if isinstance(pointmaps_activation, str):
         pointmaps_activation = ActivationType(pointmaps_activation)
     if pointmaps_activation != ActivationType.NORM_EXP or pointmaps.shape[-1] != 7:
@@ -32,9 +32,27 @@ def postprocess(pointmaps, pointmaps_activation=ActivationType.NORM_EXP, compute
     pl = torch.empty((*lead, 3), dtype=torch.float32, device=pm.device)
     cf = torch.empty(lead, dtype=torch.float32, device=pm.device)
     lib = _lib.load()
-    _lib.check(lib.must3r_hip_postprocess(pm.data_ptr(), p3.data_ptr(), pl.data_ptr(), cf.data_ptr(), npix,
-                                          torch.cuda.current_stream(pm.device).cuda_stream))
-    return {"pts3d": p3, "pts3d_local": pl, "conf": cf}
+    stream = torch.cuda.current_stream(pm.device).cuda_stream
+    out = {"pts3d": p3, "pts3d_local": pl, "conf": cf}
+    if not compute_cam:
+        _lib.check(lib.must3r_hip_postprocess(pm.data_ptr(), p3.data_ptr(), pl.data_ptr(), cf.data_ptr(), npix, stream))
+        return out
+    if pm.dim() < 3:
+        raise ValueError("compute_cam needs pointmaps of shape [..., H, W, 7]")
+    batch_dims = tuple(pm.shape[:-3])
+    H, W = int(pm.shape[-3]), int(pm.shape[-2])
+    n = npix // (H * W) if H * W else 0
+    focal = torch.empty(batch_dims, dtype=torch.float32, device=pm.device)
+    c2w = torch.empty((*batch_dims, 4, 4), dtype=torch.float32, device=pm.device)
+    if n:
+        with torch.cuda.device(pm.device):
+            nbytes = lib.must3r_hip_postprocess_cam_scratch_bytes(n, H, W)
+            scratch = torch.empty(nbytes, dtype=torch.uint8, device=pm.device)
+            _lib.check(lib.must3r_hip_postprocess_cam(pm.data_ptr(), n, H, W, p3.data_ptr(), pl.data_ptr(), cf.data_ptr(),
+                                                      focal.data_ptr(), c2w.data_ptr(), scratch.data_ptr(), nbytes, stream))
+    out["focal"] = focal
+    out["c2w"] = c2w
+    return out
 
 
 def demo_mem_batches(n_views, init_num_images=2, batch_num_views=1):
@@ -58,15 +76,33 @@ def _side_stream(device):
     return _side_streams[key]
 
 
+def partitioned_stream(device, cu_first, cu_count):
+    """A HIP stream whose kernels only run on CUs [cu_first, cu_first + cu_count) (``must3r_hip_stream_create``),
+    wrapped for ``torch.cuda.stream``.  Cached per (device, range)."""
+    device = torch.device(device)
+    key = (device.type, device.index, int(cu_first), int(cu_count))
+    if key not in _side_streams:
+        import ctypes as C
+        lib = _lib.load()
+        h = C.c_void_p()
+        idx = device.index if device.index is not None else torch.cuda.current_device()
+        _lib.check(lib.must3r_hip_stream_create(idx, int(cu_first), int(cu_count), C.byref(h)))
+        _side_streams[key] = torch.cuda.ExternalStream(h.value, device=device)
+    return _side_streams[key]
+
+
 @torch.no_grad()
 def run_scene(encoder, decoder, imgs, true_shape, mem_batches=None, render_bs=None, activate=True, encoder_tokens=None,
-              overlap=True, enc_chunk=6):
+              overlap=True, enc_chunk=6, enc_cus=0, upd_cus=0):
     """One scene with a single aspect ratio.  imgs fp32 [V,3,H,W] (cuda), true_shape int64 [V,2].
 
     ``overlap``: the sequential memory update consists of small launches that leave most of the 256 CUs idle, while the
     encoder is made of chip-filling GEMMs and is independent per view.  So only the views of the first memory batch are
     encoded up front; the rest are encoded in chunks on a second HIP stream *while* the update of the earlier views
     runs, each decoder call waiting on the event of the chunk that holds its view.
+    ``enc_cus`` > 0 restricts that second stream to the LAST ``enc_cus`` CUs (``partitioned_stream``) so the encoder's
+    chip-filling blocks cannot queue in front of the update's small kernels; ``upd_cus`` > 0 additionally runs the
+    update on a stream restricted to the FIRST ``upd_cus`` CUs.
 
     Returns dict(update=[V,H,W,7], render=[V,H,W,7], mem=mem_tuple, x, pos[, pts3d, pts3d_local, conf of the render])."""
     V = imgs.shape[0]
@@ -83,7 +119,11 @@ def run_scene(encoder, decoder, imgs, true_shape, mem_batches=None, render_bs=No
     elif overlap and imgs.is_cuda and V > mem_batches[0] + 2:
         dev = imgs.device
         main = torch.cuda.current_stream(dev)
-        side = _side_stream(dev)
+        if enc_cus:
+            ncu = _lib.load().must3r_hip_cu_count(dev.index if dev.index is not None else torch.cuda.current_device())
+            side = partitioned_stream(dev, ncu - enc_cus, enc_cus)
+        else:
+            side = _side_stream(dev)
         n0 = mem_batches[0]
         x0, p0 = encoder(imgs[:n0], true_shape[:n0])
         xs, poss, ready = [x0], [p0], [None] * n0
@@ -118,16 +158,23 @@ def run_scene(encoder, decoder, imgs, true_shape, mem_batches=None, render_bs=No
     mem = None
     upd = []
     i = 0
-    for nb in mem_batches:
-        if ready is not None:
-            for ev in {ready[j] for j in range(i, i + nb)} - {None}:
-                torch.cuda.current_stream(imgs.device).wait_event(ev)
-        xi, pi = tokens(i, i + nb)
-        mem, pm = decoder(xi.unsqueeze(0), pi.unsqueeze(0), true_shape[i:i + nb].unsqueeze(0), mem)
-        upd.append(pm[0])
-        i += nb
+    import contextlib
+    upd_stream = partitioned_stream(imgs.device, 0, upd_cus) if (upd_cus and xs is not None) else None
+    if upd_stream is not None:
+        upd_stream.wait_stream(torch.cuda.current_stream(imgs.device))
+    with (torch.cuda.stream(upd_stream) if upd_stream is not None else contextlib.nullcontext()):
+        for nb in mem_batches:
+            if ready is not None:
+                for ev in {ready[j] for j in range(i, i + nb)} - {None}:
+                    torch.cuda.current_stream(imgs.device).wait_event(ev)
+            xi, pi = tokens(i, i + nb)
+            mem, pm = decoder(xi.unsqueeze(0), pi.unsqueeze(0), true_shape[i:i + nb].unsqueeze(0), mem)
+            upd.append(pm[0])
+            i += nb
+    if upd_stream is not None:
+        torch.cuda.current_stream(imgs.device).wait_stream(upd_stream)
     if xs is not None:
-        torch.cuda.current_stream(imgs.device).wait_stream(_side_stream(imgs.device))
+        torch.cuda.current_stream(imgs.device).wait_stream(side)
         x, pos = torch.cat(xs, 0), torch.cat(poss, 0)
     ren = []
     bs = render_bs or V

@@ -91,3 +91,29 @@ def make_images(n_views: int, H: int, W: int, seed: int = 0):
     imgs = torch.randn((n_views, 3, H, W), generator=g)
     true_shape = torch.tensor([[H, W]] * n_views, dtype=torch.int64)
     return imgs, true_shape
+
+
+def make_cam_pointmaps(*lead_hw, focal=40.0, noise=0.01, seed=None):
+    """Raw head outputs [..., H, W, 7] whose activation is a noisy pinhole scene: local points on rays of a camera with
+    the given focal, world points = a random rigid motion of them."""
+    if seed is not None:
+        torch.manual_seed(seed)
+    *lead, H, W = lead_hw
+    n = 1
+    for d in lead:
+        n *= d
+    ys, xs = torch.meshgrid(torch.arange(H, dtype=torch.float32), torch.arange(W, dtype=torch.float32), indexing="ij")
+    z = 1.0 + torch.rand(n, H, W)
+    local = torch.stack(((xs - W / 2) / focal * z, (ys - H / 2) / focal * z, z), dim=-1)
+    local = local + noise * torch.randn_like(local)
+    A = torch.randn(n, 3, 3)
+    Q, _ = torch.linalg.qr(A)
+    Q = Q * torch.sign(torch.det(Q)).view(n, 1, 1)
+    t = torch.randn(n, 1, 1, 3)
+    world = torch.einsum("nij,nhwj->nhwi", Q, local) + t + noise * torch.randn_like(local)
+
+    def inv_norm_exp(p):   # raw v with v/|v| * expm1(|v|) = p
+        d = p.norm(dim=-1, keepdim=True)
+        return p / d.clip(min=1e-8) * torch.log1p(d)
+    pm = torch.cat((inv_norm_exp(world), inv_norm_exp(local), torch.randn(n, H, W, 1)), dim=-1)
+    return pm.reshape(*lead, H, W, 7)

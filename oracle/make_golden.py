@@ -87,5 +87,23 @@ def main():
     print("tiny_mixed_ar ok, Nm", mem2[0][0].shape[1])
 
 
+def make_cam():
+    """postprocess(compute_cam=True) of the REAL reference (engine/inference.py:16-48, verbatim) on a synthetic pinhole
+    scene; its two third-party leaves are the restatements of oracle/cam_ref.py (un-vendored upstream)."""
+    ref_shims.install()
+    import must3r.engine.inference as E
+    pm = S.make_cam_pointmaps(2, 3, 40, 56, focal=45.0, noise=0.02, seed=11)
+    pm[0, 0, 5, 7, 3:6] = torch.tensor([0.3, -0.2, 0.0])     # z = 0 -> x/z = inf -> nan_to_num -> 0
+    with torch.no_grad():
+        o = E.postprocess(pm, compute_cam=True)
+    np.savez_compressed(os.path.join(OUT, "cam_40x56.npz"), pm=pm.numpy(), focal=o["focal"].numpy(), c2w=o["c2w"].numpy(),
+                        conf_sum=np.float64(o["conf"].double().sum().item()))
+    print("cam_40x56 focal", o["focal"].flatten().tolist())
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "cam":
+        make_cam()
+    else:
+        main()
+        make_cam()

@@ -202,8 +202,12 @@ def install(reference_root=REFERENCE_ROOT):
          invalid_to_nans=lambda *a, **k: (_ for _ in ()).throw(NotImplementedError()))
     _mod("dust3r.patch_embed", get_patch_embed=get_patch_embed, PatchEmbedDust3R=PatchEmbedDust3R,
          ManyAR_PatchEmbed=ManyAR_PatchEmbed)
-    _mod("dust3r.post_process",
-         estimate_focal_knowing_depth=lambda *a, **k: (_ for _ in ()).throw(NotImplementedError()))
+    try:
+        from . import cam_ref
+    except ImportError:  # imported as a top-level module (oracle/ on sys.path)
+        import cam_ref
+    # restated third-party leaves of postprocess(compute_cam=True) (engine/inference.py:13,7): see oracle/cam_ref.py
+    _mod("dust3r.post_process", estimate_focal_knowing_depth=cam_ref.estimate_focal_knowing_depth)
     _mod("croco")
     _mod("croco.models")
     _mod("croco.models.blocks", Mlp=Mlp, DropPath=DropPath, PositionGetter=PositionGetter)
@@ -216,7 +220,8 @@ def install(reference_root=REFERENCE_ROOT):
     try:
         import roma  # noqa: F401
     except Exception:
-        _mod("roma")
+        _mod("roma", rigid_points_registration=cam_ref.rigid_points_registration,
+             special_procrustes=cam_ref.special_procrustes)
     if reference_root not in sys.path:
         sys.path.insert(0, reference_root)
     sys.modules["must3r_ref_shims_installed"] = types.ModuleType("must3r_ref_shims_installed")

@@ -106,3 +106,44 @@ def test_postprocess_matches_formula():
     d = pm[..., :3].norm(dim=-1, keepdim=True)
     assert torch.allclose(o["pts3d"], pm[..., :3] / d * torch.expm1(d), atol=1e-6)
     assert torch.allclose(o["conf"], 1 + pm[..., 6].exp())
+
+
+def test_cam_oracle_known_answers():
+    """No golden vectors exist upstream for the two leaves; pin the restatement with analytic cases instead: an exact
+    pinhole scene returns its focal, an exact rigid motion is recovered (proper rotation, det +1)."""
+    from oracle import cam_ref
+    torch.manual_seed(0)
+    H, W, f = 24, 32, 37.5
+    ys, xs = torch.meshgrid(torch.arange(H, dtype=torch.float32), torch.arange(W, dtype=torch.float32), indexing="ij")
+    z = 1.0 + torch.rand(2, H, W)
+    local = torch.stack(((xs - W / 2) / f * z, (ys - H / 2) / f * z, z), dim=-1)
+    got = cam_ref.estimate_focal_knowing_depth(local, torch.tensor((W / 2, H / 2)))
+    assert torch.allclose(got, torch.full((2,), f), rtol=1e-4)
+    Q, _ = torch.linalg.qr(torch.randn(2, 3, 3))
+    Q = Q * torch.sign(torch.det(Q)).view(2, 1, 1)
+    t = torch.randn(2, 3)
+    x = local.reshape(2, -1, 3)
+    y = torch.einsum("nij,nkj->nki", Q, x) + t[:, None]
+    w = torch.rand(2, x.shape[1]) + 0.1
+    Rr, tr = cam_ref.rigid_points_registration(x, y, weights=w)
+    assert torch.allclose(Rr, Q, atol=2e-5) and torch.allclose(tr, t, atol=2e-4)
+    assert torch.allclose(torch.det(Rr), torch.ones(2), atol=1e-5)
+    # reflection case: the sign fix must still return a proper rotation
+    M = torch.diag(torch.tensor([1.0, 1.0, -1.0]))
+    assert torch.det(cam_ref.special_procrustes(M)) > 0
+
+
+def test_cam_oracle_matches_reference_fixture():
+    """tests/golden/cam_40x56.npz = the reference's own postprocess(compute_cam=True) (oracle/make_golden.py cam)."""
+    from oracle import cam_ref
+    g = load_golden("cam_40x56")
+    pm = torch.from_numpy(g["pm"])
+    act = R.postprocess(pm)
+    assert abs(act["conf"].double().sum().item() - float(g["conf_sum"])) < 1e-6 * float(g["conf_sum"])
+    o = cam_ref.compute_cam(act["pts3d"], act["pts3d_local"], act["conf"])
+    assert torch.allclose(o["focal"], torch.from_numpy(g["focal"]), rtol=1e-6)
+    assert torch.allclose(o["c2w"], torch.from_numpy(g["c2w"]), rtol=1e-5, atol=1e-6)
+    # the fp64 evaluation of the same formulas is the accuracy yardstick for the GPU path
+    o64 = cam_ref.compute_cam(act["pts3d"], act["pts3d_local"], act["conf"], dtype=torch.float64)
+    assert torch.allclose(o64["focal"].float(), o["focal"], rtol=1e-4)
+    assert torch.allclose(o64["c2w"].float(), o["c2w"], atol=1e-4)

@@ -30,3 +30,6 @@ def load_golden(name):
 #          envelope (+10% for the max-norm's sampling noise; measured 6-11e-3).
 TOL = {"fp16w2": 1.0e-3, "fp16": 2.0e-3, "bf16": 1.15e-2}
 PRECISIONS = ("fp16w2", "fp16", "bf16")
+
+
+from must3r_amd.synthetic import make_cam_pointmaps as cam_scene  # noqa: E402,F401
