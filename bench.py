@@ -61,7 +61,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-alt", action="store_true")
     ap.add_argument("--cpu-timeout", type=float, default=240.0)
-    ap.add_argument("--no-overlap", action="store_true", help="encode everything before the memory update (no 2nd stream)")
+    ap.add_argument("--overlap", action="store_true", help="encode views 2.. on a second stream under the memory update (was +3 %% with "
+                    "the 4-wave GEMMs; the 8-wave one-block-per-CU GEMM leaves no room for co-resident kernels: no gain)")
     ap.add_argument("--enc-cus", type=int, default=0, help="run the overlapped encoder on a stream restricted to this many CUs")
     ap.add_argument("--upd-cus", type=int, default=0, help="run the memory update on a stream restricted to this many CUs")
     ap.add_argument("--enc-chunk", type=int, default=6, help="views per encoder call on the second stream")
@@ -120,7 +121,7 @@ def main():
         e_, d_, st = lanes[step_no[0] % len(lanes)]
         step_no[0] += 1
         if st is None:
-            return run_scene(e_, d_, imgs, ts, overlap=not args.no_overlap, enc_cus=args.enc_cus, upd_cus=args.upd_cus,
+            return run_scene(e_, d_, imgs, ts, overlap=args.overlap, enc_cus=args.enc_cus, upd_cus=args.upd_cus,
                              enc_chunk=args.enc_chunk)
         st.wait_stream(torch.cuda.current_stream(device))
         with torch.cuda.stream(st):
@@ -173,8 +174,10 @@ def main():
     # symbol in every precision (profiles/r01_bench_kernel_stats.txt: 31-37 %); the GEMM template is spread over one
     # symbol per epilogue, so its two tile classes are reported next to it under "roofline_gemm".
     big = "Li128ELi64E" if args.precision == "fp16w2" else "Li128ELi128E"   # split weights use a 128x64(+64 lo) tile
-    kern = {"attn_kernel": (["attn_self", "attn_cross"], "attn_kernel"), "gemm_kernel<big tile>": (["gemm128"], big),
-            "gemm_kernel<64x64 ring>": (["gemm64"], "Li64ELi64E")}
+    # "big tile" = the chip-filling launches: gemm256_kernel (8 waves, 256-row tiles) where its rounds fill, else the 128-row tile
+    kern = {"attn_kernel": (["attn_self", "attn_cross"], ("attn_kernel",)),
+            "gemm_kernel<big tile>": (["gemm128"], ("gemm256_kernel", big)),
+            "gemm_kernel<64x64 ring>": (["gemm64"], ("Li64ELi64E",))}
     try:
         import glob
         pmc = json.load(open(sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))[-1]))["kernels"]
@@ -192,7 +195,7 @@ def main():
              "algorithmic_flops_per_launch": round(a["flops"] / max(1, a["calls"]) / 1e9, 3), "flops_unit": "GFLOP"}
         # HBM bytes per launch from the committed PMC passes of this same command (FETCH_SIZE / WRITE_SIZE cannot be read
         # from inside the process; scripts/gpu_pmc.sh + scripts/pmc_summary.py produce the file)
-        rows = [v for k, v in pmc.items() if sym in k and want in k]
+        rows = [v for k, v in pmc.items() if any(t in k for t in sym) and want in k]
         if rows:
             n = sum(x["launches"] for x in rows)
             r["traffic"] = int(sum(x["hbm_bytes_per_launch_corrected"] * x["launches"] for x in rows) / max(1, n))

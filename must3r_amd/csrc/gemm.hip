@@ -19,6 +19,88 @@
 
 namespace m3r {
 
+// One output row segment of a lane: v[j][r] = C[m][n = nw0 + j*16 + fg*4 + r] before bias; nw0 = first column of the wave tile.
+// Shared by every tile geometry so that all of them round identically (built with -ffp-contract=off).
+template <class T, int EPI, int NF>
+__device__ __forceinline__ void epilogue_row(const GemmArgs& p, void* const outp, const float* __restrict__ bias, const int m,
+                                             const int nw0, const int fg, f32x4 (&v)[NF]) {
+    typedef typename Vec<T>::v4 v4;
+    const int nb = nw0 + fg * 4;
+#pragma unroll
+    for (int j = 0; j < NF; ++j) {
+        const bool nobias = (EPI == EPI_F32 || EPI == EPI_HEAD) && p.accumulate;
+        if (bias != nullptr && !nobias) {
+            const f32x4 b = *reinterpret_cast<const f32x4*>(bias + nb + j * 16);
+            v[j] += b;
+        }
+    }
+    if constexpr (EPI == EPI_QKV_ROPE) {
+        // wave tile is 32- or 64-column aligned inside a 64-wide head: fragments (2q, 2q+1) are the
+        // rotate-half pair of one 32-wide half; even halves rotate by y, odd halves by x.
+        if (nw0 < p.rope_cols) {
+            const long long py = p.pos[(size_t)m * 2 + 0];
+            const long long px = p.pos[(size_t)m * 2 + 1];
+#pragma unroll
+            for (int q = 0; q < NF / 2; ++q) {
+                const int nh = nw0 + q * 32;
+                int pp = (int)(((nh >> 5) & 1) ? px : py);
+                pp = pp < 0 ? 0 : (pp >= p.rope_npos ? p.rope_npos - 1 : pp);
+                const float* tb = p.rope_tab + ((size_t)pp * 16 + fg * 4) * 2;
+                const f32x4 t0 = *reinterpret_cast<const f32x4*>(tb);      // cos0 sin0 cos1 sin1
+                const f32x4 t1 = *reinterpret_cast<const f32x4*>(tb + 4);  // cos2 sin2 cos3 sin3
+                const float cs[4] = {t0[0], t0[2], t1[0], t1[2]};
+                const float sn[4] = {t0[1], t0[3], t1[1], t1[3]};
+                const f32x4 x0 = v[2 * q], x1 = v[2 * q + 1];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    v[2 * q][r] = x0[r] * cs[r] - x1[r] * sn[r];
+                    v[2 * q + 1][r] = x1[r] * cs[r] + x0[r] * sn[r];
+                }
+            }
+        }
+    }
+    if constexpr (EPI == EPI_STORE16 || EPI == EPI_QKV_ROPE) {
+        if (p.out_scale != 0.f && nw0 < p.scale_cols) {   // scale_cols is a multiple of 64: wave-uniform
+#pragma unroll
+            for (int j = 0; j < NF; ++j) v[j] *= p.out_scale;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < NF; ++j) {
+        const int n = nb + j * 16;
+        if constexpr (EPI == EPI_STORE16 || EPI == EPI_QKV_ROPE) {
+            *reinterpret_cast<v4*>(reinterpret_cast<T*>(outp) + (size_t)m * p.ldc + n) = cvt4<T>(v[j]);
+        } else if constexpr (EPI == EPI_STORE16_GELU) {
+            f32x4 g;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) g[r] = gelu_erf(v[j][r]);
+            *reinterpret_cast<v4*>(reinterpret_cast<T*>(outp) + (size_t)m * p.ldc + n) = cvt4<T>(g);
+        } else if constexpr (EPI == EPI_RESID_F32) {
+            f32x4* o = reinterpret_cast<f32x4*>(reinterpret_cast<float*>(outp) + (size_t)m * p.ldc + n);
+            *o = *o + v[j];
+        } else if constexpr (EPI == EPI_F32) {
+            f32x4* o = reinterpret_cast<f32x4*>(reinterpret_cast<float*>(outp) + (size_t)m * p.ldc + n);
+            f32x4 x = v[j];
+            if (p.accumulate) {
+                x += *o;
+            } else if (p.bias2 != nullptr && m >= p.row_start2) {
+                x += *reinterpret_cast<const f32x4*>(p.bias2 + n);
+            }
+            *o = x;
+        } else if constexpr (EPI == EPI_HEAD) {
+            // permuted feature n = (i*16 + jj)*7 + c ; token t of view vv at grid (gy, gx)
+            const int vv = m / p.ntok, t = m - vv * p.ntok;
+            const int gy = t / p.gw, gx = t - gy * p.gw;
+            const int pi = n / 112, rem = n - pi * 112;
+            const size_t off = ((size_t)(vv * p.H + gy * 16 + pi) * p.Wimg + gx * 16) * 7 + rem;
+            f32x4* o = reinterpret_cast<f32x4*>(reinterpret_cast<float*>(outp) + off);
+            f32x4 x = v[j];
+            if (p.accumulate) x += *o;
+            *o = x;
+        }
+    }
+}
+
 // WS = 2: split-weight mode, W is [N, 2K] = [W_hi | W_lo]; every K-tile stages the activation tile once plus BOTH weight
 // tiles, and each activation fragment feeds two MFMAs (acc += W_hi.a ; acc += W_lo.a).
 template <class T, int BM, int BN, int WGM, int WGN, int EPI, int NST, int WS, int BK>
@@ -177,86 +259,14 @@ __global__ void __launch_bounds__(64 * WGM * WGN) gemm_kernel(const GemmArgs p) 
     }
 
     // ---- epilogue: acc[i][j][r] = C[m = m0 + wm*WM + i*16 + fr][n = n0 + wn*WN + j*16 + fg*4 + r]
-    const int nb = n0 + wn * WN + fg * 4;
 #pragma unroll
     for (int i = 0; i < MF; ++i) {
         const int m = m0 + wm * WM + i * 16 + fr;
         if (m >= p.M) continue;
         f32x4 v[NF];
 #pragma unroll
-        for (int j = 0; j < NF; ++j) {
-            v[j] = acc[i][j];
-            const bool nobias = (EPI == EPI_F32 || EPI == EPI_HEAD) && p.accumulate;
-            if (bias != nullptr && !nobias) {
-                const f32x4 b = *reinterpret_cast<const f32x4*>(bias + nb + j * 16);
-                v[j] += b;
-            }
-        }
-        if constexpr (EPI == EPI_QKV_ROPE) {
-            // wave tile is 32- or 64-column aligned inside a 64-wide head: fragments (2q, 2q+1) are the
-            // rotate-half pair of one 32-wide half; even halves rotate by y, odd halves by x.
-            if (n0 + wn * WN < p.rope_cols) {
-                const long long py = p.pos[(size_t)m * 2 + 0];
-                const long long px = p.pos[(size_t)m * 2 + 1];
-#pragma unroll
-                for (int q = 0; q < NF / 2; ++q) {
-                    const int nh = n0 + wn * WN + q * 32;
-                    int pp = (int)(((nh >> 5) & 1) ? px : py);
-                    pp = pp < 0 ? 0 : (pp >= p.rope_npos ? p.rope_npos - 1 : pp);
-                    const float* tb = p.rope_tab + ((size_t)pp * 16 + fg * 4) * 2;
-                    const f32x4 t0 = *reinterpret_cast<const f32x4*>(tb);      // cos0 sin0 cos1 sin1
-                    const f32x4 t1 = *reinterpret_cast<const f32x4*>(tb + 4);  // cos2 sin2 cos3 sin3
-                    const float cs[4] = {t0[0], t0[2], t1[0], t1[2]};
-                    const float sn[4] = {t0[1], t0[3], t1[1], t1[3]};
-                    const f32x4 x0 = v[2 * q], x1 = v[2 * q + 1];
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        v[2 * q][r] = x0[r] * cs[r] - x1[r] * sn[r];
-                        v[2 * q + 1][r] = x1[r] * cs[r] + x0[r] * sn[r];
-                    }
-                }
-            }
-        }
-        if constexpr (EPI == EPI_STORE16 || EPI == EPI_QKV_ROPE) {
-            if (p.out_scale != 0.f && n0 + wn * WN < p.scale_cols) {   // scale_cols is a multiple of 64: wave-uniform
-#pragma unroll
-                for (int j = 0; j < NF; ++j) v[j] *= p.out_scale;
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < NF; ++j) {
-            const int n = nb + j * 16;
-            if constexpr (EPI == EPI_STORE16 || EPI == EPI_QKV_ROPE) {
-                *reinterpret_cast<v4*>(reinterpret_cast<T*>(outp) + (size_t)m * p.ldc + n) = cvt4<T>(v[j]);
-            } else if constexpr (EPI == EPI_STORE16_GELU) {
-                f32x4 g;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) g[r] = gelu_erf(v[j][r]);
-                *reinterpret_cast<v4*>(reinterpret_cast<T*>(outp) + (size_t)m * p.ldc + n) = cvt4<T>(g);
-            } else if constexpr (EPI == EPI_RESID_F32) {
-                f32x4* o = reinterpret_cast<f32x4*>(reinterpret_cast<float*>(outp) + (size_t)m * p.ldc + n);
-                *o = *o + v[j];
-            } else if constexpr (EPI == EPI_F32) {
-                f32x4* o = reinterpret_cast<f32x4*>(reinterpret_cast<float*>(outp) + (size_t)m * p.ldc + n);
-                f32x4 x = v[j];
-                if (p.accumulate) {
-                    x += *o;
-                } else if (p.bias2 != nullptr && m >= p.row_start2) {
-                    x += *reinterpret_cast<const f32x4*>(p.bias2 + n);
-                }
-                *o = x;
-            } else if constexpr (EPI == EPI_HEAD) {
-                // permuted feature n = (i*16 + jj)*7 + c ; token t of view vv at grid (gy, gx)
-                const int vv = m / p.ntok, t = m - vv * p.ntok;
-                const int gy = t / p.gw, gx = t - gy * p.gw;
-                const int pi = n / 112, rem = n - pi * 112;
-                const size_t off = ((size_t)(vv * p.H + gy * 16 + pi) * p.Wimg + gx * 16) * 7 + rem;
-                f32x4* o = reinterpret_cast<f32x4*>(reinterpret_cast<float*>(outp) + off);
-                f32x4 x = v[j];
-                if (p.accumulate) x += *o;
-                *o = x;
-            }
-        }
+        for (int j = 0; j < NF; ++j) v[j] = acc[i][j];
+        epilogue_row<T, EPI, NF>(p, outp, bias, m, n0 + wn * WN, fg, v);
     }
 }
 
@@ -272,6 +282,187 @@ static int launch_cfg(const GemmArgs& a, hipStream_t s) {
     }
     hipLaunchKernelGGL((gemm_kernel<T, BM, BN, WGM, WGN, EPI, NST, WS, BK>), dim3(nbm * nbn, a.batch > 1 ? a.batch : 1),
                        dim3(64 * WGM * WGN), lds, s, a);
+    return hipGetLastError() == hipSuccess ? 0 : 1;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// 8-wave, one-block-per-CU GEMM for chip-filling launches: 256 x 256 tile (plain weights) / 256 x 128 hi+lo (split),
+// K-tile 32, 4-stage LDS ring (128 KB), two wave groups staggered by one barrier.
+//
+// Waves 0-3 (group 0, rows 0-127 of the tile) and 4-7 (group 1, rows 128-255) share the 4 SIMDs pairwise.  Every K-tile
+// costs a wave two block barriers: [wait DMA] B [12 ds_read_b128 + issue the DMA of tile t+3] [lgkmcnt 0] B [32 MFMA].
+// Group 1 runs exactly one barrier behind group 0, so in every barrier interval one wave of each SIMD streams its 32
+// MFMAs (s_setprio 1) while its partner does the LDS reads and DMA issue for its next tile: the matrix pipe sees
+// back-to-back MFMAs instead of the read->multiply serialisation of the 4-wave kernels above.
+//   RAW  every wave waits (counted vmcnt, 2 younger tiles stay in flight) for ITS pieces of tile t before global
+//        barrier #2t; group 0 reads the tile after #2t, group 1 after #2t+1.
+//   WAR  tile t+3 lands in the buffer of tile t-1.  Both groups retire their ds_reads (lgkmcnt 0) BEFORE the barrier
+//        that ends their read interval, so after #2t nobody has a read of tile t-1 in flight; group 0 issues the DMA
+//        in (#2t, #2t+1), group 1 in (#2t+1, #2t+2).
+// The accumulation order per output (k ascending, hi before lo inside each 32-deep step) is the same as in gemm_kernel,
+// so the two kernels produce identical bits.
+template <class T, int EPI, int WS, int BN>
+__global__ void __launch_bounds__(512) gemm256_kernel(const GemmArgs p) {
+    typedef typename Vec<T>::v8 v8;
+    constexpr int BM = 256, BK = 32;
+    constexpr int WR = WS * BN;                // rows of the staged weight region: [hi BN rows | lo BN rows] when split
+    constexpr int NST = WR == 512 ? 3 : 4;     // 48 KB stages x 3 (split, BN 256) or 32 KB stages x 4
+    constexpr int WN = BN / 4;                 // wave tile: 128 (m) x WN (n)
+    constexpr int MF = 8, NF = WN / 16;        // 16x16 fragments per wave tile
+    constexpr int PW = WR / 128;               // weight DMA instructions per wave and K-tile (A: 2)
+    constexpr int IPT = 2 + PW;
+    constexpr int STAGE = (BM + WR) * BK;      // elements per stage: A [256][32] then W [WR][32]
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    T* const lds = reinterpret_cast<T*>(smem);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+
+    const int nbn = p.N / BN;
+    const int nbm = (p.M + BM - 1) / BM;
+    const int nwg = nbm * nbn;
+    int bid = blockIdx.x;
+    {
+        const int xcd = bid & 7, slot = bid >> 3;
+        const int q = nwg >> 3, r = nwg & 7;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+    }
+    constexpr int GM = 4;                      // grouped order: 4 row-blocks x all column-blocks per group
+    const int tpg = GM * nbn;
+    const int gidx = bid / tpg;
+    const int gfirst = gidx * GM;
+    const int gsz = (nbm - gfirst < GM) ? nbm - gfirst : GM;
+    const int gin = bid - gidx * tpg;
+    const int m0 = (gfirst + gin % gsz) * BM;
+    const int n0 = (gin / gsz) * BN;
+
+    const int grp = blockIdx.y;
+    const T* __restrict__ A = reinterpret_cast<const T*>(p.A) + (size_t)grp * p.strideA;
+    const T* __restrict__ W = reinterpret_cast<const T*>(p.W) + (size_t)grp * p.strideW;
+    const float* __restrict__ bias = p.bias ? p.bias + (size_t)grp * p.strideB : nullptr;
+    void* const outp = p.out_table ? p.out_table[grp] : p.out;
+
+    // ---- staging: one wave instruction moves 16 rows x 64 B; per K-tile a wave issues 2 (A) + 2 (W) instructions
+    const int srow = lane >> 2, pch = lane & 3;
+    const T* a_src[2];
+    const T* w_src[PW];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int r = (wave * 2 + t) * 16 + srow;            // 0..255
+        int gr = m0 + r;
+        gr = gr < p.M ? gr : p.M - 1;
+        a_src[t] = A + (size_t)gr * p.lda + swz32(r, pch) * 8;
+    }
+#pragma unroll
+    for (int t = 0; t < PW; ++t) {
+        // weight region row r: rows [0, BN) = (hi) weight rows n0 .. n0 + BN, rows [BN, 2 BN) = their lo halves
+        const int r = (wave * PW + t) * 16 + srow;           // 0..WR-1
+        const int part = r / BN, wrow = r - part * BN;
+        w_src[t] = W + (size_t)(n0 + wrow) * (size_t)(p.K * WS) + (size_t)part * p.K + swz32(r, pch) * 8;
+    }
+    auto stage = [&](int kt, int buf) {
+        T* base = lds + buf * STAGE;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) glds16(a_src[t] + kt * BK, base + (wave * 2 + t) * 16 * BK);
+#pragma unroll
+        for (int t = 0; t < PW; ++t) glds16(w_src[t] + kt * BK, base + BM * BK + (wave * PW + t) * 16 * BK);
+    };
+
+    f32x4 acc[MF][NF];
+#pragma unroll
+    for (int i = 0; i < MF; ++i)
+#pragma unroll
+        for (int j = 0; j < NF; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int fr = lane & 15, fg = lane >> 4;
+    const int nk = p.K / BK;
+    // LDS element offsets of this lane's fragments inside a stage
+    int a_off[MF], w_off[WS][NF];
+#pragma unroll
+    for (int i = 0; i < MF; ++i) {
+        const int r = wr * 128 + i * 16 + fr;
+        a_off[i] = r * BK + swz32(r, fg) * 8;
+    }
+#pragma unroll
+    for (int part = 0; part < WS; ++part)
+#pragma unroll
+        for (int j = 0; j < NF; ++j) {
+            const int r = part * BN + wc * WN + j * 16 + fr;
+            w_off[part][j] = BM * BK + r * BK + swz32(r, fg) * 8;
+        }
+
+    // wait until this wave's DMA pieces of tile u have landed: at most min(NST-2, nk-1-u) younger tiles (IPT loads each) pending
+    auto wait_tile = [&](int u) {
+        const int younger = nk - 1 - u;
+        if (NST >= 4 && younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * IPT) : "memory");
+        else if (younger >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(IPT) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    };
+
+#pragma unroll
+    for (int t = 0; t < NST - 1; ++t)
+        if (t < nk) stage(t, t);
+    if (wr == 1) {
+        wait_tile(0);
+        __builtin_amdgcn_s_barrier();
+    }
+    int buf = 0;
+    for (int t = 0; t < nk; ++t) {
+        if (wr == 0) wait_tile(t);
+        __builtin_amdgcn_s_barrier();
+        // ---- read interval
+        const T* base = lds + buf * STAGE;
+        v8 af[MF], wf[WS][NF];
+#pragma unroll
+        for (int part = 0; part < WS; ++part)
+#pragma unroll
+            for (int j = 0; j < NF; ++j) wf[part][j] = *reinterpret_cast<const v8*>(base + w_off[part][j]);
+#pragma unroll
+        for (int i = 0; i < MF; ++i) af[i] = *reinterpret_cast<const v8*>(base + a_off[i]);
+        if (t + NST - 1 < nk) {
+            int nb = buf + NST - 1;
+            nb = nb >= NST ? nb - NST : nb;
+            stage(t + NST - 1, nb);
+        }
+        if (wr == 1 && t + 1 < nk) wait_tile(t + 1);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        // ---- multiply interval
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int part = 0; part < WS; ++part)
+#pragma unroll
+            for (int i = 0; i < MF; ++i)
+#pragma unroll
+                for (int j = 0; j < NF; ++j) acc[i][j] = mfma16(wf[part][j], af[i], acc[i][j]);
+        __builtin_amdgcn_s_setprio(0);
+        buf = buf + 1 == NST ? 0 : buf + 1;
+    }
+    if (wr == 0) __builtin_amdgcn_s_barrier();
+
+#pragma unroll
+    for (int i = 0; i < MF; ++i) {
+        const int m = m0 + wr * 128 + i * 16 + fr;
+        if (m >= p.M) continue;
+        f32x4 v[NF];
+#pragma unroll
+        for (int j = 0; j < NF; ++j) v[j] = acc[i][j];
+        epilogue_row<T, EPI, NF>(p, outp, bias, m, n0 + wc * WN, fg, v);
+    }
+}
+
+template <class T, int EPI, int WS, int BN>
+static int launch_256(const GemmArgs& a, hipStream_t s) {
+    const int nbn = a.N / BN, nbm = (a.M + 255) / 256;
+    const size_t lds = (size_t)(WS * BN == 512 ? 3 : 4) * (256 + WS * BN) * 32 * sizeof(T);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256_kernel<T, EPI, WS, BN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((gemm256_kernel<T, EPI, WS, BN>), dim3(nbm * nbn, a.batch > 1 ? a.batch : 1), dim3(512), lds, s, a);
     return hipGetLastError() == hipSuccess ? 0 : 1;
 }
 
@@ -291,14 +482,56 @@ static long min_big(bool split) {
     return v[split];
 }
 
+// Launches of at most one 64 x 64 tile per CU run it with 8 waves (4 x 2, wave tile 16 x 32) instead of 4: the L2 -> LDS
+// operand supply of a CU grows with the number of waves issuing loads (scripts/probes/dma_rate.hip: 15 / 30 / 44 B/clk/CU
+// for 4 / 8 / 16 waves) and these launches are supply-bound (43 flop/B tiles): proj 8.7 -> 7.9 us, fc2 23.4 -> 21.8 us at
+// M = 768 with split weights; with two blocks per CU (qkv, fc1) the 4-wave form is as fast or faster.
+static bool small8(long tiles64) { return tiles64 <= 256; }
+
+// M3R_GEMM256: 0 = never use the 8-wave kernel, 1 = by the fill rule below (default), 2 = whenever the shape allows it
+static int gemm256_mode() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("M3R_GEMM256");
+        v = e ? atoi(e) : 1;
+    }
+    return v;
+}
+// the 8-wave kernel holds one block per CU: use it when its rounds over the 256 CUs are reasonably full
+static int fill256(long tiles) {   // percentage of the CU slots of its rounds that do work
+    const long rounds = (tiles + 255) / 256;
+    return (int)(tiles * 100 / (rounds * 256));
+}
+static int g256_bn_override() {    // experiments: M3R_G256_BN = 128 / 256 forces the split-mode tile width
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("M3R_G256_BN");
+        v = e ? atoi(e) : 0;
+    }
+    return v;
+}
+
 template <class T, int EPI>
 static int launch_epi(const GemmArgs& a, hipStream_t s, const char** err) {
     const long nb = a.batch > 1 ? a.batch : 1;
+    const int mode = gemm256_mode();
+    const long rb256 = (long)((a.M + 255) / 256) * nb;
     int rc;
     if (a.wsplit == 2) {
         if constexpr (sizeof(T) == 2 && std::is_same<T, f16_t>::value) {
             const long tiles = (long)((a.M + 127) / 128) * (a.N / 64) * nb;
-            if (tiles >= min_big(true)) rc = launch_cfg<T, 128, 64, 2, 2, EPI, 2, 2>(a, s);
+            const long t256 = rb256 * (a.N / 256), t128 = rb256 * (a.N / 128);
+            const bool ok256 = a.N % 256 == 0 && a.K % 32 == 0, ok128 = a.N % 128 == 0 && a.K % 32 == 0;
+            int pick = 0;
+            if (mode == 2) pick = (g256_bn_override() == 128 || !ok256) ? (ok128 ? 128 : 0) : 256;
+            else if (mode == 1) {
+                if (ok256 && t256 >= 200 && fill256(t256) >= 80) pick = 256;
+                else if (ok128 && t128 >= 200 && fill256(t128) >= 80) pick = 128;
+            }
+            if (pick == 256) rc = launch_256<T, EPI, 2, 256>(a, s);
+            else if (pick == 128) rc = launch_256<T, EPI, 2, 128>(a, s);
+            else if (tiles >= min_big(true)) rc = launch_cfg<T, 128, 64, 2, 2, EPI, 2, 2>(a, s);
+            else if (small8((long)((a.M + 63) / 64) * (a.N / 64) * nb)) rc = launch_cfg<T, 64, 64, 4, 2, EPI, 3, 2>(a, s);
             else rc = launch_cfg<T, 64, 64, 2, 2, EPI, 3, 2>(a, s);
         } else {
             *err = "gemm: split weights are only built for fp16";
@@ -307,7 +540,11 @@ static int launch_epi(const GemmArgs& a, hipStream_t s, const char** err) {
     } else {
         const bool n128 = (a.N % 128) == 0;
         const long tiles128 = (long)((a.M + 127) / 128) * (a.N / 128) * nb;
-        if (n128 && tiles128 >= min_big(false)) rc = launch_cfg<T, 128, 128, 2, 2, EPI, 2, 1>(a, s);
+        const long t256 = rb256 * (a.N / 256);
+        const bool ok256 = a.N % 256 == 0 && a.K % 32 == 0;
+        if (ok256 && (mode == 2 || (mode == 1 && t256 >= 200 && fill256(t256) >= 80))) rc = launch_256<T, EPI, 1, 256>(a, s);
+        else if (n128 && tiles128 >= min_big(false)) rc = launch_cfg<T, 128, 128, 2, 2, EPI, 2, 1>(a, s);
+        else if (small8((long)((a.M + 63) / 64) * (a.N / 64) * nb)) rc = launch_cfg<T, 64, 64, 4, 2, EPI, 4, 1>(a, s);
         else rc = launch_cfg<T, 64, 64, 2, 2, EPI, 4, 1>(a, s);
     }
     if (rc) *err = "gemm: kernel launch failed";

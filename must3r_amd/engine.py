@@ -93,16 +93,15 @@ def partitioned_stream(device, cu_first, cu_count):
 
 @torch.no_grad()
 def run_scene(encoder, decoder, imgs, true_shape, mem_batches=None, render_bs=None, activate=True, encoder_tokens=None,
-              overlap=True, enc_chunk=6, enc_cus=0, upd_cus=0):
+              overlap=False, enc_chunk=6, enc_cus=0, upd_cus=0):
     """One scene with a single aspect ratio.  imgs fp32 [V,3,H,W] (cuda), true_shape int64 [V,2].
 
-    ``overlap``: the sequential memory update consists of small launches that leave most of the 256 CUs idle, while the
-    encoder is made of chip-filling GEMMs and is independent per view.  So only the views of the first memory batch are
-    encoded up front; the rest are encoded in chunks on a second HIP stream *while* the update of the earlier views
-    runs, each decoder call waiting on the event of the chunk that holds its view.
-    ``enc_cus`` > 0 restricts that second stream to the LAST ``enc_cus`` CUs (``partitioned_stream``) so the encoder's
-    chip-filling blocks cannot queue in front of the update's small kernels; ``upd_cus`` > 0 additionally runs the
-    update on a stream restricted to the FIRST ``upd_cus`` CUs.
+    ``overlap`` (off by default): only the views of the first memory batch are encoded up front, the rest in chunks on a
+    second HIP stream *while* the memory update of the earlier views runs, each decoder call waiting on the event of the
+    chunk that holds its view.  Worth +3 % with the 4-wave GEMM kernels; the 8-wave one-block-per-CU GEMM the batched
+    encoder now uses leaves no room for co-resident kernels, and chunking costs it its fill: no gain.
+    ``enc_cus`` / ``upd_cus`` > 0 put the second stream / the update on CU-partitioned streams (``partitioned_stream``);
+    measured and rejected, kept for the record.
 
     Returns dict(update=[V,H,W,7], render=[V,H,W,7], mem=mem_tuple, x, pos[, pts3d, pts3d_local, conf of the render])."""
     V = imgs.shape[0]

@@ -41,10 +41,15 @@ def main():
         return (time.perf_counter() - t0) / steps * 1e3, out["render"].clone()
 
     configs = [dict(overlap=False), dict(overlap=True)]
-    for chunk in (6, 9, 18):
+    if os.environ.get("EXP") == "chunks":      # encoder chunking on the second stream only (no CU masks)
+        configs += [dict(overlap=True, enc_chunk=c) for c in (3, 9, 18)]
+        masks = []
+    else:
+        masks = (6, 9, 18)
+    for chunk in masks:
         for enc_cus in (64, 96, 128, 160, 192):
             configs.append(dict(overlap=True, enc_cus=enc_cus, enc_chunk=chunk))
-    for enc_cus, upd_cus in ((128, 128), (96, 160), (160, 96), (64, 192), (128, 256), (192, 64)):
+    for enc_cus, upd_cus in (((128, 128), (96, 160), (160, 96), (64, 192), (128, 256), (192, 64)) if masks else ()):
         configs.append(dict(overlap=True, enc_cus=enc_cus, upd_cus=upd_cus, enc_chunk=6))
     ref = None
     for kw in configs:
