@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MUST3R_HIP_ABI_VERSION 1
+#define MUST3R_HIP_ABI_VERSION 2
 
 typedef struct must3r_hip_ctx must3r_hip_ctx;
 
@@ -94,6 +94,10 @@ typedef struct must3r_hip_decode_args {
      * Rows [0,n_mem) are read; unless render, rows [n_mem, n_mem + sum(n_views*n_tokens)) are WRITTEN
      * (the caller guarantees capacity) -- the in-place form of torch.concatenate at decoder.py:239/330. */
     void* const* mem;
+    /* optional (`return_feats=True`, decoder.py:344-347 / :258-262): fp32 [dec_depth][R][dec_dim], R = sum(n_views*n_tokens)
+     * in group order; entry l = the residual stream after decoder block l, the last one after norm_dec (decoder.py:150).
+     * NULL = not wanted.  (feats[0] of the reference, the encoder tokens, is the caller's own input.) */
+    float* feats;
 } must3r_hip_decode_args;
 
 /* MUSt3R.forward / forward_list (decoder.py:158-350), batch B = 1. */

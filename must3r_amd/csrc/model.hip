@@ -810,6 +810,8 @@ extern "C" int must3r_hip_decode(must3r_hip_ctx* c, const must3r_hip_decode_args
         M3R_OK(gemm(c, dt, EPI_STORE16_GELU, gargs(h16, w, p32(c, b + ".mlp.fc1.bias"), g16, R, F, D, D, F), s));
         M3R_OK(w16(c, b + ".mlp.fc2.weight", dt, &w, s));
         M3R_OK(gemm(c, dt, EPI_RESID_F32, gargs(g16, w, p32(c, b + ".mlp.fc2.bias"), x, R, D, F, F, D), s));
+        if (A->feats && l < L - 1)   // return_feats: the residual stream after block l (decoder.py:321)
+            HIP_OK(hipMemcpyAsync(A->feats + (size_t)l * R * D, x, (size_t)R * D * sizeof(float), hipMemcpyDeviceToDevice, s));
     }
 
     if (update) {
@@ -846,7 +848,8 @@ extern "C" int must3r_hip_decode(must3r_hip_ctx* c, const must3r_hip_decode_args
 
     // --- prediction head in split precision (fp32-equivalent; decoder.py:149-156 runs it in fp32):
     //     y = LN(x); out = y_hi W_hi + y_lo W_hi + y_hi W_lo + b, pixel-shuffled to [n,H,W,7]
-    M3R_OK(layernorm(c, dt, x, nullptr, p32(c, "decoder.norm_dec.weight"), p32(c, "decoder.norm_dec.bias"), h16, hlo, nullptr, nullptr,
+    M3R_OK(layernorm(c, dt, x, nullptr, p32(c, "decoder.norm_dec.weight"), p32(c, "decoder.norm_dec.bias"), h16, hlo,
+                     A->feats ? A->feats + (size_t)(L - 1) * R * D : nullptr, nullptr,
                      R, D, 1e-6f, s));
     const void *whi, *wlo;
     M3R_OK(p16(c, "decoder.head_dec.proj_ps.weight", dt, true, &whi, &wlo, s));

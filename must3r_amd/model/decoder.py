@@ -149,10 +149,12 @@ class MUSt3R(HipModule):
     @torch.no_grad()
     def forward(self, x, pos, true_shape, current_mem=None, render=False, return_feats=False):
         is_list = isinstance(x, (list, tuple))
-        if return_feats and not is_list:
-            # intermediate features are never materialised by the fused native path (inference callers do not ask:
-            # engine/inference.py:190; the reference's list path silently ignores the flag, decoder.py:270)
-            raise NotImplementedError("return_feats=True is not available on the HIP path")
+        if is_list:
+            return_feats = False   # the reference's list dispatch drops the flag (decoder.py:270); forward_list honours it
+        return self._forward(x, pos, true_shape, current_mem, render, return_feats)
+
+    def _forward(self, x, pos, true_shape, current_mem, render, return_feats):
+        is_list = isinstance(x, (list, tuple))
         xs = list(x) if is_list else [x]
         poss = list(pos) if is_list else [pos]
         shapes = list(true_shape) if is_list else [true_shape]
@@ -210,8 +212,11 @@ class MUSt3R(HipModule):
             owner = self._writable_memory(mem_vals, Nm, R, tdt, device)
             ptrs = (C.c_void_p * self.depth)(*[b.data_ptr() for b in owner.bufs])
 
+        # return_feats (decoder.py:344-347): [encoder tokens, residual stream after blocks 0..depth-2, norm_dec(last)] -- fp32
+        # here (the residual stream is fp32 on this path, bf16 in the reference under autocast)
+        feats_buf = torch.empty((self.depth, R, D), dtype=torch.float32, device=device) if return_feats else None
         args = _lib.DecodeArgs(odt, _MEM_MODE[self.memory_mode], 1 if render else 0, 1 if current_mem is None else 0,
-                               len(xs), groups, Nm, ptrs)
+                               len(xs), groups, Nm, ptrs, feats_buf.data_ptr() if return_feats else None)
         _lib.check(ctx.lib.must3r_hip_decode(ctx.handle, C.byref(args), self._stream(dev)))
 
         if render:
@@ -227,10 +232,16 @@ class MUSt3R(HipModule):
             mem_labels = torch.cat([mem_labels.to(device)] + labels, dim=1)
             tot = mem_nimgs + sum(nimgs)
             out = (new_vals, mem_labels, tot, tot, mem_labels.shape[1])
+        if return_feats:
+            feats, r0 = [], 0
+            for xi, n, N in zip(xs, nimgs, Ns):
+                feats.append([xi] + [feats_buf[l, r0:r0 + n * N].view(1, n, N, D) for l in range(self.depth)])
+                r0 += n * N
+            return out, (outs if is_list else outs[0]), (feats if is_list else feats[0])
         return out, (outs if is_list else outs[0])
 
     def forward_list(self, x, pos, true_shape, current_mem=None, render=False, return_feats=False):  # decoder.py:158
-        return self.forward(list(x), list(pos), list(true_shape), current_mem, render, False)
+        return self._forward(list(x), list(pos), list(true_shape), current_mem, render, return_feats)
 
 
 class CausalMUSt3R(MUSt3R):

@@ -246,7 +246,7 @@ def decoder_forward(sd, cfg, x, pos, true_shape, current_mem=None, render=False,
         o += n * N
     Nt = o
     new_mem = []
-    feats = [[c] for c in cur]
+    feats = [[xg.reshape(1, nimgs[g], Ns[g], -1)] for g, xg in enumerate(xs)]  # decoder.py:173 / :274: the encoder tokens
     for l in range(cfg.dec_depth):
         b = f"blocks_dec.{l}"
         if not render:
@@ -269,7 +269,7 @@ def decoder_forward(sd, cfg, x, pos, true_shape, current_mem=None, render=False,
             nxt.append(torch.cat(outs, dim=0))
         cur = nxt
         for g in range(len(cur)):
-            feats[g].append(cur[g])
+            feats[g].append(cur[g].reshape(1, nimgs[g], Ns[g], D))
     if not render:
         # run_feedback_layers feedback_mechanism.py:39-53
         fb = layer_norm(new_mem[-1], sd["feedback_norm.weight"], sd["feedback_norm.bias"], 1e-5)
@@ -292,7 +292,10 @@ def decoder_forward(sd, cfg, x, pos, true_shape, current_mem=None, render=False,
         Hh, Ww = (int(v) for v in shapes[g].reshape(-1, 2)[0])
         pms.append(unpatchify_head(sd, cfg, cur[g], Hh, Ww).unsqueeze(0))
     if return_feats:
-        return out_mem, (pms if is_list else pms[0]), feats
+        # _compute_prediction_head normalises the last entry IN the list (decoder.py:150); views as decoder.py:346 / :260
+        for g in range(len(cur)):
+            feats[g][-1] = layer_norm(cur[g], sd["norm_dec.weight"], sd["norm_dec.bias"], 1e-6).reshape(1, nimgs[g], Ns[g], D)
+        return out_mem, (pms if is_list else pms[0]), (feats if is_list else feats[0])
     return out_mem, (pms if is_list else pms[0])
 
 

@@ -322,3 +322,33 @@ def test_streaming_memory_schedule_vs_oracle():
     # and the survivors can be rendered against
     _, ren = dec(*[t.unsqueeze(0) for t in enc(imgs[:2].cuda(), ts[:2])], ts[:2].unsqueeze(0), mem, render=True)
     assert torch.isfinite(ren).all()
+
+
+def test_return_feats_matches_oracle():
+    """decoder.py:344-347 / :258-262: [encoder tokens, residual stream after each block, norm_dec(last)], tensor and list
+    inputs, update and render; the list dispatch of forward() drops the flag like the reference's (decoder.py:270)."""
+    from oracle import must3r_ref as R
+    cfg = TINY
+    enc, dec = build(cfg, "fp16w2")
+    sde, sdd = S.make_encoder_state_dict(cfg, 0), S.make_decoder_state_dict(cfg, 0)
+    imgs, ts = S.make_images(3, 48, 64, 4)
+    x, pos = enc(imgs.cuda(), ts.cuda())
+    xo, po = R.encoder_forward(sde, cfg, imgs, ts)
+    tsc = ts.cuda()
+    mem, pm, feats = dec(x[:2].unsqueeze(0), pos[:2].unsqueeze(0), tsc[:2].unsqueeze(0), None, return_feats=True)
+    memo, pmo, featso = R.decoder_forward(sdd, cfg, xo[:2].unsqueeze(0), po[:2].unsqueeze(0), ts[:2].unsqueeze(0), None, False, "kv",
+                                          return_feats=True)
+    fo = featso
+    assert len(feats) == cfg.dec_depth + 1 == len(fo)
+    assert feats[0].shape == (1, 2, 12, cfg.enc_dim) and feats[-1].shape == (1, 2, 12, cfg.dec_dim)
+    errs = [rel_inf(a.cpu().reshape(-1), torch.as_tensor(b).reshape(-1)) for a, b in zip(feats, fo)]
+    record("return_feats", errs=errs)
+    assert max(errs) < TOL["fp16w2"], errs
+    # same pointmaps / memory as without the flag
+    mem2, pm2 = dec(x[:2].unsqueeze(0), pos[:2].unsqueeze(0), tsc[:2].unsqueeze(0), None)
+    assert torch.equal(pm, pm2) and all(torch.equal(a, b) for a, b in zip(mem[0], mem2[0]))
+    # render + list form through forward_list; forward() with lists ignores the flag
+    _, pml, fl = dec.forward_list([x[2:3].unsqueeze(0)], [pos[2:3].unsqueeze(0)], [tsc[2:3].unsqueeze(0)], mem, render=True, return_feats=True)
+    _, pmr = dec(x[2:3].unsqueeze(0), pos[2:3].unsqueeze(0), tsc[2:3].unsqueeze(0), mem, render=True)
+    assert torch.equal(pml[0], pmr) and len(fl) == 1 and len(fl[0]) == cfg.dec_depth + 1
+    assert len(dec([x[2:3].unsqueeze(0)], [pos[2:3].unsqueeze(0)], [tsc[2:3].unsqueeze(0)], mem, render=True, return_feats=True)) == 2

@@ -96,7 +96,7 @@ def test_invariants_memory_modes_and_render():
         sd0["feedback_layer.fc2.bias"] = torch.zeros_like(sdd["feedback_layer.fc2.bias"])
         mem_a, _, feats = R.decoder_forward(sd0, cfg, x[:2].unsqueeze(0), pos[:2].unsqueeze(0), ts[:2].unsqueeze(0), None,
                                             return_feats=True)
-        y0 = R.prepare_y(sd0, "blocks_dec.1", feats[0][1].reshape(1, -1, cfg.dec_dim), "kv")
+        y0 = R.prepare_y(sd0, "blocks_dec.1", feats[1].reshape(1, -1, cfg.dec_dim), "kv")
         assert rel_inf(mem_a[0][1], y0) < 1e-6
 
 

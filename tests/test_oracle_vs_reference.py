@@ -102,3 +102,27 @@ def test_compute_cam_glue_equals_reference_postprocess():
     assert ref["focal"].shape == (2, 3) and ref["c2w"].shape == (2, 3, 4, 4)
     assert torch.allclose(ours["focal"], ref["focal"], rtol=1e-6, atol=0)
     assert torch.allclose(ours["c2w"], ref["c2w"], rtol=1e-5, atol=1e-6)
+
+
+def test_return_feats_equals_reference():
+    """decoder.py:344-347 (tensor) and :258-262 (forward_list): list of [encoder tokens, block outputs, norm_dec(last)]."""
+    from oracle import ref_shims, must3r_ref as R
+    cfg = TINY
+    sde, sdd = S.make_encoder_state_dict(cfg, 0), S.make_decoder_state_dict(cfg, 0)
+    enc, dec = ref_shims.build_reference(cfg, sde, sdd, "kv")
+    imgs, ts = S.make_images(3, 48, 64, 2)
+    with torch.no_grad():
+        x, pos = enc(imgs, ts)
+        mem, pm, feats = dec(x[:2].unsqueeze(0), pos[:2].unsqueeze(0), ts[:2].unsqueeze(0), None, return_feats=True)
+        memo, pmo, fo = R.decoder_forward(sdd, cfg, x[:2].unsqueeze(0), pos[:2].unsqueeze(0), ts[:2].unsqueeze(0), None, False, "kv",
+                                          return_feats=True)
+        assert len(feats) == len(fo) == cfg.dec_depth + 1
+        for a, b in zip(feats, fo):
+            assert a.shape == b.shape and rel_inf(b, a) < 2e-5
+        _, pml, fl = dec.forward_list([x[2:].unsqueeze(0)], [pos[2:].unsqueeze(0)], [ts[2:].unsqueeze(0)], mem, render=True,
+                                      return_feats=True)
+        _, pmlo, flo = R.decoder_forward(sdd, cfg, [x[2:].unsqueeze(0)], [pos[2:].unsqueeze(0)], [ts[2:].unsqueeze(0)], memo, True, "kv",
+                                         return_feats=True)
+        assert len(fl) == len(flo) == 1 and len(fl[0]) == len(flo[0])
+        for a, b in zip(fl[0], flo[0]):
+            assert a.shape == b.shape and rel_inf(b, a) < 2e-5
