@@ -63,8 +63,6 @@ def main():
     ap.add_argument("--cpu-timeout", type=float, default=240.0)
     ap.add_argument("--overlap", action="store_true", help="encode views 2.. on a second stream under the memory update (was +3 %% with "
                     "the 4-wave GEMMs; the 8-wave one-block-per-CU GEMM leaves no room for co-resident kernels: no gain)")
-    ap.add_argument("--enc-cus", type=int, default=0, help="run the overlapped encoder on a stream restricted to this many CUs")
-    ap.add_argument("--upd-cus", type=int, default=0, help="run the memory update on a stream restricted to this many CUs")
     ap.add_argument("--enc-chunk", type=int, default=6, help="views per encoder call on the second stream")
     ap.add_argument("--inflight", type=int, default=1, help="scenes in flight: consecutive steps alternate over this many independent "
                     "contexts/streams (software pipelining across steps; every step still does all of its work)")
@@ -121,8 +119,7 @@ def main():
         e_, d_, st = lanes[step_no[0] % len(lanes)]
         step_no[0] += 1
         if st is None:
-            return run_scene(e_, d_, imgs, ts, overlap=args.overlap, enc_cus=args.enc_cus, upd_cus=args.upd_cus,
-                             enc_chunk=args.enc_chunk)
+            return run_scene(e_, d_, imgs, ts, overlap=args.overlap, enc_chunk=args.enc_chunk)
         st.wait_stream(torch.cuda.current_stream(device))
         with torch.cuda.stream(st):
             return run_scene(e_, d_, imgs, ts, overlap=False)

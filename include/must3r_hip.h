@@ -113,7 +113,7 @@ int must3r_hip_postprocess(const float* pointmaps, float* pts3d, float* pts3d_lo
  * (engine/inference.py:33-35) and (R, T) = roma.rigid_points_registration(pts3d_local -> pts3d, weights conf-1)
  * (engine/inference.py:37-40) written as c2w [n_views,4,4] row-major (engine/inference.py:42-46).
  * pointmaps fp32 [n_views,H,W,7]; outputs fp32; scratch: >= must3r_hip_postprocess_cam_scratch_bytes device bytes.
- * Uses a cooperative launch (all blocks co-resident): do not call it on a CU-masked stream. */
+ * Uses a cooperative launch (all blocks co-resident). */
 size_t must3r_hip_postprocess_cam_scratch_bytes(int n_views, int H, int W);
 int must3r_hip_postprocess_cam(const float* pointmaps, int n_views, int H, int W, float* pts3d, float* pts3d_local,
                                float* conf, float* focal, float* c2w, void* scratch, size_t scratch_bytes, void* stream);
@@ -155,15 +155,6 @@ int must3r_hip_op_cast(int dtype, const float* in, void* out16, void* out16_lo, 
 
 /* debug: lane -> element mapping of the gfx950 transposing LDS read the attention kernel relies on; writes 256 int16 */
 int must3r_hip_debug_tr_probe(void* out256_i16_dev, void* stream);
-
-/* CU-partitioned streams (design, not in the reference): the sequential memory update (engine/inference.py:396-442)
- * is a chain of launches that cannot fill 256 CUs, the per-view encoder (engine/inference.py:152-158) is independent of
- * it.  A stream restricted to CUs [cu_first, cu_first + cu_count) lets the two run side by side without the
- * chip-filling encoder blocks queueing in front of the update's small kernels.  CU bit i lives on XCD i % 8, so a
- * contiguous range is spread evenly over the 8 XCDs.  The handle is a hipStream_t (pass it as `stream`). */
-int must3r_hip_stream_create(int device, int cu_first, int cu_count, void** out_stream);
-int must3r_hip_stream_destroy(int device, void* stream);
-int must3r_hip_cu_count(int device);
 
 /* timing hooks used by bench.py: per-stage HIP-event timers recorded on the call's stream */
 int must3r_hip_set_profiling(must3r_hip_ctx* ctx, int enabled);

@@ -23,7 +23,6 @@ EXPORTS = (
     "must3r_hip_postprocess", "must3r_hip_op_gemm", "must3r_hip_rope_table", "must3r_hip_op_attention",
     "must3r_hip_op_layernorm", "must3r_hip_op_im2col", "must3r_hip_op_cast", "must3r_hip_set_profiling",
     "must3r_hip_get_profile", "must3r_hip_debug_tr_probe", "must3r_hip_attention_scratch_bytes",
-    "must3r_hip_stream_create", "must3r_hip_stream_destroy", "must3r_hip_cu_count",
     "must3r_hip_postprocess_cam", "must3r_hip_postprocess_cam_scratch_bytes",
 )
 
@@ -93,13 +92,10 @@ def load():
     lib.must3r_hip_postprocess_cam.argtypes = [vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, C.c_size_t, vp]
     lib.must3r_hip_postprocess_cam_scratch_bytes.argtypes = [i32, i32, i32]
     lib.must3r_hip_postprocess_cam_scratch_bytes.restype = C.c_size_t
-    lib.must3r_hip_stream_create.argtypes = [i32, i32, i32, C.POINTER(vp)]
-    lib.must3r_hip_stream_destroy.argtypes = [i32, vp]
-    lib.must3r_hip_cu_count.argtypes = [i32]
     lib.must3r_hip_get_profile.argtypes = [vp, C.POINTER(ProfRecord), i32, i32]
     for name in EXPORTS:
         fn = getattr(lib, name)
-        if fn.restype is C.c_int and name not in ("must3r_hip_abi_version", "must3r_hip_attention_scratch_bytes", "must3r_hip_cu_count",
+        if fn.restype is C.c_int and name not in ("must3r_hip_abi_version", "must3r_hip_attention_scratch_bytes",
                                                     "must3r_hip_postprocess_cam_scratch_bytes"):
             fn.restype = i32
     if lib.must3r_hip_abi_version() != ABI_VERSION:

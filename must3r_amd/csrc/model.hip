@@ -962,34 +962,6 @@ extern "C" int must3r_hip_debug_tr_probe(void* out256_i16_dev, void* stream) {
     return 0;
 }
 
-extern "C" int must3r_hip_cu_count(int device) {
-    hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return -1;
-    return prop.multiProcessorCount;
-}
-
-extern "C" int must3r_hip_stream_create(int device, int cu_first, int cu_count, void** out_stream) {
-    if (!out_stream) return fail("stream_create: null argument");
-    const int ncu = must3r_hip_cu_count(device);
-    if (ncu <= 0) return fail("stream_create: no such device");
-    if (cu_first < 0 || cu_count <= 0 || cu_first + cu_count > ncu) return fail("stream_create: CU range outside the device");
-    HIP_OK(hipSetDevice(device));
-    std::vector<uint32_t> mask((ncu + 31) / 32, 0u);
-    for (int i = cu_first; i < cu_first + cu_count; ++i) mask[i >> 5] |= 1u << (i & 31);
-    hipStream_t s = nullptr;
-    HIP_OK(hipExtStreamCreateWithCUMask(&s, (uint32_t)mask.size(), mask.data()));
-    *out_stream = s;
-    return 0;
-}
-
-extern "C" int must3r_hip_stream_destroy(int device, void* stream) {
-    if (!stream) return 0;
-    HIP_OK(hipSetDevice(device));
-    HIP_OK(hipStreamSynchronize(reinterpret_cast<hipStream_t>(stream)));
-    HIP_OK(hipStreamDestroy(reinterpret_cast<hipStream_t>(stream)));
-    return 0;
-}
-
 extern "C" int must3r_hip_set_profiling(must3r_hip_ctx* c, int enabled) {
     if (!c) return fail("set_profiling: null context");
     prof_flush(c);

@@ -76,32 +76,15 @@ def _side_stream(device):
     return _side_streams[key]
 
 
-def partitioned_stream(device, cu_first, cu_count):
-    """A HIP stream whose kernels only run on CUs [cu_first, cu_first + cu_count) (``must3r_hip_stream_create``),
-    wrapped for ``torch.cuda.stream``.  Cached per (device, range)."""
-    device = torch.device(device)
-    key = (device.type, device.index, int(cu_first), int(cu_count))
-    if key not in _side_streams:
-        import ctypes as C
-        lib = _lib.load()
-        h = C.c_void_p()
-        idx = device.index if device.index is not None else torch.cuda.current_device()
-        _lib.check(lib.must3r_hip_stream_create(idx, int(cu_first), int(cu_count), C.byref(h)))
-        _side_streams[key] = torch.cuda.ExternalStream(h.value, device=device)
-    return _side_streams[key]
-
-
 @torch.no_grad()
 def run_scene(encoder, decoder, imgs, true_shape, mem_batches=None, render_bs=None, activate=True, encoder_tokens=None,
-              overlap=False, enc_chunk=6, enc_cus=0, upd_cus=0):
+              overlap=False, enc_chunk=6):
     """One scene with a single aspect ratio.  imgs fp32 [V,3,H,W] (cuda), true_shape int64 [V,2].
 
     ``overlap`` (off by default): only the views of the first memory batch are encoded up front, the rest in chunks on a
     second HIP stream *while* the memory update of the earlier views runs, each decoder call waiting on the event of the
     chunk that holds its view.  Worth +3 % with the 4-wave GEMM kernels; the 8-wave one-block-per-CU GEMM the batched
     encoder now uses leaves no room for co-resident kernels, and chunking costs it its fill: no gain.
-    ``enc_cus`` / ``upd_cus`` > 0 put the second stream / the update on CU-partitioned streams (``partitioned_stream``);
-    measured and rejected, kept for the record.
 
     Returns dict(update=[V,H,W,7], render=[V,H,W,7], mem=mem_tuple, x, pos[, pts3d, pts3d_local, conf of the render])."""
     V = imgs.shape[0]
@@ -118,11 +101,7 @@ def run_scene(encoder, decoder, imgs, true_shape, mem_batches=None, render_bs=No
     elif overlap and imgs.is_cuda and V > mem_batches[0] + 2:
         dev = imgs.device
         main = torch.cuda.current_stream(dev)
-        if enc_cus:
-            ncu = _lib.load().must3r_hip_cu_count(dev.index if dev.index is not None else torch.cuda.current_device())
-            side = partitioned_stream(dev, ncu - enc_cus, enc_cus)
-        else:
-            side = _side_stream(dev)
+        side = _side_stream(dev)
         n0 = mem_batches[0]
         x0, p0 = encoder(imgs[:n0], true_shape[:n0])
         xs, poss, ready = [x0], [p0], [None] * n0
@@ -157,21 +136,14 @@ def run_scene(encoder, decoder, imgs, true_shape, mem_batches=None, render_bs=No
     mem = None
     upd = []
     i = 0
-    import contextlib
-    upd_stream = partitioned_stream(imgs.device, 0, upd_cus) if (upd_cus and xs is not None) else None
-    if upd_stream is not None:
-        upd_stream.wait_stream(torch.cuda.current_stream(imgs.device))
-    with (torch.cuda.stream(upd_stream) if upd_stream is not None else contextlib.nullcontext()):
-        for nb in mem_batches:
-            if ready is not None:
-                for ev in {ready[j] for j in range(i, i + nb)} - {None}:
-                    torch.cuda.current_stream(imgs.device).wait_event(ev)
-            xi, pi = tokens(i, i + nb)
-            mem, pm = decoder(xi.unsqueeze(0), pi.unsqueeze(0), true_shape[i:i + nb].unsqueeze(0), mem)
-            upd.append(pm[0])
-            i += nb
-    if upd_stream is not None:
-        torch.cuda.current_stream(imgs.device).wait_stream(upd_stream)
+    for nb in mem_batches:
+        if ready is not None:
+            for ev in {ready[j] for j in range(i, i + nb)} - {None}:
+                torch.cuda.current_stream(imgs.device).wait_event(ev)
+        xi, pi = tokens(i, i + nb)
+        mem, pm = decoder(xi.unsqueeze(0), pi.unsqueeze(0), true_shape[i:i + nb].unsqueeze(0), mem)
+        upd.append(pm[0])
+        i += nb
     if xs is not None:
         torch.cuda.current_stream(imgs.device).wait_stream(side)
         x, pos = torch.cat(xs, 0), torch.cat(poss, 0)
