@@ -352,3 +352,36 @@ def test_return_feats_matches_oracle():
     _, pmr = dec(x[2:3].unsqueeze(0), pos[2:3].unsqueeze(0), tsc[2:3].unsqueeze(0), mem, render=True)
     assert torch.equal(pml[0], pmr) and len(fl) == 1 and len(fl[0]) == cfg.dec_depth + 1
     assert len(dec([x[2:3].unsqueeze(0)], [pos[2:3].unsqueeze(0)], [tsc[2:3].unsqueeze(0)], mem, render=True, return_feats=True)) == 2
+
+
+def test_full_size_scene_properties():
+    """BASELINE config 3 at full size (20 views, 384x512, MUSt3R_512) through size-independent properties: the batched
+    encoder (M = 15360 rows: the 8-wave 256-row GEMM tiles) is bit-identical to per-view encoding (M = 768: 64x64 tiles),
+    the scene's first update call equals the same call made alone, memory bookkeeping, render independence of a view
+    from its batch, finiteness."""
+    from must3r_amd.engine import run_scene
+    cfg = MUST3R_512
+    H, W, V = 384, 512, 20
+    enc, dec = build(cfg, "fp16w2")
+    imgs, ts = S.make_images(V, H, W, 0)
+    imgs_c, ts_c = imgs.cuda(), ts.cuda()
+    out = run_scene(enc, dec, imgs_c, ts_c)
+    x, pos, mem = out["x"], out["pos"], out["mem"]
+    for v in (0, 7, 19):
+        xv, pv = enc(imgs_c[v:v + 1], ts_c[v:v + 1])
+        assert torch.equal(xv[0], x[v]) and torch.equal(pv[0], pos[v]), f"encoder batch-variance at view {v}"
+    assert out["update"].shape == out["render"].shape == (V, H, W, 7)
+    assert all(torch.isfinite(out[k]).all() for k in ("update", "render", "pts3d", "pts3d_local", "conf"))
+    assert (out["conf"] >= 1.0).all()
+    assert mem[0][0].shape == (1, V * 768, 1536) and len(mem[0]) == cfg.dec_depth and mem[2:] == (V, V, V * 768)
+    assert torch.equal(mem[1].cpu(), torch.arange(V).repeat_interleave(768).view(1, -1))
+    m2, upd2 = dec(x[:2].unsqueeze(0), pos[:2].unsqueeze(0), ts_c[:2].unsqueeze(0), None)
+    assert torch.equal(upd2[0], out["update"][:2])
+    assert all(torch.equal(a[:, :2 * 768], b) for a, b in zip(mem[0], m2[0])), "the first 2 views' memory rows changed later"
+    _, r1 = dec(x[11:12].unsqueeze(0), pos[11:12].unsqueeze(0), ts_c[11:12].unsqueeze(0), mem, render=True)
+    e = rel_inf(r1[0, 0].cpu(), out["render"][11].cpu())
+    record("full_size_render_independence", err=e)
+    assert e < 0.5 * TOL["fp16w2"], e
+    # two identical runs: bit-identical (no atomics / run-to-run nondeterminism anywhere on the path)
+    out2 = run_scene(enc, dec, imgs_c, ts_c)
+    assert torch.equal(out2["render"], out["render"]) and torch.equal(out2["update"], out["update"])
