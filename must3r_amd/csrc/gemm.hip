@@ -103,7 +103,7 @@ __device__ __forceinline__ void epilogue_row(const GemmArgs& p, void* const outp
 
 // WS = 2: split-weight mode, W is [N, 2K] = [W_hi | W_lo]; every K-tile stages the activation tile once plus BOTH weight
 // tiles, and each activation fragment feeds two MFMAs (acc += W_hi.a ; acc += W_lo.a).
-template <class T, int BM, int BN, int WGM, int WGN, int EPI, int NST, int WS, int BK>
+template <class T, int BM, int BN, int WGM, int WGN, int EPI, int NST, int WS, int BK, int PIPE>
 __global__ void __launch_bounds__(64 * WGM * WGN) gemm_kernel(const GemmArgs p) {
     typedef typename Vec<T>::v8 v8;
     typedef typename Vec<T>::v4 v4;
@@ -221,7 +221,93 @@ __global__ void __launch_bounds__(64 * WGM * WGN) gemm_kernel(const GemmArgs p) 
         }
     };
 
-    if constexpr (NST == 2) {
+    if constexpr (PIPE) {
+        // Single-round launches (one block per CU, one wave per SIMD, all waves in lock step): nothing else on the CU hides
+        // the LDS-read latency of a tile, so the fragment reads are software-pipelined inside the wave -- the reads of tile
+        // kt+1 are issued BEFORE the MFMAs of tile kt and retire under them.  Tile kt+1 therefore has to have landed one
+        // iteration earlier than in the ring below: NST-2 younger tiles in flight instead of NST-1 (NST is 6-8 here: one
+        // block per CU can spend the whole LDS on prefetch depth).  Buffer (kt-1) is overwritten by the DMA of tile
+        // kt+NST-1 after the barrier of iteration kt; its reads were issued in iteration kt-2 and waited for in kt-1.
+        static_assert(NST >= 4 && BK == 64, "pipelined ring");
+        constexpr int IPT = PA + WS * PW;
+        constexpr int PEND = (NST - 3) * IPT;       // tiles kt+2 .. kt+NST-2 may still be in flight when kt+1 is needed
+        static_assert(PEND < 64, "vmcnt field");
+        v8 fw[2][2][WS][NF], fa[2][2][MF];          // [set][ks]
+        auto load_frags = [&](int set, int buf) {
+            const T* a = sA + buf * BM * BK;
+            const T* w = sW + buf * WS * BN * BK;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const int lc = ks * 4 + fg;
+#pragma unroll
+                for (int part = 0; part < WS; ++part)
+#pragma unroll
+                    for (int j = 0; j < NF; ++j) {
+                        const int r = wn * WN + j * 16 + fr;
+                        fw[set][ks][part][j] = *reinterpret_cast<const v8*>(w + (part * BN + r) * BK + swzk<BK>(r, lc) * 8);
+                    }
+#pragma unroll
+                for (int i = 0; i < MF; ++i) {
+                    const int r = wm * WM + i * 16 + fr;
+                    fa[set][ks][i] = *reinterpret_cast<const v8*>(a + r * BK + swzk<BK>(r, lc) * 8);
+                }
+            }
+        };
+        auto wait_dma = [&](int younger) {          // younger = tiles issued after the one that must have landed
+            if (younger >= NST - 3) __builtin_amdgcn_s_waitcnt(0x0f70 | (PEND & 15) | ((PEND >> 4) << 14));
+            else __builtin_amdgcn_s_waitcnt(0x0f70);   // tail: drain
+        };
+#pragma unroll
+        for (int t = 0; t < NST - 1; ++t)
+            if (t < nk) stage(t, t);
+        // tile 0: everything issued so far except tiles 1..NST-2 must be in
+        if (nk - 1 >= NST - 2) __builtin_amdgcn_s_waitcnt(0x0f70 | (((NST - 2) * IPT) & 15) | ((((NST - 2) * IPT) >> 4) << 14));
+        else __builtin_amdgcn_s_waitcnt(0x0f70);
+        __builtin_amdgcn_s_barrier();
+        load_frags(0, 0);
+        int buf = 0;
+        // two iterations per trip so that the fragment set index is a compile-time constant (registers, not scratch)
+        auto body = [&](auto curc, int kt) {
+            constexpr int cur = decltype(curc)::value;
+            const int nbuf = buf + 1 == NST ? 0 : buf + 1;
+            if (kt + 1 < nk) wait_dma(nk - 2 - kt < NST - 3 ? nk - 2 - kt : NST - 3);
+            __builtin_amdgcn_s_barrier();
+            const int nt = kt + NST - 1;
+            if (nt < nk) {
+                int sb = buf + NST - 1;
+                sb = sb >= NST ? sb - NST : sb;
+                stage(nt, sb);                          // buffer of tile kt-1
+            }
+            // Fragments of tile kt were read one iteration ago.  "Using" them here makes the compiler place its own wait for
+            // them BEFORE the next tile's reads are issued; with an opaque inline s_waitcnt it keeps treating the
+            // loop-carried registers as pending and drains the new reads as well (lgkmcnt(0)) in front of the MFMAs.
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+                for (int part = 0; part < WS; ++part)
+#pragma unroll
+                    for (int j = 0; j < NF; ++j) asm volatile("" ::"v"(fw[cur][ks][part][j]));
+#pragma unroll
+                for (int i = 0; i < MF; ++i) asm volatile("" ::"v"(fa[cur][ks][i]));
+            }
+            if (kt + 1 < nk) load_frags(cur ^ 1, nbuf);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int part = 0; part < WS; ++part)
+#pragma unroll
+                    for (int i = 0; i < MF; ++i)
+#pragma unroll
+                        for (int j = 0; j < NF; ++j) acc[i][j] = mfma16(fw[cur][ks][part][j], fa[cur][ks][i], acc[i][j]);
+            buf = nbuf;
+        };
+        int kt = 0;
+        for (; kt + 1 < nk; kt += 2) {
+            body(std::integral_constant<int, 0>{}, kt);
+            body(std::integral_constant<int, 1>{}, kt + 1);
+        }
+        if (kt < nk) body(std::integral_constant<int, 0>{}, kt);
+    } else if constexpr (NST == 2) {
         // double buffer: the DMA of tile kt+1 is in flight while tile kt is multiplied
         stage(0, 0);
         for (int kt = 0; kt < nk; ++kt) {
@@ -270,17 +356,17 @@ __global__ void __launch_bounds__(64 * WGM * WGN) gemm_kernel(const GemmArgs p) 
     }
 }
 
-template <class T, int BM, int BN, int WGM, int WGN, int EPI, int NST, int WS, int BK = 64>
+template <class T, int BM, int BN, int WGM, int WGN, int EPI, int NST, int WS, int BK = 64, int PIPE = 0>
 static int launch_cfg(const GemmArgs& a, hipStream_t s) {
     const int nbn = a.N / BN, nbm = (a.M + BM - 1) / BM;
     const size_t lds = (size_t)NST * (BM + WS * BN) * BK * sizeof(T);
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<T, BM, BN, WGM, WGN, EPI, NST, WS, BK>),
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<T, BM, BN, WGM, WGN, EPI, NST, WS, BK, PIPE>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm_kernel<T, BM, BN, WGM, WGN, EPI, NST, WS, BK>), dim3(nbm * nbn, a.batch > 1 ? a.batch : 1),
+    hipLaunchKernelGGL((gemm_kernel<T, BM, BN, WGM, WGN, EPI, NST, WS, BK, PIPE>), dim3(nbm * nbn, a.batch > 1 ? a.batch : 1),
                        dim3(64 * WGM * WGN), lds, s, a);
     return hipGetLastError() == hipSuccess ? 0 : 1;
 }
@@ -482,11 +568,24 @@ static long min_big(bool split) {
     return v[split];
 }
 
-// Launches of at most one 64 x 64 tile per CU run it with 8 waves (4 x 2, wave tile 16 x 32) instead of 4: the L2 -> LDS
-// operand supply of a CU grows with the number of waves issuing loads (scripts/probes/dma_rate.hip: 15 / 30 / 44 B/clk/CU
-// for 4 / 8 / 16 waves) and these launches are supply-bound (43 flop/B tiles): proj 8.7 -> 7.9 us, fc2 23.4 -> 21.8 us at
-// M = 768 with split weights; with two blocks per CU (qkv, fc1) the 4-wave form is as fast or faster.
+// Launches of at most one 64 x 64 tile per CU (M = 768: proj, fc2, projq) run it with 8 waves (4 x 2, wave tile 16 x 32), a
+// 6-8 slot LDS ring (one block per CU: the whole LDS can be prefetch depth) and the fragment reads of tile kt+1 issued
+// before the MFMAs of tile kt (PIPE).  Measured at M = 768 with split weights: proj 8.7 -> 8.1 us, fc2 23.4 -> 20.7 us.
+// What the experiments say about these launches (scripts/bench_gemm_small.py; debug builds that drop one component):
+// per K-tile DMA, LDS reads and MFMAs each cost ~0.1 us ALONE (fc2: 16.3 / 16.8 / 16.6 us with one of them removed, 5.4 us
+// with all three removed, 21 us with all) -- they add up instead of overlapping, whatever the ring depth (3 vs 6 slots:
+// same), the bytes per tile (half the lo tile: -2 %) or the wave count; with two blocks per CU (qkv, fc1) the 4-wave form
+// is as fast or faster.
 static bool small8(long tiles64) { return tiles64 <= 256; }
+#ifndef SMALL_WGM
+#define SMALL_WGM 4
+#endif
+#ifndef SMALL8_NST_SPLIT
+#define SMALL8_NST_SPLIT 6   // 6 x 24 KB = 144 KB: one block per CU anyway, so the whole LDS can be prefetch depth
+#endif
+#ifndef SMALL8_NST_PLAIN
+#define SMALL8_NST_PLAIN 8   // 8 x 16 KB = 128 KB
+#endif
 
 // M3R_GEMM256: 0 = never use the 8-wave kernel, 1 = by the fill rule below (default), 2 = whenever the shape allows it
 static int gemm256_mode() {
@@ -531,7 +630,7 @@ static int launch_epi(const GemmArgs& a, hipStream_t s, const char** err) {
             if (pick == 256) rc = launch_256<T, EPI, 2, 256>(a, s);
             else if (pick == 128) rc = launch_256<T, EPI, 2, 128>(a, s);
             else if (tiles >= min_big(true)) rc = launch_cfg<T, 128, 64, 2, 2, EPI, 2, 2>(a, s);
-            else if (small8((long)((a.M + 63) / 64) * (a.N / 64) * nb)) rc = launch_cfg<T, 64, 64, 4, 2, EPI, 3, 2>(a, s);
+            else if (small8((long)((a.M + 63) / 64) * (a.N / 64) * nb)) rc = launch_cfg<T, 64, 64, SMALL_WGM, 2, EPI, SMALL8_NST_SPLIT, 2, 64, 1>(a, s);
             else rc = launch_cfg<T, 64, 64, 2, 2, EPI, 3, 2>(a, s);
         } else {
             *err = "gemm: split weights are only built for fp16";
@@ -544,7 +643,7 @@ static int launch_epi(const GemmArgs& a, hipStream_t s, const char** err) {
         const bool ok256 = a.N % 256 == 0 && a.K % 32 == 0;
         if (ok256 && (mode == 2 || (mode == 1 && t256 >= 200 && fill256(t256) >= 80))) rc = launch_256<T, EPI, 1, 256>(a, s);
         else if (n128 && tiles128 >= min_big(false)) rc = launch_cfg<T, 128, 128, 2, 2, EPI, 2, 1>(a, s);
-        else if (small8((long)((a.M + 63) / 64) * (a.N / 64) * nb)) rc = launch_cfg<T, 64, 64, 4, 2, EPI, 4, 1>(a, s);
+        else if (small8((long)((a.M + 63) / 64) * (a.N / 64) * nb)) rc = launch_cfg<T, 64, 64, SMALL_WGM, 2, EPI, SMALL8_NST_PLAIN, 1, 64, 1>(a, s);
         else rc = launch_cfg<T, 64, 64, 2, 2, EPI, 4, 1>(a, s);
     }
     if (rc) *err = "gemm: kernel launch failed";
