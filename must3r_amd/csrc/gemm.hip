@@ -575,7 +575,7 @@ static long min_big(bool split) {
 // per K-tile DMA, LDS reads and MFMAs each cost ~0.1 us ALONE (fc2: 16.3 / 16.8 / 16.6 us with one of them removed, 5.4 us
 // with all three removed, 21 us with all) -- they add up instead of overlapping, whatever the ring depth (3 vs 6 slots:
 // same), the bytes per tile (half the lo tile: -2 %) or the wave count; with two blocks per CU (qkv, fc1) the 4-wave form
-// is as fast or faster.
+// is as fast or faster; 64 x 32 tiles (twice the blocks, half the work each): same time per K-tile (0.36 us).
 static bool small8(long tiles64) { return tiles64 <= 256; }
 #ifndef SMALL_WGM
 #define SMALL_WGM 4
