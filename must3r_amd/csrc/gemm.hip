@@ -575,7 +575,10 @@ static long min_big(bool split) {
 // per K-tile DMA, LDS reads and MFMAs each cost ~0.1 us ALONE (fc2: 16.3 / 16.8 / 16.6 us with one of them removed, 5.4 us
 // with all three removed, 21 us with all) -- they add up instead of overlapping, whatever the ring depth (3 vs 6 slots:
 // same), the bytes per tile (half the lo tile: -2 %) or the wave count; with two blocks per CU (qkv, fc1) the 4-wave form
-// is as fast or faster; 64 x 32 tiles (twice the blocks, half the work each): same time per K-tile (0.36 us).
+// is as fast or faster; 64 x 32 tiles (twice the blocks, half the work each): same time per K-tile; the staggered
+// two-group structure of gemm256_kernel on the 64 x 64 tile: same (fc2 20.4-21.0 us).  The slope is 0.35 us per
+// 64-deep K-tile whatever the structure (proj 12 tiles 8.0 us, fc2 48 tiles 20.5 us); K off the power-of-two strides
+// (3008 / 3136 instead of 3072) changes nothing, so it is not L2-channel camping either.  Open.
 static bool small8(long tiles64) { return tiles64 <= 256; }
 #ifndef SMALL_WGM
 #define SMALL_WGM 4

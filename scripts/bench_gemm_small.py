@@ -8,6 +8,11 @@ st = torch.cuda.current_stream().cuda_stream
 split = int(os.environ.get("SPLIT", "0"))
 shapes = [("qkv", 768, 2304, 768, lib.EPI_STORE16), ("proj", 768, 768, 768, lib.EPI_RESID_F32), ("fc1", 768, 3072, 768, lib.EPI_STORE16_GELU),
           ("fc2", 768, 768, 3072, lib.EPI_RESID_F32), ("kv", 768, 1536, 768, lib.EPI_STORE16), ("init2 fc1", 1536, 3072, 768, lib.EPI_STORE16_GELU)]
+if os.environ.get("STRIDE_EXP"):   # L2-channel camping check: same shapes with K off the power-of-two-ish strides
+    shapes = [("fc2 K3072", 768, 768, 3072, lib.EPI_RESID_F32), ("fc2 K3136", 768, 768, 3136, lib.EPI_RESID_F32),
+              ("fc2 K3008", 768, 768, 3008, lib.EPI_RESID_F32), ("proj K768", 768, 768, 768, lib.EPI_RESID_F32),
+              ("proj K832", 768, 768, 832, lib.EPI_RESID_F32), ("proj K704", 768, 768, 704, lib.EPI_RESID_F32),
+              ("fc1 K768", 768, 3072, 768, lib.EPI_STORE16_GELU), ("fc1 K832", 768, 3072, 832, lib.EPI_STORE16_GELU)]
 tot = 0
 for name, M, N, K, epi in shapes:
     A = torch.randn((M, K), device="cuda").half()
