@@ -118,6 +118,14 @@ size_t must3r_hip_postprocess_cam_scratch_bytes(int n_views, int H, int W);
 int must3r_hip_postprocess_cam(const float* pointmaps, int n_views, int H, int W, float* pts3d, float* pts3d_local,
                                float* conf, float* focal, float* c2w, void* scratch, size_t scratch_bytes, void* stream);
 
+/* SLAM keyframe test, SURVEY.md section 8f rank 3 (slam/model.py:62-91 get_overlap_score; slam/nns.py:40-92).
+ * must3r_hip_nn_query replaces KDTree_scipy.query (nns.py:52-57: scipy KDTree.query(k=1), Euclidean): out_dist[i] =
+ * min_j |q_i - db_j| for fp32 xyz points [n,3] on the device, +inf when n_db == 0 (nns.py:53-54).  Exact (brute force).
+ * must3r_hip_quadrant_ids replaces get_quadrant_id (slam/tools.py:9-31) on rays p - cam_center (nns.py:81,88):
+ * out[i] in [0, 2*divider^2). */
+int must3r_hip_nn_query(const float* db_xyz, int64_t n_db, const float* q_xyz, int64_t n_q, float* out_dist, void* stream);
+int must3r_hip_quadrant_ids(const float* pts_xyz, int64_t n, const float* cam_center_host3, int divider, int32_t* out, void* stream);
+
 /* ------------------------------------------------------------------------------------------------------
  * Operator-level entry points (the same kernels the two forwards are built from), exported so that parity
  * tests and roofline measurements can drive each kernel alone.

@@ -122,6 +122,9 @@ int launch_fill_pos(int64_t* pos, int V, int gh, int gw, hipStream_t s, const ch
 // pointmaps [npix,7] fp32 -> pts3d [npix,3], pts3d_local [npix,3], conf [npix]
 int launch_postprocess(const float* pm, float* pts3d, float* pts3d_local, float* conf, size_t npix, hipStream_t s,
                        const char** err);
+// SLAM keyframe test (slam/nns.py, slam/tools.py:9-31): exact 1-NN distances by brute force, view-direction quadrants; nn.hip
+int launch_nn_query(const float* db, long long n_db, const float* q, long long n_q, float* out_dist, hipStream_t s, const char** err);
+int launch_quadrant_ids(const float* pts, long long n, const float* cam_center_host, int div, int* out, hipStream_t s, const char** err);
 // postprocess(compute_cam=True): activation + focal (Weiszfeld) + weighted rigid registration, cam.hip
 size_t cam_scratch_bytes(int n_views, int H, int W);
 int launch_postprocess_cam(const float* pm, int n_views, int H, int W, float* pts3d, float* pts3d_local, float* conf,

@@ -879,6 +879,24 @@ extern "C" int must3r_hip_postprocess(const float* pm, float* p3, float* pl, flo
     return 0;
 }
 
+extern "C" int must3r_hip_nn_query(const float* db, int64_t n_db, const float* q, int64_t n_q, float* out, void* stream) {
+    if (n_db < 0 || n_q < 0) return fail("nn_query: negative count");
+    if (n_q == 0) return 0;
+    if (!q || !out || (n_db > 0 && !db)) return fail("nn_query: null argument");
+    const char* err = nullptr;
+    if (launch_nn_query(db, n_db, q, n_q, out, reinterpret_cast<hipStream_t>(stream), &err)) return fail("%s", err);
+    return 0;
+}
+
+extern "C" int must3r_hip_quadrant_ids(const float* pts, int64_t n, const float* cam_center, int divider, int32_t* out, void* stream) {
+    if (n < 0) return fail("quadrant_ids: negative count");
+    if (n == 0) return 0;
+    if (!pts || !cam_center || !out) return fail("quadrant_ids: null argument");
+    const char* err = nullptr;
+    if (launch_quadrant_ids(pts, n, cam_center, divider, out, reinterpret_cast<hipStream_t>(stream), &err)) return fail("%s", err);
+    return 0;
+}
+
 extern "C" size_t must3r_hip_postprocess_cam_scratch_bytes(int n_views, int H, int W) {
     if (n_views <= 0 || H <= 0 || W <= 0) return 0;
     return cam_scratch_bytes(n_views, H, W);

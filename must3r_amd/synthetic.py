@@ -13,6 +13,7 @@ the dicts with ``load_state_dict(strict=True)``.
 """
 import math
 
+import numpy as np
 import torch
 
 from .config import ModelConfig
@@ -117,3 +118,18 @@ def make_cam_pointmaps(*lead_hw, focal=40.0, noise=0.01, seed=None):
         return p / d.clip(min=1e-8) * torch.log1p(d)
     pm = torch.cat((inv_norm_exp(world), inv_norm_exp(local), torch.randn(n, H, W, 1)), dim=-1)
     return pm.reshape(*lead, H, W, 7)
+
+
+def make_overlap_frames(seed, n_kf=3, H=24, W=32):
+    """Synthetic keyframe sequence: pointmaps on a wavy surface seen from moving camera centres."""
+    rng = np.random.default_rng(seed)
+    frames = []
+    for k in range(n_kf + 1):
+        cam = np.array([0.3 * k, 0.05 * k, 0.0], dtype=np.float32)
+        ys, xs = np.meshgrid(np.linspace(-1, 1, H, dtype=np.float32), np.linspace(-1.3, 1.3, W, dtype=np.float32), indexing="ij")
+        z = 3.0 + 0.3 * np.sin(2 * xs + k) + 0.05 * rng.standard_normal((H, W)).astype(np.float32)
+        local = np.stack((xs * z * 0.5, ys * z * 0.5, z), -1).astype(np.float32)
+        pts = local + cam
+        conf = (1.0 + np.exp(rng.standard_normal((H, W)))).astype(np.float32)
+        frames.append(dict(pts3d=pts[None, None], pts3d_local=local[None, None], conf=conf[None, None], cam=cam))
+    return frames

@@ -101,9 +101,41 @@ def make_cam():
     print("cam_40x56 focal", o["focal"].flatten().tolist())
 
 
+def make_nn():
+    """SLAM keyframe test: the reference's own searchers (must3r/slam/nns.py, verbatim) and get_overlap_score
+    (must3r/slam/model.py:62-91, the function's source compiled alone: its module needs un-vendored imports)."""
+    import ast
+    ref_shims.install()
+    import must3r.slam.nns as ref_nns
+    path = "/root/reference/must3r/slam/model.py"
+    node = next(n for n in ast.parse(open(path).read()).body if isinstance(n, ast.FunctionDef) and n.name == "get_overlap_score")
+    ns = {"np": np}
+    exec(compile(ast.Module(body=[node], type_ignores=[]), path, "exec"), ns)
+    ref_score = ns["get_overlap_score"]
+    frames = S.make_overlap_frames(7, n_kf=4, H=48, W=64)
+    out = {}
+    for method in ("kdtree-scipy", "kdtree-scipy-quadrant_x2"):
+        tree = ref_nns.get_searcher(method)
+        scores, dists = [], []
+        for f in frames:
+            res = {k: torch.from_numpy(f[k]) for k in ("pts3d", "pts3d_local", "conf")}
+            cam = torch.from_numpy(f["cam"])
+            scores.append([float(ref_score(res, tree, cam, mode=m, kf_x_subsamp=2, percentile=70)) for m in ("nn", "nn-norm")])
+            q = torch.from_numpy(f["pts3d"][0, 0, ::2, ::2].reshape(-1, 3))
+            dists.append(np.asarray(tree.query(q, cam_center=cam), dtype=np.float64))
+            sel = f["pts3d"][0, 0][f["conf"][0, 0] > 1.5]
+            tree.add_pts(torch.from_numpy(sel), cam_center=cam)
+        out[method + "/scores"] = np.array(scores)
+        out[method + "/dists"] = np.stack(dists)
+    np.savez_compressed(os.path.join(OUT, "nn_overlap.npz"), **out)
+    print("nn_overlap", {k: v.shape for k, v in out.items()})
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "cam":
-        make_cam()
-    else:
+    which = sys.argv[1] if len(sys.argv) > 1 else "all"
+    if which in ("all", "model"):
         main()
+    if which in ("all", "cam"):
         make_cam()
+    if which in ("all", "nn"):
+        make_nn()

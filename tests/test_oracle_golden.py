@@ -147,3 +147,19 @@ def test_cam_oracle_matches_reference_fixture():
     o64 = cam_ref.compute_cam(act["pts3d"], act["pts3d_local"], act["conf"], dtype=torch.float64)
     assert torch.allclose(o64["focal"].float(), o["focal"], rtol=1e-4)
     assert torch.allclose(o64["c2w"].float(), o["c2w"], atol=1e-4)
+
+
+def test_nn_oracle_matches_reference_fixture():
+    """tests/golden/nn_overlap.npz = the reference's searchers and get_overlap_score (oracle/make_golden.py nn)."""
+    from oracle import nn_ref
+    g = load_golden("nn_overlap")
+    frames = S.make_overlap_frames(7, n_kf=4, H=48, W=64)
+    for method in ("kdtree-scipy", "kdtree-scipy-quadrant_x2"):
+        tree = nn_ref.get_searcher(method)
+        for i, f in enumerate(frames):
+            res = {k: f[k] for k in ("pts3d", "pts3d_local", "conf")}
+            sc = [float(nn_ref.get_overlap_score(res, tree, f["cam"], mode=m, kf_x_subsamp=2, percentile=70)) for m in ("nn", "nn-norm")]
+            assert sc == g[method + "/scores"][i].tolist(), (method, i)
+            d = tree.query(f["pts3d"][0, 0, ::2, ::2].reshape(-1, 3), cam_center=f["cam"])
+            assert np.array_equal(np.asarray(d, dtype=np.float64), g[method + "/dists"][i])
+            tree.add_pts(f["pts3d"][0, 0][f["conf"][0, 0] > 1.5], cam_center=f["cam"])
