@@ -118,6 +118,22 @@ size_t must3r_hip_postprocess_cam_scratch_bytes(int n_views, int H, int W);
 int must3r_hip_postprocess_cam(const float* pointmaps, int n_views, int H, int W, float* pts3d, float* pts3d_local,
                                float* conf, float* focal, float* c2w, void* scratch, size_t scratch_bytes, void* stream);
 
+/* Retrieval front-end on the encoder tokens, SURVEY.md section 8f rank 4 (retrieval/model.py).
+ * must3r_hip_affine: out[M,N] fp32 = (A[M,K] - sub[K]) . B + bias[N] + resid[M,N]; with is_double the subtraction, the
+ *   products and the sums are float64 like Whitener.forward (retrieval/model.py:67-79: x.double() - m, matmul with p), with
+ *   b_transposed B is an nn.Linear weight [N,K] (the projector, :139-151,169).  sub / bias / resid may be NULL; sub, B and
+ *   bias are float64 arrays when is_double, fp32 otherwise.
+ * must3r_hip_row_norm: attention = x.norm(dim=-1) (:130-131).
+ * must3r_hip_topk_gather: how_select_local (:91-101): per image the k tokens of largest attention, sorted descending
+ *   (ties: lower index first), their features, attentions and int64 indices.  N <= 4096.
+ * must3r_hip_weighted_spoc: weighted_spoc (:82-88): normalize(sum_n attn[n] * feat[n,:]). */
+int must3r_hip_affine(int is_double, const float* A, const void* sub, const void* B, int b_transposed, const void* bias,
+                      const float* resid, float* out, int M, int N, int K, void* stream);
+int must3r_hip_row_norm(const float* x, int M, int C, float* out, void* stream);
+int must3r_hip_topk_gather(const float* feat, const float* attn, int n_images, int N, int C, int k, float* out_feat,
+                           float* out_attn, int64_t* out_idx, void* stream);
+int must3r_hip_weighted_spoc(const float* feat, const float* attn, int n_images, int N, int C, float* out, void* stream);
+
 /* SLAM keyframe test, SURVEY.md section 8f rank 3 (slam/model.py:62-91 get_overlap_score; slam/nns.py:40-92).
  * must3r_hip_nn_query replaces KDTree_scipy.query (nns.py:52-57: scipy KDTree.query(k=1), Euclidean): out_dist[i] =
  * min_j |q_i - db_j| for fp32 xyz points [n,3] on the device, +inf when n_db == 0 (nns.py:53-54).  Exact (brute force).

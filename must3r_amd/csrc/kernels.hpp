@@ -122,6 +122,13 @@ int launch_fill_pos(int64_t* pos, int V, int gh, int gw, hipStream_t s, const ch
 // pointmaps [npix,7] fp32 -> pts3d [npix,3], pts3d_local [npix,3], conf [npix]
 int launch_postprocess(const float* pm, float* pts3d, float* pts3d_local, float* conf, size_t npix, hipStream_t s,
                        const char** err);
+// retrieval front-end on the encoder tokens (retrieval/model.py:59-101,165-183); retrieval.hip
+int launch_gemmx(int is_double, const float* A, const void* sub, const void* B, int b_transposed, const void* bias, const float* resid,
+                 float* out, int M, int N, int K, hipStream_t s, const char** err);
+int launch_row_norm(const float* x, int M, int C, float* out, hipStream_t s, const char** err);
+int launch_topk_gather(const float* feat, const float* attn, int Bn, int N, int C, int k, float* out_feat, float* out_attn,
+                       long long* out_idx, hipStream_t s, const char** err);
+int launch_weighted_spoc(const float* feat, const float* attn, int Bn, int N, int C, float* out, hipStream_t s, const char** err);
 // SLAM keyframe test (slam/nns.py, slam/tools.py:9-31): exact 1-NN distances by brute force, view-direction quadrants; nn.hip
 int launch_nn_query(const float* db, long long n_db, const float* q, long long n_q, float* out_dist, hipStream_t s, const char** err);
 int launch_quadrant_ids(const float* pts, long long n, const float* cam_center_host, int div, int* out, hipStream_t s, const char** err);

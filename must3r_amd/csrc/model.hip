@@ -879,6 +879,45 @@ extern "C" int must3r_hip_postprocess(const float* pm, float* p3, float* pl, flo
     return 0;
 }
 
+extern "C" int must3r_hip_affine(int is_double, const float* A, const void* sub, const void* B, int b_transposed, const void* bias,
+                                 const float* resid, float* out, int M, int N, int K, void* stream) {
+    if (M < 0 || N < 0 || K < 0) return fail("affine: negative size");
+    if (M == 0 || N == 0) return 0;
+    if (!A || !B || !out) return fail("affine: null argument");
+    const char* err = nullptr;
+    if (launch_gemmx(is_double, A, sub, B, b_transposed, bias, resid, out, M, N, K, reinterpret_cast<hipStream_t>(stream), &err)) return fail("%s", err);
+    return 0;
+}
+
+extern "C" int must3r_hip_row_norm(const float* x, int M, int C, float* out, void* stream) {
+    if (M < 0 || C <= 0) return fail("row_norm: bad shape");
+    if (M == 0) return 0;
+    if (!x || !out) return fail("row_norm: null argument");
+    const char* err = nullptr;
+    if (launch_row_norm(x, M, C, out, reinterpret_cast<hipStream_t>(stream), &err)) return fail("%s", err);
+    return 0;
+}
+
+extern "C" int must3r_hip_topk_gather(const float* feat, const float* attn, int n_images, int N, int C, int k, float* out_feat,
+                                      float* out_attn, int64_t* out_idx, void* stream) {
+    if (n_images < 0 || N < 0 || C <= 0 || k < 0) return fail("topk_gather: bad shape");
+    if (n_images == 0 || k == 0) return 0;
+    if (!feat || !attn || !out_feat || !out_attn || !out_idx) return fail("topk_gather: null argument");
+    const char* err = nullptr;
+    if (launch_topk_gather(feat, attn, n_images, N, C, k, out_feat, out_attn, reinterpret_cast<long long*>(out_idx),
+                           reinterpret_cast<hipStream_t>(stream), &err)) return fail("%s", err);
+    return 0;
+}
+
+extern "C" int must3r_hip_weighted_spoc(const float* feat, const float* attn, int n_images, int N, int C, float* out, void* stream) {
+    if (n_images < 0 || N < 0 || C <= 0) return fail("weighted_spoc: bad shape");
+    if (n_images == 0) return 0;
+    if (!feat || !attn || !out) return fail("weighted_spoc: null argument");
+    const char* err = nullptr;
+    if (launch_weighted_spoc(feat, attn, n_images, N, C, out, reinterpret_cast<hipStream_t>(stream), &err)) return fail("%s", err);
+    return 0;
+}
+
 extern "C" int must3r_hip_nn_query(const float* db, int64_t n_db, const float* q, int64_t n_q, float* out, void* stream) {
     if (n_db < 0 || n_q < 0) return fail("nn_query: negative count");
     if (n_q == 0) return 0;

@@ -133,3 +133,19 @@ def make_overlap_frames(seed, n_kf=3, H=24, W=32):
         conf = (1.0 + np.exp(rng.standard_normal((H, W)))).astype(np.float32)
         frames.append(dict(pts3d=pts[None, None], pts3d_local=local[None, None], conf=conf[None, None], cam=cam))
     return frames
+
+
+def make_retrieval_state_dict(dim, seed=0, prewhiten=True, postwhiten=True):
+    """Seeded RetrievalModel state dict (reference keys, retrieval/model.py:104-151): whiteners with a non-trivial mean and a
+    well-conditioned random projection (float64), xavier Linear projector with a non-zero bias."""
+    g = torch.Generator().manual_seed(1000 + seed)
+    sd = {}
+    for name, on in (("prewhiten", prewhiten), ("postwhiten", postwhiten)):
+        if on:
+            sd[name + ".m"] = (torch.randn((1, dim), generator=g, dtype=torch.float64) * 0.1)
+            q, _ = torch.linalg.qr(torch.randn((dim, dim), generator=g, dtype=torch.float64))
+            sd[name + ".p"] = q * (0.5 + torch.rand((dim,), generator=g, dtype=torch.float64))[None, :]
+    bound = (6.0 / (2 * dim)) ** 0.5
+    sd["projector.0.weight"] = (torch.rand((dim, dim), generator=g) * 2 - 1) * bound
+    sd["projector.0.bias"] = torch.randn((dim,), generator=g) * 0.02
+    return sd

@@ -131,6 +131,29 @@ def make_nn():
     print("nn_overlap", {k: v.shape for k, v in out.items()})
 
 
+def make_retrieval():
+    """Retrieval front-end: the reference's own RetrievalModel (must3r/retrieval/model.py, verbatim import)."""
+    ref_shims.install()
+    import must3r.retrieval.model as RM
+
+    class _Backbone(torch.nn.Module):
+        embed_dim = 256
+    out = {}
+    for tag, kw in (("full", dict(prewhiten=-1, postwhiten=-1)), ("resid", dict(prewhiten=None, postwhiten=-1, residual=True))):
+        model = RM.RetrievalModel(_Backbone(), prewhiten=kw.get("prewhiten"), postwhiten=kw.get("postwhiten"), hdims=[256],
+                                  residual=kw.get("residual", False), nfeat=20).eval()
+        sd = S.make_retrieval_state_dict(256, seed=3, prewhiten=kw.get("prewhiten") is not None)
+        msg = model.load_state_dict(sd, strict=False)
+        assert not msg.unexpected_keys and not [k for k in msg.missing_keys if not k.startswith("backbone")], msg
+        x = torch.randn((3, 48, 256), generator=torch.Generator().manual_seed(5))
+        with torch.no_grad():
+            feat, attn, idx = model.forward_local(x)
+            glob = model.forward_global(x)
+        out.update({tag + "/feat": feat.numpy(), tag + "/attn": attn.numpy(), tag + "/idx": idx.numpy(), tag + "/glob": glob.numpy()})
+    np.savez_compressed(os.path.join(OUT, "retrieval_small.npz"), **out)
+    print("retrieval_small", {k: v.shape for k, v in out.items()})
+
+
 if __name__ == "__main__":
     which = sys.argv[1] if len(sys.argv) > 1 else "all"
     if which in ("all", "model"):
@@ -139,3 +162,5 @@ if __name__ == "__main__":
         make_cam()
     if which in ("all", "nn"):
         make_nn()
+    if which in ("all", "retrieval"):
+        make_retrieval()

@@ -200,6 +200,8 @@ def install(reference_root=REFERENCE_ROOT):
     _mod("dust3r.utils.misc",
          invalid_to_zeros=lambda *a, **k: (_ for _ in ()).throw(NotImplementedError()),
          invalid_to_nans=lambda *a, **k: (_ for _ in ()).throw(NotImplementedError()))
+    # retrieval/model.py:12 imports the image loader at module level; only its dataset class calls it (image files)
+    _mod("dust3r.utils.image", load_images=lambda *a, **k: (_ for _ in ()).throw(NotImplementedError()))
     _mod("dust3r.patch_embed", get_patch_embed=get_patch_embed, PatchEmbedDust3R=PatchEmbedDust3R,
          ManyAR_PatchEmbed=ManyAR_PatchEmbed)
     try:

@@ -163,3 +163,16 @@ def test_nn_oracle_matches_reference_fixture():
             d = tree.query(f["pts3d"][0, 0, ::2, ::2].reshape(-1, 3), cam_center=f["cam"])
             assert np.array_equal(np.asarray(d, dtype=np.float64), g[method + "/dists"][i])
             tree.add_pts(f["pts3d"][0, 0][f["conf"][0, 0] > 1.5], cam_center=f["cam"])
+
+
+def test_retrieval_oracle_matches_reference_fixture():
+    """tests/golden/retrieval_small.npz = the reference's RetrievalModel (oracle/make_golden.py retrieval)."""
+    from oracle import retrieval_ref as RR
+    g = load_golden("retrieval_small")
+    x = torch.randn((3, 48, 256), generator=torch.Generator().manual_seed(5))
+    for tag, pre, resid in (("full", True, False), ("resid", False, True)):
+        sd = S.make_retrieval_state_dict(256, seed=3, prewhiten=pre)
+        f, a, i = RR.forward_local(sd, x, 20, resid)
+        assert np.array_equal(i.numpy(), g[tag + "/idx"]) and np.array_equal(a.numpy(), g[tag + "/attn"])
+        assert np.array_equal(f.numpy(), g[tag + "/feat"])
+        assert np.array_equal(RR.forward_global(sd, x, resid).numpy(), g[tag + "/glob"])

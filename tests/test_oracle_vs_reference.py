@@ -196,3 +196,27 @@ def test_get_overlap_score_equals_reference_source(mode, subsamp):
         sel = f["pts3d"][0, 0][f["conf"][0, 0] > 1.5]
         tr.add_pts(torch.from_numpy(sel), cam_center=torch.from_numpy(f["cam"]))
         to.add_pts(sel, cam_center=f["cam"])
+
+
+@pytest.mark.parametrize("cfg", [dict(prewhiten=-1, postwhiten=-1), dict(prewhiten=None, postwhiten=-1, residual=True),
+                                 dict(prewhiten=None, postwhiten=None)])
+def test_retrieval_equals_reference(cfg):
+    """must3r/retrieval/model.py RetrievalModel (verbatim import) vs oracle/retrieval_ref.py: local and global paths."""
+    from oracle import ref_shims, retrieval_ref as RR
+    ref_shims.install()
+    import must3r.retrieval.model as RM
+
+    class _Backbone(torch.nn.Module):
+        embed_dim = 128
+    model = RM.RetrievalModel(_Backbone(), prewhiten=cfg.get("prewhiten"), postwhiten=cfg.get("postwhiten"), hdims=[128],
+                              residual=cfg.get("residual", False), nfeat=17).eval()
+    sd = S.make_retrieval_state_dict(128, seed=1, prewhiten=cfg.get("prewhiten") is not None, postwhiten=cfg.get("postwhiten") is not None)
+    msg = model.load_state_dict(sd, strict=False)
+    assert not msg.unexpected_keys and not [k for k in msg.missing_keys if not k.startswith("backbone")]
+    x = torch.randn((2, 40, 128), generator=torch.Generator().manual_seed(0))
+    with torch.no_grad():
+        f, a, i = model.forward_local(x)
+        g = model.forward_global(x)
+    fo, ao, io = RR.forward_local(sd, x, 17, cfg.get("residual", False))
+    go = RR.forward_global(sd, x, cfg.get("residual", False))
+    assert torch.equal(i, io) and torch.equal(a, ao) and torch.equal(f, fo) and torch.equal(g, go)
