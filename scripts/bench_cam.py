@@ -10,8 +10,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from must3r_amd import synthetic as S  # noqa: E402
 from must3r_amd.engine import postprocess  # noqa: E402
 
+pm20 = S.make_cam_pointmaps(20, 384, 512, focal=450.0, noise=0.02, seed=1).cuda()
 for V in (20, 1, 4):
-    pm = S.make_cam_pointmaps(V, 384, 512, focal=450.0, noise=0.02, seed=1).cuda()
+    pm = pm20[:V].contiguous()     # slices of one resident tensor: freeing big tensors inside the loop stalls the next timings
     for cc in (False, True):
         for _ in range(3):
             postprocess(pm, compute_cam=cc)
