@@ -53,6 +53,7 @@ struct Param {
     void* x2[2] = {nullptr, nullptr};    // [rows][hi(K) | lo(K)] layout for the split-weight GEMM, lazy
     bool loaded = false;
     bool derived = false;     // built by finalize, not loaded
+    bool optional = false;    // may legitimately be absent (feedback layer variants)
 };
 
 // softmax scale folded into q by the projection epilogues: 1/sqrt(64) * log2(e)
@@ -218,20 +219,25 @@ static int attention(must3r_hip_ctx* c, DType dt, const AttnArgs& a, double flop
 // ------------------------------------------------------------------------------------------------
 // parameters
 // ------------------------------------------------------------------------------------------------
-static void expect(must3r_hip_ctx* c, const std::string& name, std::vector<int64_t> shape) {
+static void expect(must3r_hip_ctx* c, const std::string& name, std::vector<int64_t> shape, bool optional = false) {
     Param p;
+    p.optional = optional;
     p.shape = shape;
     p.n = 1;
     for (auto d : shape) p.n *= (size_t)d;
     c->params[name] = p;
 }
-static void expect_linear(must3r_hip_ctx* c, const std::string& pfx, int64_t out, int64_t in) {
-    expect(c, pfx + ".weight", {out, in});
-    expect(c, pfx + ".bias", {out});
+static void expect_linear(must3r_hip_ctx* c, const std::string& pfx, int64_t out, int64_t in, bool optional = false) {
+    expect(c, pfx + ".weight", {out, in}, optional);
+    expect(c, pfx + ".bias", {out}, optional);
 }
-static void expect_ln(must3r_hip_ctx* c, const std::string& pfx, int64_t dim) {
-    expect(c, pfx + ".weight", {dim});
-    expect(c, pfx + ".bias", {dim});
+static void expect_ln(must3r_hip_ctx* c, const std::string& pfx, int64_t dim, bool optional = false) {
+    expect(c, pfx + ".weight", {dim}, optional);
+    expect(c, pfx + ".bias", {dim}, optional);
+}
+static bool is_loaded(must3r_hip_ctx* c, const std::string& name) {
+    auto it = c->params.find(name);
+    return it != c->params.end() && it->second.loaded;
 }
 
 static void build_expected(must3r_hip_ctx* c) {
@@ -266,9 +272,12 @@ static void build_expected(must3r_hip_ctx* c) {
         expect_linear(c, b + ".mlp.fc1", r * D, D);
         expect_linear(c, b + ".mlp.fc2", D, r * D);
     }
-    expect_linear(c, "decoder.feedback_layer.fc1", 4 * D, D);
-    expect_linear(c, "decoder.feedback_layer.fc2", D, 4 * D);
-    expect_ln(c, "decoder.feedback_norm", D);
+    // feedback_mechanism.py:11-22: 'single_mlp' (fc1/fc2 + norm), 'single_linear' (weight/bias + norm) or no feedback layer:
+    // all optional here, told apart by which keys were loaded; finalize rejects incomplete or mixed sets
+    expect_linear(c, "decoder.feedback_layer.fc1", 4 * D, D, true);
+    expect_linear(c, "decoder.feedback_layer.fc2", D, 4 * D, true);
+    expect_linear(c, "decoder.feedback_layer", D, D, true);
+    expect_ln(c, "decoder.feedback_norm", D, true);
     expect_ln(c, "decoder.norm_dec", D);
     expect_linear(c, "decoder.head_dec.proj", p * p * 7, D);
 }
@@ -434,7 +443,17 @@ extern "C" int must3r_hip_finalize_weights(must3r_hip_ctx* c, int parts) {
     for (auto& kv : c->params) {
         const bool is_enc = kv.first.compare(0, 8, "encoder.") == 0;
         if (!((is_enc && (parts & 1)) || (!is_enc && (parts & 2)))) continue;
-        if (!kv.second.loaded && !kv.second.derived) return fail("finalize: missing key '%s'", kv.first.c_str());
+        if (!kv.second.loaded && !kv.second.derived && !kv.second.optional) return fail("finalize: missing key '%s'", kv.first.c_str());
+    }
+    if (parts & 2) {
+        int mlp = 0, lin = 0, nrm = 0;
+        for (const char* k : {"decoder.feedback_layer.fc1.weight", "decoder.feedback_layer.fc1.bias", "decoder.feedback_layer.fc2.weight",
+                              "decoder.feedback_layer.fc2.bias"}) mlp += is_loaded(c, k);
+        for (const char* k : {"decoder.feedback_layer.weight", "decoder.feedback_layer.bias"}) lin += is_loaded(c, k);
+        for (const char* k : {"decoder.feedback_norm.weight", "decoder.feedback_norm.bias"}) nrm += is_loaded(c, k);
+        const bool ok = (mlp == 4 && lin == 0 && nrm == 2) || (mlp == 0 && lin == 2 && nrm == 2) || (mlp == 0 && lin == 0 && nrm == 0);
+        if (!ok) return fail("finalize: inconsistent feedback layer keys (single_mlp: fc1/fc2 + feedback_norm; single_linear: "
+                             "weight/bias + feedback_norm; none: neither)");
     }
     // RoPE table for positions up to 256 (4096-pixel side), shared by both halves
     {
@@ -815,13 +834,24 @@ extern "C" int must3r_hip_decode(must3r_hip_ctx* c, const must3r_hip_decode_args
     }
 
     if (update) {
-        // --- feedback (feedback_mechanism.py:39-53): offset = Mlp(LN_1e-5(new_mem[L-1])), added to layers 0..L-2
-        M3R_OK(layernorm(c, dt, newmem + (size_t)(L - 1) * R * D, nullptr, p32(c, "decoder.feedback_norm.weight"),
-                         p32(c, "decoder.feedback_norm.bias"), h16, nullptr, nullptr, nullptr, R, D, 1e-5f, s));
-        M3R_OK(w16(c, "decoder.feedback_layer.fc1.weight", dt, &w, s));
-        M3R_OK(gemm(c, dt, EPI_STORE16_GELU, gargs(h16, w, p32(c, "decoder.feedback_layer.fc1.bias"), g16, R, 4 * D, D, D, 4 * D), s));
-        M3R_OK(w16(c, "decoder.feedback_layer.fc2.weight", dt, &w, s));
-        M3R_OK(gemm(c, dt, EPI_F32, gargs(g16, w, p32(c, "decoder.feedback_layer.fc2.bias"), off32, R, D, 4 * D, 4 * D, D), s));
+        // --- feedback (feedback_mechanism.py:39-53): offset = layer(LN_1e-5(new_mem[L-1])), added to layers 0..L-2;
+        //     layer = Mlp ('single_mlp'), Linear ('single_linear') or nothing (feedback_type None: no offset)
+        const bool fb_mlp = is_loaded(c, "decoder.feedback_layer.fc1.weight");
+        const bool fb_lin = !fb_mlp && is_loaded(c, "decoder.feedback_layer.weight");
+        if (fb_mlp || fb_lin)
+            M3R_OK(layernorm(c, dt, newmem + (size_t)(L - 1) * R * D, nullptr, p32(c, "decoder.feedback_norm.weight"),
+                             p32(c, "decoder.feedback_norm.bias"), h16, nullptr, nullptr, nullptr, R, D, 1e-5f, s));
+        if (fb_mlp) {
+            M3R_OK(w16(c, "decoder.feedback_layer.fc1.weight", dt, &w, s));
+            M3R_OK(gemm(c, dt, EPI_STORE16_GELU, gargs(h16, w, p32(c, "decoder.feedback_layer.fc1.bias"), g16, R, 4 * D, D, D, 4 * D), s));
+            M3R_OK(w16(c, "decoder.feedback_layer.fc2.weight", dt, &w, s));
+            M3R_OK(gemm(c, dt, EPI_F32, gargs(g16, w, p32(c, "decoder.feedback_layer.fc2.bias"), off32, R, D, 4 * D, 4 * D, D), s));
+        } else if (fb_lin) {
+            M3R_OK(w16(c, "decoder.feedback_layer.weight", dt, &w, s));
+            M3R_OK(gemm(c, dt, EPI_F32, gargs(h16, w, p32(c, "decoder.feedback_layer.bias"), off32, R, D, D, D, D), s));
+        } else {
+            off32 = nullptr;
+        }
         // --- stored memory = prepare_y(new_mem + offset) (decoder.py:236-239 / :327-330)
         if (mode == MUST3R_MEM_KV) {
             // the L projections are independent: ONE grouped LayerNorm over [L*R, D] (per-layer affine, offset on layers

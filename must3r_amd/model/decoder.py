@@ -63,9 +63,8 @@ class MUSt3R(HipModule):
         assert memory_mode in MEMORY_MODES
         if head != "Linear":
             raise ValueError(f"invalid head {head}")  # decoder.py:80
-        if feedback_type != "single_mlp":
-            raise NotImplementedError("must3r_amd implements feedback_type='single_mlp' (the released checkpoints); "
-                                      f"got {feedback_type!r}")
+        if feedback_type not in ("single_mlp", "single_linear", None, "", False):
+            raise ValueError(f"Unknown {feedback_type=}")   # feedback_mechanism.py:18-19 asserts on anything else
         assert output_dim == patch_size * patch_size * 7
         self.pointmaps_activation = pointmaps_activation
         self.depth = depth
@@ -81,14 +80,26 @@ class MUSt3R(HipModule):
         self.feat_embed_enc_to_dec = nn.Linear(enc_embed_dim, embed_dim, bias=True)
         self.image2_embed = nn.Parameter(torch.zeros(1, 1, embed_dim))
         self.blocks_dec = nn.ModuleList([DecBlockParams(embed_dim, mlp_ratio, memory_mode) for _ in range(depth)])
-        self.feedback_layer = MlpParams(embed_dim, 4 * embed_dim, embed_dim)
-        self.feedback_norm = nn.LayerNorm(embed_dim)  # default eps 1e-5 (feedback_mechanism.py:14)
+        # feedback_mechanism.py:11-22 create_feedback_layers
+        if feedback_type == "single_mlp":
+            self.feedback_layer = MlpParams(embed_dim, 4 * embed_dim, embed_dim)
+            self.feedback_norm = nn.LayerNorm(embed_dim)  # default eps 1e-5 (feedback_mechanism.py:14)
+        elif feedback_type == "single_linear":
+            self.feedback_layer = nn.Linear(embed_dim, embed_dim)
+            self.feedback_norm = nn.LayerNorm(embed_dim)
+        else:
+            self.feedback_layer = None
+            self.feedback_norm = None
         self.norm_dec = nn.LayerNorm(embed_dim, eps=1e-6)
         self.head_dec = LinearHeadParams(embed_dim, output_dim, patch_size)
         init_weights(self)
         torch.nn.init.normal_(self.image2_embed, std=0.02)
-        nn.init.constant_(self.feedback_layer.fc2.bias, 0)    # feedback_mechanism.py:26-36
-        nn.init.constant_(self.feedback_layer.fc2.weight, 0)
+        if feedback_type == "single_mlp":                      # feedback_mechanism.py:26-36: inactive at the start
+            nn.init.constant_(self.feedback_layer.fc2.bias, 0)
+            nn.init.constant_(self.feedback_layer.fc2.weight, 0)
+        elif feedback_type == "single_linear":
+            nn.init.constant_(self.feedback_layer.bias, 0)
+            nn.init.constant_(self.feedback_layer.weight, 0)
         self._hip_init(ModelConfig(img_size=max(img_size), patch_size=patch_size, enc_dim=enc_embed_dim,
                                    enc_heads=enc_embed_dim // 64, dec_dim=embed_dim, dec_depth=depth, dec_heads=num_heads,
                                    mlp_ratio=mlp_ratio, rope_freq=freq, rope_f0=f0), precision)

@@ -58,7 +58,7 @@ def make_encoder_state_dict(cfg: ModelConfig, seed: int = 0):
     return sd
 
 
-def make_decoder_state_dict(cfg: ModelConfig, seed: int = 0):
+def make_decoder_state_dict(cfg: ModelConfig, seed: int = 0, feedback_type="single_mlp"):
     g = torch.Generator().manual_seed(seed + 7919)
     sd = {}
     C, D = cfg.enc_dim, cfg.dec_dim
@@ -76,10 +76,17 @@ def make_decoder_state_dict(cfg: ModelConfig, seed: int = 0):
         _ln(g, sd, b + ".norm3", D)
         _linear(g, sd, b + ".mlp.fc1", cfg.mlp_ratio * D, D)
         _linear(g, sd, b + ".mlp.fc2", D, cfg.mlp_ratio * D)
-    _linear(g, sd, "feedback_layer.fc1", 4 * D, D)
-    sd["feedback_layer.fc2.weight"] = torch.randn((D, 4 * D), generator=g) * 0.02
-    sd["feedback_layer.fc2.bias"] = _bias(g, D)
-    _ln(g, sd, "feedback_norm", D)
+    if feedback_type == "single_mlp":
+        _linear(g, sd, "feedback_layer.fc1", 4 * D, D)
+        sd["feedback_layer.fc2.weight"] = torch.randn((D, 4 * D), generator=g) * 0.02
+        sd["feedback_layer.fc2.bias"] = _bias(g, D)
+        _ln(g, sd, "feedback_norm", D)
+    elif feedback_type == "single_linear":      # feedback_mechanism.py:15-17
+        sd["feedback_layer.weight"] = torch.randn((D, D), generator=g) * 0.02
+        sd["feedback_layer.bias"] = _bias(g, D)
+        _ln(g, sd, "feedback_norm", D)
+    else:
+        assert not feedback_type
     _ln(g, sd, "norm_dec", D)
     _linear(g, sd, "head_dec.proj", cfg.output_dim, D)
     return sd

@@ -272,9 +272,15 @@ def decoder_forward(sd, cfg, x, pos, true_shape, current_mem=None, render=False,
             feats[g].append(cur[g].reshape(1, nimgs[g], Ns[g], D))
     if not render:
         # run_feedback_layers feedback_mechanism.py:39-53
-        fb = layer_norm(new_mem[-1], sd["feedback_norm.weight"], sd["feedback_norm.bias"], 1e-5)
-        offset = mlp(sd, "feedback_layer", fb, opq)
-        new_mem = [m + offset for m in new_mem[:-1]] + [new_mem[-1]]
+        if "feedback_layer.fc1.weight" in sd:          # 'single_mlp' (feedback_mechanism.py:12-14)
+            fb = layer_norm(new_mem[-1], sd["feedback_norm.weight"], sd["feedback_norm.bias"], 1e-5)
+            offset = mlp(sd, "feedback_layer", fb, opq)
+            new_mem = [m + offset for m in new_mem[:-1]] + [new_mem[-1]]
+        elif "feedback_layer.weight" in sd:           # 'single_linear' (:15-17)
+            fb = layer_norm(new_mem[-1], sd["feedback_norm.weight"], sd["feedback_norm.bias"], 1e-5)
+            offset = linear(fb, sd["feedback_layer.weight"], sd["feedback_layer.bias"], opq)
+            new_mem = [m + offset for m in new_mem[:-1]] + [new_mem[-1]]
+        # else: no feedback layer, run_feedback_layers returns mem unchanged (:45-46)
         mem_out = [torch.cat((mem_vals[l], prepare_y(sd, f"blocks_dec.{l}", new_mem[l], memory_mode, opq)), dim=1)
                    for l in range(cfg.dec_depth)]  # decoder.py:236-239 / :327-330
         labels = []

@@ -236,7 +236,7 @@ def import_reference_model(reference_root=REFERENCE_ROOT):
     return ref_model
 
 
-def build_reference(cfg, sd_enc, sd_dec, memory_mode="kv"):
+def build_reference(cfg, sd_enc, sd_dec, memory_mode="kv", feedback_type="single_mlp"):
     """Reference constructors (encoder.py:13, decoder.py:14) for ``cfg`` (must3r_amd.config.ModelConfig),
     loaded ``strict=True`` with the given state dicts -- which also pins the state-dict key contract
     of SURVEY.md section 8b."""
@@ -245,7 +245,7 @@ def build_reference(cfg, sd_enc, sd_dec, memory_mode="kv"):
                             embed_dim=cfg.enc_dim, depth=cfg.enc_depth, num_heads=cfg.enc_heads)
     dec = ref.MUSt3R(img_size=(cfg.img_size, cfg.img_size), enc_embed_dim=cfg.enc_dim,
                      patch_size=cfg.patch_size, embed_dim=cfg.dec_dim, output_dim=cfg.output_dim,
-                     depth=cfg.dec_depth, num_heads=cfg.dec_heads, feedback_type="single_mlp",
+                     depth=cfg.dec_depth, num_heads=cfg.dec_heads, feedback_type=feedback_type,
                      memory_mode=memory_mode, landscape_only=False)
     enc.load_state_dict(sd_enc, strict=True)
     dec.load_state_dict(sd_dec, strict=True)

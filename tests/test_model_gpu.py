@@ -385,3 +385,31 @@ def test_full_size_scene_properties():
     # two identical runs: bit-identical (no atomics / run-to-run nondeterminism anywhere on the path)
     out2 = run_scene(enc, dec, imgs_c, ts_c)
     assert torch.equal(out2["render"], out["render"]) and torch.equal(out2["update"], out["update"])
+
+
+@pytest.mark.parametrize("fb", ["single_linear", None])
+def test_feedback_types_vs_oracle(fb):
+    """feedback_mechanism.py:11-22: the two feedback variants besides 'single_mlp' (update + update + render, kv memory)."""
+    from oracle import must3r_ref as R
+    from must3r_amd.model import Dust3rEncoder, MUSt3R
+    cfg = TINY
+    sde, sdd = S.make_encoder_state_dict(cfg, 0), S.make_decoder_state_dict(cfg, 0, feedback_type=fb)
+    enc, _ = build(cfg, "fp16w2")
+    dec = MUSt3R(img_size=(cfg.img_size, cfg.img_size), enc_embed_dim=cfg.enc_dim, patch_size=cfg.patch_size, embed_dim=cfg.dec_dim,
+                 output_dim=cfg.output_dim, depth=cfg.dec_depth, num_heads=cfg.dec_heads, feedback_type=fb, memory_mode="kv",
+                 landscape_only=False, precision="fp16w2").cuda().eval()
+    dec.load_state_dict(sdd, strict=True)
+    imgs, ts = S.make_images(3, 48, 64, 1)
+    x, pos = enc(imgs.cuda(), ts.cuda())
+    tsc = ts.cuda()
+    mem, pm = dec(x[:2].unsqueeze(0), pos[:2].unsqueeze(0), tsc[:2].unsqueeze(0), None)
+    mem, pm2 = dec(x[2:].unsqueeze(0), pos[2:].unsqueeze(0), tsc[2:].unsqueeze(0), mem)
+    _, ren = dec(x.unsqueeze(0), pos.unsqueeze(0), tsc.unsqueeze(0), mem, render=True)
+    with torch.no_grad():
+        xo, po = R.encoder_forward(sde, cfg, imgs, ts)
+        memo, pmo = R.decoder_forward(sdd, cfg, xo[:2].unsqueeze(0), po[:2].unsqueeze(0), ts[:2].unsqueeze(0), None, False, "kv")
+        memo, pmo2 = R.decoder_forward(sdd, cfg, xo[2:].unsqueeze(0), po[2:].unsqueeze(0), ts[2:].unsqueeze(0), memo, False, "kv")
+        _, reno = R.decoder_forward(sdd, cfg, xo.unsqueeze(0), po.unsqueeze(0), ts.unsqueeze(0), memo, True, "kv")
+    errs = [rel_inf(pm.cpu(), pmo), rel_inf(pm2.cpu(), pmo2), rel_inf(ren.cpu(), reno)]
+    record("feedback_types", fb=str(fb), errs=errs)
+    assert max(errs) < TOL["fp16w2"], errs

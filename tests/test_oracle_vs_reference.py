@@ -220,3 +220,22 @@ def test_retrieval_equals_reference(cfg):
     fo, ao, io = RR.forward_local(sd, x, 17, cfg.get("residual", False))
     go = RR.forward_global(sd, x, cfg.get("residual", False))
     assert torch.equal(i, io) and torch.equal(a, ao) and torch.equal(f, fo) and torch.equal(g, go)
+
+
+@pytest.mark.parametrize("fb", ["single_linear", None])
+def test_feedback_types_equal_reference(fb):
+    """feedback_mechanism.py:11-22,39-53: 'single_linear' and no feedback layer (the released checkpoints use 'single_mlp')."""
+    from oracle import ref_shims, must3r_ref as R
+    cfg = TINY
+    sde, sdd = S.make_encoder_state_dict(cfg, 0), S.make_decoder_state_dict(cfg, 0, feedback_type=fb)
+    enc, dec = ref_shims.build_reference(cfg, sde, sdd, "kv", feedback_type=fb)
+    imgs, ts = S.make_images(3, 48, 64, 1)
+    with torch.no_grad():
+        x, pos = enc(imgs, ts)
+        mem, pm = dec(x[:2].unsqueeze(0), pos[:2].unsqueeze(0), ts[:2].unsqueeze(0), None)
+        mem, pm2 = dec(x[2:].unsqueeze(0), pos[2:].unsqueeze(0), ts[2:].unsqueeze(0), mem)
+        memo, pmo = R.decoder_forward(sdd, cfg, x[:2].unsqueeze(0), pos[:2].unsqueeze(0), ts[:2].unsqueeze(0), None, False, "kv")
+        memo, pmo2 = R.decoder_forward(sdd, cfg, x[2:].unsqueeze(0), pos[2:].unsqueeze(0), ts[2:].unsqueeze(0), memo, False, "kv")
+    assert rel_inf(pmo, pm) < 2e-5 and rel_inf(pmo2, pm2) < 2e-5
+    for a, b in zip(memo[0], mem[0]):
+        assert rel_inf(a, b) < 2e-5
