@@ -39,16 +39,9 @@ template <class T> __device__ __forceinline__ typename Vec<T>::v8 cvt8(f32x8 v) 
     return __builtin_convertvector(v, typename Vec<T>::v8);
 }
 
-// LDS transposed read: each lane passes the address of its own 8-byte (4 x 16-bit) chunk; inside a
-// 16-lane group the 16 chunks form a 4 x 16 row-major matrix X (chunk m = row m>>2, cols 4*(m&3)..+3)
-// and lane i of the group receives column i: {X[0][i], X[1][i], X[2][i], X[3][i]}.
-template <class T> __device__ __forceinline__ typename Vec<T>::v4 lds_read_tr4(const T* p) {
-    s16x4 r = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p));
-    typename Vec<T>::v4 o;
-    __builtin_memcpy(&o, &r, 8);
-    return o;
-}
-
+// LDS transposed read (ds_read_b64_tr_b16): each lane passes the address of its own 8-byte (4 x 16-bit) chunk; inside a
+// 16-lane group the 16 chunks form a 4 x 16 row-major matrix X (chunk m = row m>>2, cols 4*(m&3)..+3) and lane i of the
+// group receives column i: {X[0][i], X[1][i], X[2][i], X[3][i]}  (checked on hardware: must3r_hip_debug_tr_probe).
 // Eight transposing reads (one 32-key slot of V^T: 4 d-fragments x {keys 0-15, keys 16-31}) issued from inline asm
 // together with their own lgkmcnt(0).  hipcc orders the builtin form behind every in-flight LDS-DMA (it emits
 // s_waitcnt vmcnt(0) before it), which would drain the next tile's prefetch in the middle of the current tile; the
