@@ -3,7 +3,7 @@
 // keyframe (nns.py:47-50: O(n log n) per keyframe on the host) and queries it with 4 workers (nns.py:56); here the
 // database simply stays in HBM and a query is an exact brute-force scan:
 //
-//   nn_query_kernel      d2[i] = min_j |q_i - db_j|^2   (fp32; 3 sub + 1 mul + 2 fma + 1 min per pair)
+//   nn_query_kernel      d2[i] = min_j |q_i - db_j|^2   (fp32; 3 sub + 1 mul + 2 fma + 1 min per pair, packed two pairs wide)
 //                        block = 256 threads x 4 queries; the database is streamed through LDS in tiles of 2048
 //                        points repacked to float4 (one broadcast ds_read_b128 per point serves 4 x 64 x 4 pairs);
 //                        the grid is (query blocks) x (database splits) so that a 12 k-point query batch still fills
@@ -28,16 +28,30 @@ __global__ void __launch_bounds__(NN_T) nn_query_kernel(const float* __restrict_
     const long long q0 = (long long)blockIdx.x * (NN_T * NN_QPT);
     const long long j_begin = (long long)blockIdx.y * chunk;
     const long long j_end = j_begin + chunk < n_db ? j_begin + chunk : n_db;
-    float qx[NN_QPT], qy[NN_QPT], qz[NN_QPT], best[NN_QPT];
+    // queries in PAIRS: v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32 do two (query, point) pairs per instruction
+    // (3 + 1 + 2 packed ops + 2 v_min_f32 per two pairs = 4 VALU per pair instead of 7)
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    f32x2 qx[NN_QPT / 2], qy[NN_QPT / 2], qz[NN_QPT / 2];
+    float best[NN_QPT];
 #pragma unroll
     for (int k = 0; k < NN_QPT; ++k) {
         long long i = q0 + (long long)k * NN_T + threadIdx.x;     // consecutive threads -> consecutive points
         i = i < n_q ? i : n_q - 1;
-        qx[k] = q[i * 3 + 0];
-        qy[k] = q[i * 3 + 1];
-        qz[k] = q[i * 3 + 2];
+        qx[k >> 1][k & 1] = q[i * 3 + 0];
+        qy[k >> 1][k & 1] = q[i * 3 + 1];
+        qz[k >> 1][k & 1] = q[i * 3 + 2];
         best[k] = INFINITY;
     }
+    auto visit = [&](const f32x4 p) {
+        const f32x2 px = {p[0], p[0]}, py = {p[1], p[1]}, pz = {p[2], p[2]};
+#pragma unroll
+        for (int h = 0; h < NN_QPT / 2; ++h) {
+            const f32x2 dx = qx[h] - px, dy = qy[h] - py, dz = qz[h] - pz;
+            const f32x2 d2 = __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dy, dy, dx * dx));
+            best[2 * h] = fminf(best[2 * h], d2[0]);
+            best[2 * h + 1] = fminf(best[2 * h + 1], d2[1]);
+        }
+    };
     for (long long j0 = j_begin; j0 < j_end; j0 += NN_TILE) {
         const int n = (int)(j_end - j0 < NN_TILE ? j_end - j0 : NN_TILE);
         __syncthreads();
@@ -49,23 +63,9 @@ __global__ void __launch_bounds__(NN_T) nn_query_kernel(const float* __restrict_
         int t = 0;
         for (; t + 4 <= n; t += 4) {
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const f32x4 p = tile[t + u];
-#pragma unroll
-                for (int k = 0; k < NN_QPT; ++k) {
-                    const float dx = qx[k] - p[0], dy = qy[k] - p[1], dz = qz[k] - p[2];
-                    best[k] = fminf(best[k], fmaf(dz, dz, fmaf(dy, dy, dx * dx)));
-                }
-            }
+            for (int u = 0; u < 4; ++u) visit(tile[t + u]);
         }
-        for (; t < n; ++t) {
-            const f32x4 p = tile[t];
-#pragma unroll
-            for (int k = 0; k < NN_QPT; ++k) {
-                const float dx = qx[k] - p[0], dy = qy[k] - p[1], dz = qz[k] - p[2];
-                best[k] = fminf(best[k], fmaf(dz, dz, fmaf(dy, dy, dx * dx)));
-            }
-        }
+        for (; t < n; ++t) visit(tile[t]);
     }
 #pragma unroll
     for (int k = 0; k < NN_QPT; ++k) {
