@@ -19,6 +19,10 @@
 
 namespace m3r {
 
+#ifdef GEMM_TRACE
+__device__ unsigned long long g_gemm_trace[64 * 8];   // scripts/probes/gemm_trace.hip: cycle stamps of block 0 / thread 0
+#endif
+
 // One output row segment of a lane: v[j][r] = C[m][n = nw0 + j*16 + fg*4 + r] before bias; nw0 = first column of the wave tile.
 // Shared by every tile geometry so that all of them round identically (built with -ffp-contract=off).
 template <class T, int EPI, int NF>
@@ -267,17 +271,26 @@ __global__ void __launch_bounds__(64 * WGM * WGN) gemm_kernel(const GemmArgs p) 
         load_frags(0, 0);
         int buf = 0;
         // two iterations per trip so that the fragment set index is a compile-time constant (registers, not scratch)
+#ifdef GEMM_TRACE
+#define M3R_STAMP(slot) do { if (blockIdx.x == 0 && tid == 0 && kt < 64) g_gemm_trace[kt * 8 + (slot)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define M3R_STAMP(slot) do { } while (0)
+#endif
         auto body = [&](auto curc, int kt) {
             constexpr int cur = decltype(curc)::value;
             const int nbuf = buf + 1 == NST ? 0 : buf + 1;
+            M3R_STAMP(0);
             if (kt + 1 < nk) wait_dma(nk - 2 - kt < NST - 3 ? nk - 2 - kt : NST - 3);
+            M3R_STAMP(1);
             __builtin_amdgcn_s_barrier();
+            M3R_STAMP(2);
             const int nt = kt + NST - 1;
             if (nt < nk) {
                 int sb = buf + NST - 1;
                 sb = sb >= NST ? sb - NST : sb;
                 stage(nt, sb);                          // buffer of tile kt-1
             }
+            M3R_STAMP(3);
             // Fragments of tile kt were read one iteration ago.  "Using" them here makes the compiler place its own wait for
             // them BEFORE the next tile's reads are issued; with an opaque inline s_waitcnt it keeps treating the
             // loop-carried registers as pending and drains the new reads as well (lgkmcnt(0)) in front of the MFMAs.
@@ -290,7 +303,9 @@ __global__ void __launch_bounds__(64 * WGM * WGN) gemm_kernel(const GemmArgs p) 
 #pragma unroll
                 for (int i = 0; i < MF; ++i) asm volatile("" ::"v"(fa[cur][ks][i]));
             }
+            M3R_STAMP(4);
             if (kt + 1 < nk) load_frags(cur ^ 1, nbuf);
+            M3R_STAMP(5);
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -299,6 +314,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN) gemm_kernel(const GemmArgs p) 
                     for (int i = 0; i < MF; ++i)
 #pragma unroll
                         for (int j = 0; j < NF; ++j) acc[i][j] = mfma16(fw[cur][ks][part][j], fa[cur][ks][i], acc[i][j]);
+            M3R_STAMP(6);
             buf = nbuf;
         };
         int kt = 0;
@@ -552,6 +568,136 @@ static int launch_256(const GemmArgs& a, hipStream_t s) {
     return hipGetLastError() == hipSuccess ? 0 : 1;
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// M = 768 launches with N = 768 (proj, fc2, projq of the memory update): 48 x 48 tiles = exactly 256 blocks, ONE per CU,
+// 9 waves (3 x 3, wave tile 16 x 16).  A cycle trace of the 64 x 64 kernels (scripts/probes/gemm_trace.hip) shows where a
+// K-tile's 0.35 us go: every wave spends ~250 cycles ISSUING its three 1 KB LDS-DMA instructions (~80 cycles each), ~270
+// on its ten ds_read_b128 and only ~130 on its eight MFMAs -- per-wave instruction issue, in lock step, not bandwidth.
+// With 144 tiles of 64 x 64 the other 112 CUs idle; 48 x 48 tiles put all 256 CUs to work with 2 DMA + 6 LDS reads + 4
+// MFMAs per wave and K-tile.  Measured (split weights, M = N = 768): proj 8.0 -> 6.9 us, fc2 20.6 -> 18.9 us, same bits.
+// (The K-loop slope stays ~0.33 us per tile even here, so per-wave issue is not the whole story either; the gain is in
+// the fixed part.)  Split weights only: with plain weights the 12 pieces do not divide evenly over 9 waves.
+template <class T, int EPI, int WS, int NST>
+__global__ void __launch_bounds__(576) gemm48_kernel(const GemmArgs p) {
+    typedef typename Vec<T>::v8 v8;
+    constexpr int BM = 48, BN = 48, BK = 64, NW = 9, RPP = 8;
+    constexpr int ROWS = BM + WS * BN;                 // staging region: A rows, then W rows (hi, then lo)
+    static_assert((ROWS / RPP) % NW == 0, "every wave must issue the same number of DMA pieces per tile (counted vmcnt)");
+    constexpr int NPIECE = ROWS / RPP;                 // 18 (split) or 12 (plain)
+    constexpr int STAGE = ROWS * BK;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    T* const lds = reinterpret_cast<T*>(smem);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / 3, wn = wave - wm * 3;
+    const int nbn = p.N / BN;
+    const int nbm = (p.M + BM - 1) / BM;
+    const int nwg = nbm * nbn;
+    int bid = blockIdx.x;
+    {
+        const int xcd = bid & 7, slot = bid >> 3;
+        const int q = nwg >> 3, r = nwg & 7;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+    }
+    const int m0 = (bid % nbm) * BM;                    // row-block fastest: the blocks of an XCD share weight panels
+    const int n0 = (bid / nbm) * BN;
+    const int grp = blockIdx.y;
+    const T* __restrict__ A = reinterpret_cast<const T*>(p.A) + (size_t)grp * p.strideA;
+    const T* __restrict__ W = reinterpret_cast<const T*>(p.W) + (size_t)grp * p.strideW;
+    const float* __restrict__ bias = p.bias ? p.bias + (size_t)grp * p.strideB : nullptr;
+    void* const outp = p.out_table ? p.out_table[grp] : p.out;
+
+    // pieces dealt round-robin: piece = t * NW + wave (split weights: 18 pieces, 2 per wave)
+    constexpr int TMAX = (NPIECE + NW - 1) / NW;
+    const int srow = lane >> 3, pch = lane & 7;
+    const T* src[TMAX];
+    bool has[TMAX];
+#pragma unroll
+    for (int t = 0; t < TMAX; ++t) {
+        const int piece = t * NW + wave;
+        has[t] = piece < NPIECE;
+        const int r = (has[t] ? piece : 0) * RPP + srow;
+        if (r < BM) {
+            int gr = m0 + r;
+            gr = gr < p.M ? gr : p.M - 1;
+            src[t] = A + (size_t)gr * p.lda + swz(r, pch) * 8;
+        } else {
+            const int rr = r - BM, part = rr / BN, wrow = rr - part * BN;
+            src[t] = W + (size_t)(n0 + wrow) * (size_t)(p.K * WS) + (size_t)part * p.K + swz(rr, pch) * 8;
+        }
+    }
+    auto stage = [&](int kt, int buf) {
+        T* base = lds + buf * STAGE;
+#pragma unroll
+        for (int t = 0; t < TMAX; ++t)
+            if (has[t]) glds16(src[t] + kt * BK, base + (t * NW + wave) * RPP * BK);
+    };
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const int fr = lane & 15, fg = lane >> 4;
+    const int nk = p.K / BK;
+    int a_off[2], w_off[2][WS];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        const int r = wm * 16 + fr;
+        a_off[ks] = r * BK + swz(r, ks * 4 + fg) * 8;
+#pragma unroll
+        for (int part = 0; part < WS; ++part) {
+            const int rr = part * BN + wn * 16 + fr;
+            w_off[ks][part] = (BM + rr) * BK + swz(rr, ks * 4 + fg) * 8;
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < NST - 1; ++t)
+        if (t < nk) stage(t, t);
+    int buf = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        // tile kt landed: at most NST-2 younger tiles x TMAX loads may still be in flight (tail: drain)
+        if (kt + NST - 2 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * TMAX) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        const int nt = kt + NST - 1;
+        if (nt < nk) {
+            int nb = buf + NST - 1;
+            nb = nb >= NST ? nb - NST : nb;
+            stage(nt, nb);
+        }
+        const T* base = lds + buf * STAGE;
+        v8 af[2], wf[2][WS];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            af[ks] = *reinterpret_cast<const v8*>(base + a_off[ks]);
+#pragma unroll
+            for (int part = 0; part < WS; ++part) wf[ks][part] = *reinterpret_cast<const v8*>(base + w_off[ks][part]);
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int part = 0; part < WS; ++part) acc = mfma16(wf[ks][part], af[ks], acc);
+        buf = buf + 1 == NST ? 0 : buf + 1;
+    }
+    const int m = m0 + wm * 16 + fr;
+    if (m < p.M) {
+        f32x4 v[1] = {acc};
+        epilogue_row<T, EPI, 1>(p, outp, bias, m, n0 + wn * 16, fg, v);
+    }
+}
+
+template <class T, int EPI, int WS>
+static int launch_48(const GemmArgs& a, hipStream_t s) {
+    constexpr int NST = 6;
+    const int nbn = a.N / 48, nbm = (a.M + 47) / 48;
+    const size_t lds = (size_t)NST * (48 + WS * 48) * 64 * sizeof(T);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm48_kernel<T, EPI, WS, NST>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((gemm48_kernel<T, EPI, WS, NST>), dim3(nbm * nbn, a.batch > 1 ? a.batch : 1), dim3(576), lds, s, a);
+    return hipGetLastError() == hipSuccess ? 0 : 1;
+}
+
 // Tile selection (measured on MI355X, scripts/bench_gemm.py): two resident blocks per CU beat every larger tile that
 // leaves one (128x128 3-stage, 256x128 with 4 or 8 waves: 465-613 TF/s vs 644 TF/s on the scene's big-batch shapes).
 //   plain weights : 128x128x64, 2 stages (64 KB)  for chip-filling grids, 64x64x64 4-stage ring (64 KB) otherwise
@@ -589,6 +735,17 @@ static bool small8(long tiles64) { return tiles64 <= 256; }
 #ifndef SMALL8_NST_PLAIN
 #define SMALL8_NST_PLAIN 8   // 8 x 16 KB = 128 KB
 #endif
+
+static bool use_48(const GemmArgs& a, long nb) {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("M3R_GEMM48");
+        v = e ? atoi(e) : 1;
+    }
+    if (!v || a.N % 48 || a.K % 64 || a.rope_tab != nullptr) return false;
+    const long tiles = (long)((a.M + 47) / 48) * (a.N / 48) * nb;
+    return tiles <= 256 && tiles >= 192;
+}
 
 // M3R_GEMM256: 0 = never use the 8-wave kernel, 1 = by the fill rule below (default), 2 = whenever the shape allows it
 static int gemm256_mode() {
@@ -630,7 +787,8 @@ static int launch_epi(const GemmArgs& a, hipStream_t s, const char** err) {
                 if (ok256 && t256 >= 200 && fill256(t256) >= 80) pick = 256;
                 else if (ok128 && t128 >= 200 && fill256(t128) >= 80) pick = 128;
             }
-            if (pick == 256) rc = launch_256<T, EPI, 2, 256>(a, s);
+            if (EPI != EPI_QKV_ROPE && EPI != EPI_HEAD && use_48(a, nb)) rc = launch_48<T, EPI == EPI_QKV_ROPE || EPI == EPI_HEAD ? EPI_STORE16 : EPI, 2>(a, s);
+            else if (pick == 256) rc = launch_256<T, EPI, 2, 256>(a, s);
             else if (pick == 128) rc = launch_256<T, EPI, 2, 128>(a, s);
             else if (tiles >= min_big(true)) rc = launch_cfg<T, 128, 64, 2, 2, EPI, 2, 2>(a, s);
             else if (small8((long)((a.M + 63) / 64) * (a.N / 64) * nb)) rc = launch_cfg<T, 64, 64, SMALL_WGM, 2, EPI, SMALL8_NST_SPLIT, 2, 64, 1>(a, s);

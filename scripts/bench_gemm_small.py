@@ -14,6 +14,7 @@ if os.environ.get("STRIDE_EXP"):   # L2-channel camping check: same shapes with 
               ("proj K832", 768, 768, 832, lib.EPI_RESID_F32), ("proj K704", 768, 768, 704, lib.EPI_RESID_F32),
               ("fc1 K768", 768, 3072, 768, lib.EPI_STORE16_GELU), ("fc1 K832", 768, 3072, 832, lib.EPI_STORE16_GELU)]
 tot = 0
+torch.manual_seed(0)
 for name, M, N, K, epi in shapes:
     A = torch.randn((M, K), device="cuda").half()
     W = (torch.randn((N, K * (2 if split else 1)), device="cuda") / math.sqrt(K)).half()
@@ -21,6 +22,10 @@ for name, M, N, K, epi in shapes:
     out = torch.zeros((M, N), device="cuda", dtype=torch.float32 if epi == lib.EPI_RESID_F32 else torch.float16)
     def run():
         lib.check(L.must3r_hip_op_gemm(1, epi, P(A), P(W), P(b), P(out), M, N, K, K, N, None, None, 0, 0, None, 0, 0, 0, 0, 0, 0, 2 if split else 0, st))
+    if os.environ.get("M3R_CHECK"):   # digest of the output bits (compare kernels across env settings)
+        import hashlib
+        out.zero_(); run(); torch.cuda.synchronize()
+        print("   sha", name, hashlib.sha1(out.view(torch.int16 if out.element_size() == 2 else torch.int32).cpu().numpy().tobytes()).hexdigest()[:12])
     for _ in range(5): run()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
