@@ -174,7 +174,7 @@ def main():
     # "big tile" = the chip-filling launches: gemm256_kernel (8 waves, 256-row tiles) where its rounds fill, else the 128-row tile
     kern = {"attn_kernel": (["attn_self", "attn_cross"], ("attn_kernel",)),
             "gemm_kernel<big tile>": (["gemm128"], ("gemm256_kernel", big)),
-            "gemm_kernel<64x64 ring>": (["gemm64"], ("Li64ELi64E",))}
+            "gemm_kernel<64x64 ring>": (["gemm64"], ("Li64ELi64E", "gemm48_kernel"))}   # small-M launches (incl. the 48x48 form)
     try:
         import glob
         pmc = json.load(open(sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))[-1]))["kernels"]
