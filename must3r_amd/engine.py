@@ -136,6 +136,8 @@ def run_scene(encoder, decoder, imgs, true_shape, mem_batches=None, render_bs=No
     mem = None
     upd = []
     i = 0
+    if imgs.is_cuda and hasattr(decoder, "reserve_memory_tokens"):
+        decoder.reserve_memory_tokens = sum(mem_batches) * ((imgs.shape[-2] // 16) * (imgs.shape[-1] // 16))   # final memory size
     for nb in mem_batches:
         if ready is not None:
             for ev in {ready[j] for j in range(i, i + nb)} - {None}:

@@ -73,6 +73,8 @@ def run_scene_sharded(encoder, decoder, imgs_local, true_shape_local, keyframe_l
         raise ValueError("run_scene_sharded: no keyframe on any rank")
     mem = None
     i = 0
+    if hasattr(decoder, "reserve_memory_tokens"):
+        decoder.reserve_memory_tokens = K * kx.shape[1]     # final memory size: no growth copies
     for nb in (mem_batches or demo_mem_batches(K)):
         mem, _ = decoder(kx[i:i + nb].unsqueeze(0), kpos[i:i + nb].unsqueeze(0), kts[i:i + nb].unsqueeze(0), mem)
         i += nb
