@@ -173,6 +173,39 @@ class MUSt3R(HipModule):
         xs = list(x) if is_list else [x]
         poss = list(pos) if is_list else [pos]
         shapes = list(true_shape) if is_list else [true_shape]
+        B = int(xs[0].shape[0])
+        if B == 1:
+            out, outs, feats = self._forward_scene(xs, poss, shapes, current_mem, render, return_feats)
+        else:
+            # B > 1 (training-style batches; every inference caller of the reference uses B = 1): the scenes of a batch
+            # never interact -- memory, labels and attention are all per batch element (decoder.py:158-350) -- so a
+            # batch is B independent native calls whose results are stacked.  Each scene gets its own memory buffers;
+            # the stacked copy is what the caller holds, so the in-place append of the B = 1 path does not apply.
+            assert all(int(t.shape[0]) == B for t in xs + poss), "all groups must share the batch size"
+            per = []
+            for b in range(B):
+                mem_b = None
+                if current_mem is not None:
+                    mv, ml, mn, mpi, mpt = current_mem
+                    mem_b = ([v[b:b + 1] for v in mv], ml[b:b + 1], mn, mpi, mpt)
+                per.append(self._forward_scene([t[b:b + 1] for t in xs], [t[b:b + 1] for t in poss],
+                                               [t.reshape(B, -1, 2)[b:b + 1] for t in shapes], mem_b, render, return_feats))
+            if render:
+                out = current_mem   # decoder.py:252 / :339
+            else:
+                o0 = per[0][0]
+                out = ([torch.cat([p[0][0][l] for p in per], dim=0) for l in range(self.depth)],
+                       torch.cat([p[0][1] for p in per], dim=0), o0[2], o0[3], o0[4])
+            outs = [torch.cat([p[1][g] for p in per], dim=0) for g in range(len(xs))]
+            feats = None
+            if return_feats:
+                feats = [[torch.cat([p[2][g][l] for p in per], dim=0) for l in range(self.depth + 1)] for g in range(len(xs))]
+        if return_feats:
+            return out, (outs if is_list else outs[0]), (feats if is_list else feats[0])
+        return out, (outs if is_list else outs[0])
+
+    def _forward_scene(self, xs, poss, shapes, current_mem, render, return_feats):
+        """One scene (B = 1): the native decode call.  Returns (memory, [pointmaps per group], [feats per group] | None)."""
         ctx = self._context()
         dev = self._ctx_dev
         device = torch.device("cuda", dev)
@@ -188,9 +221,7 @@ class MUSt3R(HipModule):
         nimgs, Ns = [], []
         for i, (xi, pi, ti) in enumerate(zip(xs, poss, shapes)):
             B, n, N, Cenc = xi.shape
-            if B != 1:
-                raise NotImplementedError("must3r_amd decodes one scene (B=1) per call, like every inference caller "
-                                          "(engine/inference.py:185-188)")
+            assert B == 1
             xi = self._check_input(xi, "x", torch.float32)
             pi = self._check_input(pi, "pos", torch.int64)
             ts = ti.reshape(-1, 2)
@@ -247,13 +278,13 @@ class MUSt3R(HipModule):
             mem_labels = torch.cat([mem_labels.to(device)] + labels, dim=1)
             tot = mem_nimgs + sum(nimgs)
             out = (new_vals, mem_labels, tot, tot, mem_labels.shape[1])
+        feats = None
         if return_feats:
             feats, r0 = [], 0
             for xi, n, N in zip(xs, nimgs, Ns):
                 feats.append([xi] + [feats_buf[l, r0:r0 + n * N].view(1, n, N, D) for l in range(self.depth)])
                 r0 += n * N
-            return out, (outs if is_list else outs[0]), (feats if is_list else feats[0])
-        return out, (outs if is_list else outs[0])
+        return out, outs, feats
 
     def forward_list(self, x, pos, true_shape, current_mem=None, render=False, return_feats=False):  # decoder.py:158
         return self._forward(list(x), list(pos), list(true_shape), current_mem, render, return_feats)

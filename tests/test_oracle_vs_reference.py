@@ -239,3 +239,29 @@ def test_feedback_types_equal_reference(fb):
     assert rel_inf(pmo, pm) < 2e-5 and rel_inf(pmo2, pm2) < 2e-5
     for a, b in zip(memo[0], mem[0]):
         assert rel_inf(a, b) < 2e-5
+
+
+@pytest.mark.parametrize("mode", ["kv", "norm_y"])
+def test_batch_elements_are_independent_in_reference(mode):
+    """Pins the fact the B > 1 route of must3r_amd.model.decoder rests on: the reference's B = 2 forward equals its two
+    B = 1 forwards stacked (memory, labels and attention are per batch element, decoder.py:158-350)."""
+    from oracle import ref_shims
+    cfg = TINY
+    sde, sdd = S.make_encoder_state_dict(cfg, 5), S.make_decoder_state_dict(cfg, 5)
+    imgs, ts = S.make_images(6, 48, 64, 5)
+    enc, dec = ref_shims.build_reference(cfg, sde, sdd, mode)
+    with torch.no_grad():
+        x, pos = enc(imgs, ts)
+        x, pos, t = x.view(2, 3, *x.shape[1:]), pos.view(2, 3, *pos.shape[1:]), ts.view(2, 3, 2)
+        c = lambda *a: [v.contiguous() for v in a]   # the reference .view()s its inputs (decoder.py:274)
+        mem2, pm2 = dec(*c(x[:, :2], pos[:, :2], t[:, :2]), None)
+        mem2, pm2b = dec(*c(x[:, 2:], pos[:, 2:], t[:, 2:]), mem2)
+        _, pm2r = dec(x, pos, t, mem2, render=True)
+        for b in range(2):
+            s = slice(b, b + 1)
+            mem1, pm1 = dec(*c(x[s, :2], pos[s, :2], t[s, :2]), None)
+            mem1, pm1b = dec(*c(x[s, 2:], pos[s, 2:], t[s, 2:]), mem1)
+            _, pm1r = dec(x[s], pos[s], t[s], mem1, render=True)
+            assert rel_inf(pm2[s], pm1) < 1e-5 and rel_inf(pm2b[s], pm1b) < 1e-5 and rel_inf(pm2r[s], pm1r) < 1e-5
+            assert max(rel_inf(a[s], c) for a, c in zip(mem2[0], mem1[0])) < 1e-5
+            assert torch.equal(mem2[1][s], mem1[1]) and tuple(mem2[2:]) == tuple(mem1[2:])
