@@ -168,3 +168,37 @@ def test_auxiliary_entry_points_refuse_cpu_tensors():
     assert slam_nn.get_searcher("none") is None
     with pytest.raises(ValueError):
         slam_nn.get_searcher("faiss")
+
+
+def test_header_is_plain_c_and_links_from_c(tmp_path):
+    """The drop-in boundary is a C ABI: include/must3r_hip.h must compile as C (no C++/torch types) and a C program must
+    link against libmust3r_hip.so by the declared names (host-only entry points are called; no GPU)."""
+    import shutil
+    import subprocess
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("no gcc")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib_dir = os.path.join(root, "must3r_amd")
+    if not os.path.exists(os.path.join(lib_dir, "libmust3r_hip.so")):
+        pytest.skip("library not built")
+    src = tmp_path / "abi.c"
+    src.write_text('#include "must3r_hip.h"\n#include <stdio.h>\n'
+                   'int main(void) {\n'
+                   '  float t[2 * 16 * 2];   /* [npos][16][cos, sin] */\n'
+                   '  if (must3r_hip_abi_version() != MUST3R_HIP_ABI_VERSION) return 2;\n'
+                   '  if (must3r_hip_rope_table(100.0f, 1.0f, 2, t) != 0) return 3;\n'
+                   '  must3r_hip_ctx* c = 0;\n'
+                   '  if (must3r_hip_create(0, 0, &c) == 0) return 4;   /* null config must be refused */\n'
+                   '  printf("%s|%.8f\\n", must3r_hip_last_error(), t[32]);\n'
+                   '  return 0;\n}\n')
+    exe = tmp_path / "abi"
+    inc = os.path.join(root, "include")
+    subprocess.run([gcc, "-std=c99", "-Wall", "-Werror", "-pedantic", "-fsyntax-only", "-x", "c", os.path.join(inc, "must3r_hip.h")], check=True)
+    subprocess.run([gcc, "-std=c99", "-Wall", "-I", inc, str(src), "-o", str(exe), "-L", lib_dir, "-lmust3r_hip",
+                    "-Wl,-rpath," + lib_dir], check=True)
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, (r.returncode, r.stdout, r.stderr)
+    err, t16 = r.stdout.strip().split("|")
+    import math
+    assert "null" in err and abs(float(t16) - math.cos(1.0)) < 1e-6   # angle(p=1, i=0) = f0 = 1
