@@ -201,6 +201,20 @@ def update_in_mem(old_values, new_values, old_labels, new_labels, old_idx, new_i
     return old_values
 
 
+def rewind_mem(mem_values):
+    """Declare the (shorter) views ``mem_values`` the newest ones of their buffers again.
+
+    A refinement pass (engine/inference.py:427-440) decodes a batch against the memory, copies the appended tokens over the
+    batch's old ones and throws the appended copy away: the rows the decoder appended are scratch.  Without this the
+    buffers would still count them and the next update would take the copy-out path.  Only call it when nothing keeps the
+    longer views.  No-op for tensors that are not prefix views of the decoder's buffers."""
+    owner = getattr(mem_values[0], "_m3r_owner", None)
+    if owner is not None and len(mem_values) == len(owner.bufs) and all(
+            getattr(v, "_m3r_owner", None) is owner and v.data_ptr() == b.data_ptr() for v, b in zip(mem_values, owner.bufs)):
+        owner.valid = int(mem_values[0].shape[1])
+    return mem_values
+
+
 @torch.no_grad()
 def run_video(encoder, decoder, imgs, true_shape, local_context_size=25, is_keyframe=lambda i: i % 3 == 0,
               init_num_images=2, encoder_tokens=None):

@@ -265,3 +265,224 @@ def test_batch_elements_are_independent_in_reference(mode):
             assert rel_inf(pm2[s], pm1) < 1e-5 and rel_inf(pm2b[s], pm1b) < 1e-5 and rel_inf(pm2r[s], pm1r) < 1e-5
             assert max(rel_inf(a[s], c) for a, c in zip(mem2[0], mem1[0])) < 1e-5
             assert torch.equal(mem2[1][s], mem1[1]) and tuple(mem2[2:]) == tuple(mem1[2:])
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# L3 drivers: must3r_amd.inference against must3r/engine/inference.py, both driving the SAME
+# (reference, CPU) modules -> every tensor must be bit-equal, every label / index / count identical.
+# ----------------------------------------------------------------------------------------------------------------------
+def _mixed_views(n, seed):
+    """n views over three aspect ratios (16-px patches: 3x4, 4x3 and 2x4 tokens), deliberately interleaved."""
+    g = torch.Generator().manual_seed(seed)
+    sizes = [(48, 64), (64, 48), (32, 64)]
+    imgs, ts = [], []
+    for i in range(n):
+        H, W = sizes[(i * 2 + i // 3) % 3]
+        imgs.append(torch.rand((3, H, W), generator=g) * 2 - 1)
+        ts.append(torch.tensor([H, W]))
+    return imgs, ts
+
+
+def _same(a, b):
+    if a is None or b is None:
+        assert a is None and b is None
+    elif isinstance(a, dict):
+        assert a.keys() == b.keys()
+        for k in a:
+            _same(a[k], b[k])
+    elif isinstance(a, (list, tuple)):
+        assert len(a) == len(b)
+        for u, v in zip(a, b):
+            _same(u, v)
+    elif torch.is_tensor(a):
+        assert a.shape == b.shape and a.dtype == b.dtype and torch.equal(a, b)
+    else:
+        assert a == b, (a, b)
+
+
+def _drivers(mode="kv"):
+    from oracle import ref_shims
+    ref_shims.install()
+    import must3r.engine.inference as RI
+    import must3r_amd.inference as MI
+    cfg = TINY
+    sde, sdd = S.make_encoder_state_dict(cfg, 2), S.make_decoder_state_dict(cfg, 2)
+    enc, dec = ref_shims.build_reference(cfg, sde, sdd, mode)
+    pp = lambda pm: RI.postprocess(pm, compute_cam=False)  # noqa: E731
+    return RI, MI, enc, dec, pp
+
+
+def test_stack_views_equals_reference():
+    RI, MI, *_ = _drivers()
+    imgs, ts = _mixed_views(9, 0)
+    tst = torch.stack(ts)
+    x = [torch.full((2,), float(i)) for i in range(9)]
+    ids = [torch.tensor(i) for i in range(9)]
+    for max_bs in (None, 1, 2, 5):
+        _same(MI.stack_views(tst, [x, ids], max_bs=max_bs), RI.stack_views(tst, [x, ids], max_bs=max_bs))
+        # partially missing encoder tokens: those views are regrouped behind the complete ones
+        for holes in ([1, 4], [0, 3, 6], list(range(9)), [8]):
+            # (tokens and positions are missing together, like everywhere in the reference: a value that is only missing
+            # for part of a regrouped chunk comes back as an unstacked list there, :112/:129-134, and crashes its caller)
+            xh = [None if i in holes else v for i, v in enumerate(x)]
+            ph = [None if i in holes else v + 1 for i, v in enumerate(x)]
+            _same(MI.stack_views(tst, [xh, ph, imgs], max_bs=max_bs), RI.stack_views(tst, [xh, ph, imgs], max_bs=max_bs))
+    got = MI.unstack_pointmaps([[2, 0], [1]], [{"a": torch.arange(4).view(2, 2)}, {"a": torch.arange(2).view(1, 2)}])
+    _same(got, RI.unstack_pointmaps([[2, 0], [1]], [{"a": torch.arange(4).view(2, 2)}, {"a": torch.arange(2).view(1, 2)}]))
+
+
+@pytest.mark.parametrize("case", [dict(), dict(max_bs=2), dict(num_refinements_iterations=1), dict(to_render=[7, 2, 3], max_bs=2),
+                                  dict(precompute="some"), dict(precompute="all", num_refinements_iterations=2, max_bs=1),
+                                  dict(mode="norm_y", num_refinements_iterations=1)])
+def test_inference_multi_ar_equals_reference(case):
+    case = dict(case)
+    RI, MI, enc, dec, pp = _drivers(case.pop("mode", "kv"))
+    n = 8
+    imgs, ts = _mixed_views(n, 1)
+    ids = [torch.tensor(v) for v in (5, 0, 7, 2, 9, 4, 1, 3)]      # ids are arbitrary (keyframes first in the demo)
+    mem_batches = [2, 1, 2]
+    pre = case.pop("precompute", None)
+
+    def feats(module):
+        if pre is None:
+            return None
+        x, pos = module.encoder_multi_ar(enc, imgs, torch.stack(ts), max_bs=case.get("max_bs"), device=torch.device("cpu"))
+        if pre == "some":
+            for i in (1, 6):
+                x[i] = pos[i] = None
+        return x, pos
+    with torch.no_grad():
+        want = RI.inference_multi_ar(enc, dec, list(imgs), ids, list(ts), mem_batches, post_process_function=pp,
+                                     encoder_precomputed_features=feats(RI), return_mem=True, device=torch.device("cpu"), **case)
+        got = MI.inference_multi_ar(enc, dec, list(imgs), ids, list(ts), mem_batches, post_process_function=pp,
+                                    encoder_precomputed_features=feats(MI), return_mem=True, device=torch.device("cpu"), **case)
+    _same(list(got), list(want))
+    assert all(p is not None for p in got[1]) and len(got[2]) == (3 if "to_render" in case else n)
+    # render-only entry: a precomputed memory, nothing to update (engine/inference.py:461-463)
+    with torch.no_grad():
+        want2 = RI.inference_multi_ar(enc, dec, list(imgs), ids, list(ts), mem_batches, post_process_function=pp,
+                                      precomputed_mem=want[0], to_render=[4, 5], device=torch.device("cpu"))
+        got2 = MI.inference_multi_ar(enc, dec, list(imgs), ids, list(ts), mem_batches, post_process_function=pp,
+                                     precomputed_mem=got[0], to_render=[4, 5], device=torch.device("cpu"))
+        _same(list(got2), list(want2))
+        _same(list(MI.inference_multi_ar(enc, dec, list(imgs), ids, list(ts), mem_batches, precomputed_mem=got[0], to_render=[],
+                                         device=torch.device("cpu"))), [None, []])
+
+
+@pytest.mark.parametrize("case", [dict(), dict(local_context_size=2, max_bs=1), dict(num_refinements_iterations=1, local_context_size=3),
+                                  dict(num_refinements_iterations=2, local_context_size=100), dict(batches=[3, 2, 2, 2, 2]),
+                                  dict(stateful=True, local_context_size=4, num_refinements_iterations=1)])
+def test_inference_video_multi_ar_equals_reference(case):
+    case = dict(case)
+    RI, MI, enc, dec, pp = _drivers()
+    n = 11
+    imgs, ts = _mixed_views(n, 3)
+    mem_batches = case.pop("batches", [2] + [1] * (n - 2))
+    kw = {}
+    if case.pop("stateful", False):
+        # a keyframe test that looks at the result and at a running scene state, like slam's (demo/inference.py:63-106)
+        kw = dict(is_keyframe_function=lambda i, res, st: float(res["conf"].mean()) > st["thr"] or i % 4 == 0,
+                  scene_state_update_function=lambda res, st: {"thr": 0.5 * st["thr"] + 0.5 * float(res["conf"].mean()),
+                                                                "n": st["n"] + 1})
+    with torch.no_grad():
+        if kw:
+            kw_r, kw_m = dict(kw, scene_state={"thr": 0.0, "n": 0}), dict(kw, scene_state={"thr": 0.0, "n": 0})
+        else:
+            kw_r = kw_m = {}
+        want = RI.inference_video_multi_ar(enc, dec, list(imgs), list(ts), mem_batches, post_process_function=pp, return_mem=True,
+                                           device=torch.device("cpu"), **case, **kw_r)
+        got = MI.inference_video_multi_ar(enc, dec, list(imgs), list(ts), mem_batches, post_process_function=pp, return_mem=True,
+                                          device=torch.device("cpu"), **case, **kw_m)
+    _same(list(got), list(want))
+    assert MI.get_Nmem(got[0]) == RI.get_Nmem(want[0]) > 0
+
+
+def test_tensor_inference_driver_equals_reference():
+    """engine/inference.py:570-688 (`inference`, `inference_encoder`): B = 2 scenes of one aspect ratio, with and without
+    max_bs slicing, to_render, train_decoder_skip."""
+    RI, MI, enc, dec, _ = _drivers()
+    imgs, ts = S.make_images(10, 48, 64, 6)
+    imgs, ts = imgs.view(2, 5, 3, 48, 64), ts.view(2, 5, 2)
+    for kw in (dict(), dict(max_bs=3), dict(to_render=[4, 0, 2], max_bs=4), dict(train_decoder_skip=1), dict(to_render=[])):
+        with torch.no_grad():
+            want = RI.inference(enc, dec, imgs, ts, [2, 1, 1], **kw)
+            got = MI.inference(enc, dec, imgs, ts, [2, 1, 1], **kw)
+        _same(list(got), list(want))
+
+
+class _InPlaceMemoryDecoder:
+    """The reference decoder's arithmetic behind the NATIVE module's memory management: the memory tuple it returns is made
+    of prefix views of ``MUSt3R._writable_memory``'s over-allocated buffers and an update appends in place -- the aliasing
+    the L3 drivers have to live with on the GPU (refinement scratch rows, in-place compaction, rewind), on CPU."""
+
+    def __init__(self, ref_dec, cfg):
+        import must3r_amd.model as M
+        self.ref = ref_dec
+        self.native = M.MUSt3R(img_size=(cfg.img_size,) * 2, enc_embed_dim=cfg.enc_dim, embed_dim=cfg.dec_dim, depth=cfg.dec_depth,
+                               num_heads=cfg.dec_heads, feedback_type="single_mlp", memory_mode="kv")
+        self.copies = 0            # how often the memory had to be copied out into fresh buffers
+        self.appends = 0
+
+    @property
+    def reserve_memory_tokens(self):
+        return self.native.reserve_memory_tokens
+
+    @reserve_memory_tokens.setter
+    def reserve_memory_tokens(self, v):
+        self.native.reserve_memory_tokens = v
+
+    def __call__(self, x, pos, true_shape, current_mem=None, render=False):
+        plain = None
+        if current_mem is not None:
+            plain = ([v.clone() for v in current_mem[0]], current_mem[1].clone(), *current_mem[2:])
+        new_mem, pm = self.ref(x, pos, true_shape, plain, render=render)
+        if render:
+            return current_mem, pm
+        Nm = 0 if current_mem is None else int(current_mem[0][0].shape[1])
+        R = int(new_mem[0][0].shape[1]) - Nm
+        before = None if current_mem is None else getattr(current_mem[0][0], "_m3r_owner", None)
+        owner = self.native._writable_memory(None if current_mem is None else list(current_mem[0]), Nm, R, torch.float32,
+                                             torch.device("cpu"))
+        self.copies += int(current_mem is not None and owner is not before)
+        self.appends += int(current_mem is not None and owner is before)
+        for b, v in zip(owner.bufs, new_mem[0]):
+            b[:, Nm:Nm + R] = v[:, Nm:]
+        owner.valid = Nm + R
+        return (owner.views(Nm + R), new_mem[1], *new_mem[2:]), pm
+
+
+@pytest.mark.parametrize("video", [False, True])
+def test_drivers_on_in_place_memory_equal_reference(video):
+    RI, MI, enc, dec, pp = _drivers()
+    n = 10
+    imgs, ts = _mixed_views(n, 5)
+    ids = [torch.tensor(v) for v in range(n)]
+    native_like = _InPlaceMemoryDecoder(dec, TINY)
+    with torch.no_grad():
+        if video:
+            args = ([2] + [1] * (n - 2),)
+            kw = dict(post_process_function=pp, return_mem=True, device=torch.device("cpu"), num_refinements_iterations=2,
+                      local_context_size=3)
+            want = RI.inference_video_multi_ar(enc, dec, list(imgs), list(ts), *args, **kw)
+            got = MI.inference_video_multi_ar(enc, native_like, list(imgs), list(ts), *args, **kw)
+        else:
+            args = (ids, list(ts), [2, 1, 2, 1])
+            kw = dict(post_process_function=pp, return_mem=True, device=torch.device("cpu"), num_refinements_iterations=2)
+            want = RI.inference_multi_ar(enc, dec, list(imgs), *args, **kw)
+            got = MI.inference_multi_ar(enc, native_like, list(imgs), *args, **kw)
+    _same(list(got), list(want))
+    # the memory stayed in the decoder's buffers the whole way: no update had to copy it out
+    assert native_like.appends > 0 and native_like.copies == 0, (native_like.appends, native_like.copies)
+    assert getattr(got[0][0][0], "_m3r_owner", None) is not None
+    if not video:
+        # rewind_mem is an optimisation, never a correctness requirement: without it the refinement passes copy the memory
+        # out (the buffers still count the scratch rows) and the results are the same
+        slow = _InPlaceMemoryDecoder(dec, TINY)
+        keep, MI.rewind_mem = MI.rewind_mem, (lambda vals: vals)
+        try:
+            with torch.no_grad():
+                again = MI.inference_multi_ar(enc, slow, list(imgs), *args, **kw)
+        finally:
+            MI.rewind_mem = keep
+        _same(list(again), list(want))
+        assert slow.copies > 0
