@@ -30,24 +30,40 @@ def shard_range(n_items, rank, world):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def all_gather_varlen(t, group=None):
-    """Concatenate ``t`` ([k_rank, ...], k may differ per rank, may be 0) over ranks, in rank order."""
+def gather_counts(k, device, group=None):
+    """Row counts of every rank (host ints), one tiny all-gather + one read-back."""
+    rank, world = _world(group)
+    if world == 1:
+        return [int(k)]
+    if device.type == "cuda" and dist.get_backend(group) == "gloo":
+        device = torch.device("cpu")
+    counts = [torch.zeros(1, dtype=torch.int64, device=device) for _ in range(world)]
+    dist.all_gather(counts, torch.tensor([int(k)], dtype=torch.int64, device=device), group=group)
+    return [int(c) for c in torch.cat(counts).tolist()]
+
+
+def all_gather_varlen(t, group=None, counts=None):
+    """Concatenate ``t`` ([k_rank, ...], k may differ per rank, may be 0) over ranks, in rank order.  ``counts``: the row
+    counts of all ranks when the caller already knows them (saves the count exchange and its device->host read-back)."""
     rank, world = _world(group)
     if world == 1:
         return t
     if t.is_cuda and dist.get_backend(group) == "gloo":
         # gloo has no CUDA all_gather: stage through the host (only used when ranks share a GPU in tests)
-        return all_gather_varlen(t.cpu(), group).to(t.device)
-    counts = [torch.zeros(1, dtype=torch.int64, device=t.device) for _ in range(world)]
-    dist.all_gather(counts, torch.tensor([t.shape[0]], dtype=torch.int64, device=t.device), group=group)
-    counts = [int(c.item()) for c in counts]
+        return all_gather_varlen(t.cpu(), group, counts).to(t.device)
+    if counts is None:
+        counts = gather_counts(t.shape[0], t.device, group)
+    assert counts[rank] == t.shape[0], (counts, rank, t.shape)
     kmax = max(counts)
     if kmax == 0:
         return t
-    pad = torch.zeros((kmax,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
-    pad[: t.shape[0]] = t
+    if min(counts) == kmax:
+        pad = t.contiguous()                      # equal shards: no staging copy
+    else:
+        pad = torch.zeros((kmax,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+        pad[: t.shape[0]] = t
     out = [torch.empty_like(pad) for _ in range(world)]
-    dist.all_gather(out, pad.contiguous(), group=group)
+    dist.all_gather(out, pad, group=group)
     return torch.cat([o[:c] for o, c in zip(out, counts)], dim=0)
 
 
@@ -65,9 +81,10 @@ def run_scene_sharded(encoder, decoder, imgs_local, true_shape_local, keyframe_l
     kx = x[kf]
     if comm_dtype is not None:
         kx = kx.to(comm_dtype)  # 16-bit on the wire; the decoder rounds its operands to this type anyway
-    kx = all_gather_varlen(kx, group).float()
-    kpos = all_gather_varlen(pos[kf], group)
-    kts = all_gather_varlen(true_shape_local.to(x.device)[kf], group).cpu()   # host copy: no per-call sync in the decoder
+    counts = gather_counts(int(keyframe_local.sum()), x.device, group)       # host-known locally: one exchange for all three
+    kx = all_gather_varlen(kx, group, counts).float()
+    kpos = all_gather_varlen(pos[kf], group, counts)
+    kts = all_gather_varlen(true_shape_local.to(x.device)[kf], group, counts).cpu()   # host copy: no per-call sync in the decoder
     K = kx.shape[0]
     if K == 0:
         raise ValueError("run_scene_sharded: no keyframe on any rank")
