@@ -5,6 +5,7 @@ Same class / function names and call signatures as the reference (``get_searcher
 reference.  Instead of rebuilding a scipy KD-tree over all keyframe points after every keyframe (nns.py:47-50) and
 querying it on 4 host threads (nns.py:56), the points stay in HBM and a query is an exact brute-force scan
 (``must3r_hip_nn_query``); quadrant ids (slam/tools.py:9-31) come from ``must3r_hip_quadrant_ids``.
+``forward_must3r`` is the SLAM agent's forward wrapper (slam/model.py:22-59).
 """
 import ctypes as C
 
@@ -145,3 +146,29 @@ def get_overlap_score(res, overlap_tree, cam_center, mode="nn", kf_x_subsamp=Non
         dists[np.isposinf(dists)] = np.finfo(dists.dtype).max   # unseen quadrant (slam/model.py:87-88)
         outscore = np.percentile(dists, percentile)
     return outscore
+
+
+@torch.no_grad()
+def forward_must3r(model, input_views, memory, render=False, device='cuda:0', postprocess=None):
+    """slam/model.py:22-59: encode every view (dict with ``img`` [1,3,H,W] and ``true_shape`` [1,2], dust3r's view layout) on its own,
+    ONE decoder call over the list (one group per view: views may differ in aspect ratio), activation per view.
+    Returns ``(list of {pts3d, pts3d_local, conf} with a leading [1, 1] batch, new_memory)``.
+
+    The (H, W) pairs stay on the host (both modules read them as host integers: no device round trip per view) and the
+    allocator cache is left alone (the reference empties it after every frame, :50).  ``postprocess`` defaults to the
+    fused native activation (``must3r_amd.engine.postprocess``)."""
+    if postprocess is None:
+        from .engine import postprocess
+    from .model import get_pointmaps_activation
+    encoder, decoder = model
+    xs, poss, shapes = [], [], []
+    for view in input_views:
+        shape = view['true_shape']
+        shape = (shape.cpu() if torch.is_tensor(shape) else torch.as_tensor(shape))[None]   # :31, kept on the host
+        x, pos = encoder(view['img'].to(device), shape.view(-1, 2))
+        xs.append(x[None])
+        poss.append(pos[None])
+        shapes.append(shape)
+    new_memory, preds = decoder(xs, poss, shapes, memory, render=render)
+    activation = get_pointmaps_activation(decoder, verbose=False)
+    return [postprocess(pred, pointmaps_activation=activation) for pred in preds], new_memory

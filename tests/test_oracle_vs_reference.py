@@ -486,3 +486,29 @@ def test_drivers_on_in_place_memory_equal_reference(video):
             MI.rewind_mem = keep
         _same(list(again), list(want))
         assert slow.copies > 0
+
+
+def test_forward_must3r_equals_reference_source():
+    """slam/model.py:22-59 (the SLAM agent's forward wrapper; its module needs dust3r.datasets, the function does not)
+    against must3r_amd.slam_nn.forward_must3r, both on the reference modules (CPU): update and render calls, views of
+    different aspect ratios in one call."""
+    from oracle import ref_shims
+    ref_shims.install()
+    import must3r.engine.inference as RI
+    import must3r.model as RM
+    from must3r_amd.slam_nn import forward_must3r
+    ns = {"torch": torch, "postprocess": RI.postprocess, "get_pointmaps_activation": RM.get_pointmaps_activation}
+    ref_forward = _reference_function("/root/reference/must3r/slam/model.py", "forward_must3r", ns)
+    cfg = TINY
+    sde, sdd = S.make_encoder_state_dict(cfg, 4), S.make_decoder_state_dict(cfg, 4)
+    enc, dec = ref_shims.build_reference(cfg, sde, sdd, "kv")
+    imgs, ts = _mixed_views(4, 11)
+    views = [{"img": im[None], "true_shape": t.numpy()[None]} for im, t in zip(imgs, ts)]   # [1,2] like dust3r load_images
+    import unittest.mock as mock
+    with torch.no_grad(), mock.patch("torch.cuda.empty_cache", lambda: None):
+        mem_r = mem_m = None
+        for batch, render in ((views[:2], False), (views[2:3], False), (views, True), (views[3:], False)):
+            out_r, mem_r = ref_forward((enc, dec), batch, mem_r, render=render, device="cpu")
+            out_m, mem_m = forward_must3r((enc, dec), batch, mem_m, render=render, device="cpu", postprocess=RI.postprocess)
+            _same(out_m, out_r)
+            _same(list(mem_m), list(mem_r))
