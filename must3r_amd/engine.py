@@ -161,20 +161,123 @@ def run_scene(encoder, decoder, imgs, true_shape, mem_batches=None, render_bs=No
     return out
 
 
+@torch.no_grad()
+def run_scene_mixed(encoder, decoder, img_groups, mem_batches=None, activate=True):
+    """One scene whose views come in several aspect ratios (BASELINE.json configs[4]: 512 x {384,336,288,256,160}).
+
+    ``img_groups``: list of fp32 [n_g,3,H_g,W_g] cuda tensors, one per aspect ratio; the scene's view order is group order,
+    then order inside the group.  Every group is encoded with one batched encoder call; the memory update walks the views
+    with the demo schedule ``[2,1,...,1]`` (a batch that spans two aspect ratios becomes a ``forward_list`` call,
+    decoder.py:158-265, like ``inference_multi_ar`` does it, engine/inference.py:396-442); the render pass is ONE
+    ``forward_list`` call over all groups against the final memory (engine/inference.py:489-522).
+
+    Returns dict(update=[per-view [H,W,7]], render=[per-group [n_g,H_g,W_g,7]], mem[, pts3d/pts3d_local/conf per group])."""
+    dev = img_groups[0].device
+    enc = []
+    for g in img_groups:
+        n, _, H, W = g.shape
+        ts = torch.tensor([[H, W]] * n, dtype=torch.int64)
+        x, pos = encoder(g, ts)
+        enc.append((x, pos, ts))
+    owner = [(gi, j) for gi, g in enumerate(img_groups) for j in range(g.shape[0])]
+    V = len(owner)
+    if mem_batches is None:
+        mem_batches = demo_mem_batches(V)
+    if hasattr(decoder, "reserve_memory_tokens"):
+        decoder.reserve_memory_tokens = sum(int(enc[gi][0].shape[1]) for gi, _ in owner[:sum(mem_batches)])   # final memory size
+    mem, upd, i = None, [], 0
+    for nb in mem_batches:
+        batch = owner[i:i + nb]
+        gids = sorted({gi for gi, _ in batch})
+        xs, ps, tss = [], [], []
+        for gi in gids:
+            js = [j for g2, j in batch if g2 == gi]
+            x, pos, ts = enc[gi]
+            xs.append(x[js[0]:js[-1] + 1].unsqueeze(0))
+            ps.append(pos[js[0]:js[-1] + 1].unsqueeze(0))
+            tss.append(ts[js[0]:js[-1] + 1].unsqueeze(0))
+        if len(gids) == 1:
+            mem, pm = decoder(xs[0], ps[0], tss[0], mem)
+            pms = [pm]
+        else:
+            mem, pms = decoder(xs, ps, tss, mem)
+        for pm in pms:
+            upd += [pm[0, k] for k in range(pm.shape[1])]
+        i += nb
+    _, ren = decoder([e[0].unsqueeze(0) for e in enc], [e[1].unsqueeze(0) for e in enc], [e[2].unsqueeze(0) for e in enc], mem,
+                     render=True)
+    out = {"update": upd, "render": [r[0] for r in ren], "mem": mem}
+    if activate:
+        pp = [postprocess(r) for r in out["render"]]
+        for k in ("pts3d", "pts3d_local", "conf"):
+            out[k] = [p[k] for p in pp]
+    return out
+
+
 # ------------------------------------------------------------------------------------------------------------------
 # memory surgery of the L3 engine (SURVEY.md section 8f rank 2) -- same semantics as the reference helpers
 # engine/inference.py:205-228, but the per-layer buffers are compacted IN PLACE, so the tensors stay prefix views of
 # the decoder's over-allocated K|V buffers and the next memory update appends without copying the whole memory.
 # ------------------------------------------------------------------------------------------------------------------
+def _label_runs(mem_labels):
+    """Host mirror of the label layout, ``[(label, n_tokens), ...]`` in row order, attached by the decoder to the label
+    tensors it returns (``MUSt3R._forward_scene``) and kept up to date by the helpers below.  None when the caller built
+    the labels itself: the helpers then fall back to the reference's boolean-mask indexing (a device->host sync each)."""
+    runs = getattr(mem_labels, "_m3r_runs", None)
+    if runs is None or mem_labels.dim() != 2 or mem_labels.shape[0] != 1 or sum(c for _, c in runs) != mem_labels.shape[1]:
+        return None
+    return runs
+
+
+def _ranges_of(runs, idx):
+    out, off = [], 0
+    for lab, cnt in runs:
+        if lab == idx:
+            out.append((off, off + cnt))
+        off += cnt
+    return out
+
+
 def remove_from_mem(mem_values, mem_labels, idx):
     """``_remove_from_mem`` (engine/inference.py:205-213): drop every token whose label equals ``idx``.
 
-    mem_values: list of [B=1, Nm, D]; mem_labels: int64 [1, Nm].  Returns (mem_values, mem_labels)."""
-    keep = mem_labels != idx
-    B, _, D = mem_values[0].shape
+    mem_values: list of [B=1, Nm, D]; mem_labels: int64 [1, Nm].  Returns (mem_values, mem_labels).
+
+    When the tensors are the newest prefix views of the decoder's own buffers they are compacted IN PLACE (rows behind the
+    first dropped one move up; the shorter views alias the same storage, so OLDER, longer views of these buffers change
+    under the caller -- the L3 drivers never keep them).  With the host mirror of the labels the kept-row index is built
+    on the host and uploaded: no ``nonzero`` read-back, the host keeps queueing ahead of the GPU."""
+    B, Nm, D = mem_values[0].shape
     owner = getattr(mem_values[0], "_m3r_owner", None)
-    in_place = (B == 1 and owner is not None and owner.valid == mem_values[0].shape[1]
+    in_place = (B == 1 and owner is not None and owner.valid == Nm
                 and all(getattr(v, "_m3r_owner", None) is owner for v in mem_values))
+    runs = _label_runs(mem_labels)
+    if runs is not None:
+        drop = _ranges_of(runs, idx)
+        new_runs = [(lab, cnt) for lab, cnt in runs if lab != idx]
+        if not drop:
+            return mem_values, mem_labels
+        first = drop[0][0]
+        tail, off = [], 0
+        for lab, cnt in runs:
+            if lab != idx and off >= first:
+                tail.append(torch.arange(off, off + cnt))
+            off += cnt
+        n = sum(c for _, c in new_runs)
+        dev = mem_labels.device
+        tail_idx = (torch.cat(tail) if tail else torch.zeros(0, dtype=torch.int64)).to(dev, non_blocking=True)
+        if in_place:
+            if n > first:
+                for b in owner.bufs:
+                    b[:, first:n] = b[:, tail_idx]     # gather into a temporary, then prefix write: sources are read first
+            owner.valid = n
+            vals = owner.views(n)
+        else:
+            vals = [torch.cat([v[:, :first], v[:, tail_idx]], dim=1) for v in mem_values]
+        labels = torch.cat([mem_labels[:, :first], mem_labels[:, tail_idx]], dim=1)
+        labels._m3r_runs = new_runs
+        return vals, labels
+    keep = mem_labels != idx
     if not in_place:
         return [v[keep].view(B, -1, D) for v in mem_values], mem_labels[keep].view(B, -1)
     kept = keep[0].nonzero().flatten()
@@ -187,13 +290,25 @@ def remove_from_mem(mem_values, mem_labels, idx):
 
 def restore_label_in_mem(mem_labels, old_idx_to_restore, new_idx_to_remove):
     """``_restore_label_in_mem`` (engine/inference.py:216-219), in place."""
+    runs = getattr(mem_labels, "_m3r_runs", None)
     mem_labels[mem_labels == new_idx_to_remove] = old_idx_to_restore
+    if runs is not None:
+        mem_labels._m3r_runs = [(old_idx_to_restore if lab == new_idx_to_remove else lab, cnt) for lab, cnt in runs]
     return mem_labels
 
 
 def update_in_mem(old_values, new_values, old_labels, new_labels, old_idx, new_idx):
     """``_update_in_mem`` (engine/inference.py:222-228): overwrite the tokens labelled ``old_idx`` in ``old_values`` with
-    the tokens labelled ``new_idx`` of ``new_values`` (in place; views of the decoder's buffers stay valid)."""
+    the tokens labelled ``new_idx`` of ``new_values`` (in place; views of the decoder's buffers stay valid).  Slice copies
+    when both label layouts are known on the host, the reference's boolean masks otherwise."""
+    ro, rn = _label_runs(old_labels), _label_runs(new_labels)
+    if ro is not None and rn is not None:
+        dst, src = _ranges_of(ro, old_idx), _ranges_of(rn, new_idx)
+        if len(dst) == len(src) and all(d[1] - d[0] == s_[1] - s_[0] for d, s_ in zip(dst, src)):
+            for k in range(len(old_values)):
+                for (d0, d1), (s0, s1) in zip(dst, src):
+                    old_values[k][:, d0:d1] = new_values[k][:, s0:s1]
+            return old_values
     old_mask = old_labels == old_idx
     new_mask = new_labels == new_idx
     for k in range(len(old_values)):
@@ -228,9 +343,9 @@ def run_video(encoder, decoder, imgs, true_shape, local_context_size=25, is_keyf
 
     Returns (mem_tuple, pointmaps_0 [V,H,W,7], keyframe ids)."""
     from collections import deque
-    V = imgs.shape[0]
     ts_host = true_shape.cpu() if true_shape.is_cuda else true_shape
     x, pos = encoder_tokens if encoder_tokens is not None else encoder(imgs, true_shape)
+    V = x.shape[0]
     mem = None
     img_labels, keyframes, working = {}, set(), deque()
     pointmaps_0 = []

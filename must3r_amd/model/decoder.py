@@ -153,7 +153,12 @@ class MUSt3R(HipModule):
             # growth doubles the capacity (amortised O(1) appends); a caller that knows how many tokens the memory will
             # reach (engine.run_scene: keyframes x tokens) can say so through ``reserve_memory_tokens`` and skip the
             # 12 x log2 re-allocation copies of a scene (measured: 49 copies, 0.5 ms per 20-view scene)
-            cap = max(Nm + R, 2 * Nm, 1024, int(getattr(self, "reserve_memory_tokens", 0) or 0))
+            # The hint is ONE-SHOT: it sizes the first buffer of a scene (Nm == 0) and is consumed there, so later fresh
+            # allocations (copy-out after a discarded / older tuple, another scene, the B > 1 path) are not sized for it.
+            hint = int(getattr(self, "reserve_memory_tokens", 0) or 0) if Nm == 0 else 0
+            if Nm == 0:
+                self.reserve_memory_tokens = 0
+            cap = max(Nm + R, 2 * Nm, 1024, hint)
             owner = _MemBuffers(self.depth, cap, mem_D, tdt, device)
             if Nm > 0:
                 for v, b in zip(mem_vals, owner.bufs):
@@ -272,10 +277,18 @@ class MUSt3R(HipModule):
             new_vals = owner.views(Nm + R)
             labels = []
             k = 0
+            # host mirror of the label layout (engine._label_runs): lets the L3 memory surgery build its indices without
+            # reading the labels back from the device
+            runs = [] if Nm == 0 else getattr(mem_labels, "_m3r_runs", None)
+            runs = list(runs) if runs is not None and sum(c for _, c in runs) == Nm else None
             for n, N in zip(nimgs, Ns):  # decoder.py:241-249 / :332-334
                 labels.append((torch.arange(n, dtype=torch.int64, device=device) + (mem_nimgs + k)).repeat_interleave(N).view(1, -1))
+                if runs is not None:
+                    runs += [(mem_nimgs + k + j, N) for j in range(n)]
                 k += n
             mem_labels = torch.cat([mem_labels.to(device)] + labels, dim=1)
+            if runs is not None:
+                mem_labels._m3r_runs = runs
             tot = mem_nimgs + sum(nimgs)
             out = (new_vals, mem_labels, tot, tot, mem_labels.shape[1])
         feats = None

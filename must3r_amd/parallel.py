@@ -57,6 +57,20 @@ def all_gather_varlen(t, group=None, counts=None):
     kmax = max(counts)
     if kmax == 0:
         return t
+    if min(counts) == 0:
+        # a rank without rows may not know the trailing shape (e.g. the token width of an encoder it never ran): adopt the
+        # shape of the ranks that have rows (one tiny exchange, only in this ragged case)
+        dev = torch.device("cpu") if dist.get_backend(group) == "gloo" else t.device
+        mine = torch.zeros(8, dtype=torch.int64, device=dev)
+        if t.shape[0] > 0:
+            mine[0] = t.dim() - 1
+            mine[1:t.dim()] = torch.tensor(tuple(t.shape[1:]), dtype=torch.int64, device=dev)
+        shapes = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(shapes, mine, group=group)
+        ref = next(sh for sh, c in zip(shapes, counts) if c > 0).tolist()
+        trail = tuple(int(v) for v in ref[1:1 + int(ref[0])])
+        if t.shape[0] == 0 and tuple(t.shape[1:]) != trail:
+            t = t.new_zeros((0,) + trail)
     if min(counts) == kmax:
         pad = t.contiguous()                      # equal shards: no staging copy
     else:
@@ -67,24 +81,50 @@ def all_gather_varlen(t, group=None, counts=None):
     return torch.cat([o[:c] for o, c in zip(out, counts)], dim=0)
 
 
+def _encode_local(encoder, imgs_local, true_shape_local):
+    """Encode this rank's views; a rank without views (n_views < world) skips the call and returns empty [0,N,C] tokens."""
+    if imgs_local.shape[0] > 0:
+        return encoder(imgs_local, true_shape_local)
+    N = (imgs_local.shape[-2] // 16) * (imgs_local.shape[-1] // 16)
+    C = int(getattr(encoder, "embed_dim", 1024))
+    return (torch.zeros((0, N, C), dtype=torch.float32, device=imgs_local.device),
+            torch.zeros((0, N, 2), dtype=torch.int64, device=imgs_local.device))
+
+
+def _gather_keyframes(x, pos, true_shape_local, keyframe_local, group, comm_dtype):
+    """All-gather of the encoded keyframe tokens (+ positions, shapes) in rank order.  The keyframe selection is a host
+    index list (no boolean-mask indexing on the device = no nonzero() sync)."""
+    idx = torch.nonzero(keyframe_local.cpu()).flatten()
+    counts = gather_counts(int(idx.numel()), x.device, group)               # one exchange for all three gathers
+    idx_d = idx.to(x.device)
+    kx = x.index_select(0, idx_d)
+    if comm_dtype is not None:
+        kx = kx.to(comm_dtype)  # 16-bit on the wire; the decoder rounds its operands to this type anyway
+    kx = all_gather_varlen(kx, group, counts).float()
+    kpos = all_gather_varlen(pos.index_select(0, idx_d), group, counts)
+    kts = all_gather_varlen(true_shape_local.cpu().index_select(0, idx).to(x.device), group, counts).cpu()   # host copy
+    return kx, kpos, kts
+
+
+def _render_local(decoder, x, pos, true_shape_local, mem, imgs_local):
+    if x.shape[0] > 0:
+        _, pm = decoder(x.unsqueeze(0), pos.unsqueeze(0), true_shape_local.cpu().unsqueeze(0), mem, render=True)
+        return pm[0]
+    return torch.zeros((0, imgs_local.shape[-2], imgs_local.shape[-1], 7), dtype=torch.float32, device=x.device)
+
+
 @torch.no_grad()
 def run_scene_sharded(encoder, decoder, imgs_local, true_shape_local, keyframe_local, group=None, comm_dtype=None,
                       mem_batches=None, gather_outputs=False):
     """One scene whose views are sharded over the ranks of ``group``.
 
-    imgs_local [v,3,H,W], true_shape_local [v,2]: this rank's views (global order = rank order, then local order).
-    keyframe_local bool[v]: which local views enter the memory.  Returns dict(render=[v,H,W,7] local pointmaps,
-    mem=memory tuple (identical on all ranks), n_keyframes) (+ render_all when gather_outputs).
+    imgs_local [v,3,H,W], true_shape_local [v,2]: this rank's views (global order = rank order, then local order; v may be
+    0 when there are fewer views than ranks).  keyframe_local bool[v]: which local views enter the memory.  Returns
+    dict(render=[v,H,W,7] local pointmaps, mem=memory tuple (identical on all ranks), n_keyframes) (+ render_all when
+    gather_outputs).  With all views keyframes this is the STRONG-scaling form of the 20-view benchmark scene.
     """
-    x, pos = encoder(imgs_local, true_shape_local)
-    kf = keyframe_local.to(x.device)
-    kx = x[kf]
-    if comm_dtype is not None:
-        kx = kx.to(comm_dtype)  # 16-bit on the wire; the decoder rounds its operands to this type anyway
-    counts = gather_counts(int(keyframe_local.sum()), x.device, group)       # host-known locally: one exchange for all three
-    kx = all_gather_varlen(kx, group, counts).float()
-    kpos = all_gather_varlen(pos[kf], group, counts)
-    kts = all_gather_varlen(true_shape_local.to(x.device)[kf], group, counts).cpu()   # host copy: no per-call sync in the decoder
+    x, pos = _encode_local(encoder, imgs_local, true_shape_local)
+    kx, kpos, kts = _gather_keyframes(x, pos, true_shape_local, keyframe_local, group, comm_dtype)
     K = kx.shape[0]
     if K == 0:
         raise ValueError("run_scene_sharded: no keyframe on any rank")
@@ -96,11 +136,34 @@ def run_scene_sharded(encoder, decoder, imgs_local, true_shape_local, keyframe_l
         mem, _ = decoder(kx[i:i + nb].unsqueeze(0), kpos[i:i + nb].unsqueeze(0), kts[i:i + nb].unsqueeze(0), mem)
         i += nb
     out = {"mem": mem, "n_keyframes": K}
-    if x.shape[0] > 0:
-        _, pm = decoder(x.unsqueeze(0), pos.unsqueeze(0), true_shape_local.cpu().unsqueeze(0), mem, render=True)
-        out["render"] = pm[0]
-    else:
-        out["render"] = x.new_zeros((0,))
+    out["render"] = _render_local(decoder, x, pos, true_shape_local, mem, imgs_local)
     if gather_outputs:
         out["render_all"] = all_gather_varlen(out["render"], group)
+    return out
+
+
+@torch.no_grad()
+def run_video_sharded(encoder, decoder, imgs_local, true_shape_local, group=None, comm_dtype=None, local_context_size=25,
+                      is_keyframe=lambda i: i % 3 == 0, init_num_images=2, render=True, gather_outputs=False):
+    """Online / streaming memory over a sharded frame sequence (BASELINE.json configs[3]; schedule of
+    ``inference_video_multi_ar``, engine/inference.py:232-366, via ``engine.run_video``).
+
+    The frames of the sequence are dealt to the ranks in contiguous blocks (global frame id = rank order, then local order).
+    Encoding -- the only per-frame work that does not depend on the memory -- is sharded; the encoded tokens of ALL frames
+    are exchanged with one all-gather (every frame updates the memory in the online schedule, so every rank needs every
+    frame's tokens); the sequential memory update with the sliding window / keyframe eviction is replicated
+    (deterministic -> identical memories, nothing else to exchange); the final render of every frame against the final
+    keyframe memory (engine/inference.py:489-522) is sharded again.  Returns dict(mem, keyframes, pointmaps_0 (update-pass
+    pointmaps of ALL frames, identical on every rank), render (local frames)[, render_all])."""
+    from .engine import run_video
+    x, pos = _encode_local(encoder, imgs_local, true_shape_local)
+    all_kf = torch.ones(x.shape[0], dtype=torch.bool)
+    ax, apos, ats = _gather_keyframes(x, pos, true_shape_local, all_kf, group, comm_dtype)
+    mem, pm0, keyframes = run_video(None, decoder, None, ats, local_context_size=local_context_size, is_keyframe=is_keyframe,
+                                    init_num_images=init_num_images, encoder_tokens=(ax, apos))
+    out = {"mem": mem, "keyframes": keyframes, "pointmaps_0": pm0}
+    if render:
+        out["render"] = _render_local(decoder, x, pos, true_shape_local, mem, imgs_local)
+        if gather_outputs:
+            out["render_all"] = all_gather_varlen(out["render"], group)
     return out

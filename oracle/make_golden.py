@@ -18,7 +18,7 @@ sys.path.insert(0, ROOT)
 sys.dont_write_bytecode = True
 
 from oracle import ref_shims  # noqa: E402
-from must3r_amd.config import TINY, SMALL, MUST3R_224  # noqa: E402
+from must3r_amd.config import TINY, SMALL, MUST3R_224, MUST3R_512  # noqa: E402
 from must3r_amd import synthetic as S  # noqa: E402
 
 OUT = os.path.join(ROOT, "tests", "golden")
@@ -28,6 +28,11 @@ CASES = {
     "tiny_48x64_v4": (TINY, 48, 64, 4, [2, 1, 1], 1, 1),
     "small_224_v3": (SMALL, 224, 224, 3, [2, 1], 4, 4),
     "must3r224_v2": (MUST3R_224, 224, 224, 2, [2], 8, 7),   # BASELINE.json configs[0]
+}
+# full-depth cases of the benchmark configurations (minutes of CPU time each; `python oracle/make_golden.py model_big`)
+BIG_CASES = {
+    "must3r224_v10": (MUST3R_224, 224, 224, 10, [2] + [1] * 8, 4, 5),     # BASELINE.json configs[1]
+    "must3r512_v20": (MUST3R_512, 384, 512, 20, [2] + [1] * 18, 8, 11),   # BASELINE.json configs[2]: the headline scene
 }
 
 
@@ -48,10 +53,10 @@ def run_reference(cfg, H, W, V, mem_batches, seed=0):
     return x, pos, torch.cat(upd, 0), ren[0], mem
 
 
-def main():
+def main(cases=None, mixed=True):
     torch.set_num_threads(os.cpu_count() or 8)
     os.makedirs(OUT, exist_ok=True)
-    for name, (cfg, H, W, V, mb, ps, tks) in CASES.items():
+    for name, (cfg, H, W, V, mb, ps, tks) in (cases or CASES).items():
         x, pos, upd, ren, mem = run_reference(cfg, H, W, V, mb)
         np.savez_compressed(
             os.path.join(OUT, name + ".npz"),
@@ -64,6 +69,8 @@ def main():
             mem_first=mem[0][0][0, ::tks, ::tks].numpy(), mem_last=mem[0][-1][0, ::tks, ::tks].numpy(),
             labels=mem[1].numpy(), tail=np.array(mem[2:], dtype=np.int64))
         print(name, "x", tuple(x.shape), "update", tuple(upd.shape), "render", tuple(ren.shape), "Nm", mem[0][0].shape[1])
+    if not mixed:
+        return
 
     # mixed aspect ratios through forward_list (tiny geometry): init with [2 x 48x64, 1 x 32x64], update with
     # [1 x 32x64, 2 x 48x64], render both groups
@@ -158,6 +165,8 @@ if __name__ == "__main__":
     which = sys.argv[1] if len(sys.argv) > 1 else "all"
     if which in ("all", "model"):
         main()
+    if which == "model_big":
+        main(BIG_CASES, mixed=False)
     if which in ("all", "cam"):
         make_cam()
     if which in ("all", "nn"):

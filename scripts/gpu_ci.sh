@@ -10,13 +10,12 @@ echo "== rocminfo"; /opt/rocm/bin/rocminfo 2>/dev/null | grep -E "gfx950|Compute
 nproc
 if [ "$STAGE" = "all" ] || [ "$STAGE" = "ops" ]; then
   echo "== ops"
-  timeout 900 python -m pytest tests/test_ops_gpu.py -m gpu -q -p no:cacheprovider --timeout=300 > gpurun_out/ops.log 2>&1; tail -40 gpurun_out/ops.log
-  rc=$?
+  timeout 900 python -m pytest tests/test_ops_gpu.py -m gpu -q -p no:cacheprovider --timeout=300 > gpurun_out/ops.log 2>&1; rc=$?; tail -40 gpurun_out/ops.log
   if [ $rc -ne 0 ] && [ "$STAGE" = "all" ]; then echo "ops failed (rc=$rc): stopping"; exit 1; fi
 fi
 if [ "$STAGE" = "all" ] || [ "$STAGE" = "model" ]; then
   echo "== model"
-  timeout 1500 python -m pytest tests/test_model_gpu.py -m gpu -q -p no:cacheprovider --timeout=900 > gpurun_out/model.log 2>&1; tail -40 gpurun_out/model.log
+  timeout 1500 python -m pytest tests/test_model_gpu.py -m gpu -q -p no:cacheprovider --timeout=900 > gpurun_out/model.log 2>&1; rc_model=$?; tail -40 gpurun_out/model.log
   echo "== smoke"
   timeout 600 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -20 | tee gpurun_out/smoke.log
 fi
@@ -25,3 +24,4 @@ if [ "$STAGE" = "all" ] || [ "$STAGE" = "bench" ]; then
   timeout 1200 python bench.py --gpus 1 --steps 3 --warmup 1 2>&1 | tail -20 | tee gpurun_out/bench.log
 fi
 echo "== done"
+exit ${rc_model:-0}

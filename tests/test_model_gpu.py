@@ -66,6 +66,40 @@ def test_scene_matches_reference_fixture(name, precision):
     assert errs["mem_first"] < tol + u and errs["mem_last"] < tol + u, errs
 
 
+BIG_CASES = {"must3r224_v10": MUST3R_224, "must3r512_v20": MUST3R_512}
+
+
+@pytest.mark.parametrize("precision", list(PRECISIONS))
+@pytest.mark.parametrize("name", list(BIG_CASES))
+def test_full_depth_scene_matches_reference_fixture(name, precision):
+    """Full-depth parity at the benchmark configurations (BASELINE.json configs[1] / configs[2]) against outputs of the
+    REAL reference (oracle/make_golden.py model_big): every view of the sequential memory update [2,1,...,1]
+    (engine/inference.py:396-442) and of the render pass against the final memory (:489-522), per view, plus the first and
+    last layer of the final memory -- error growth with memory depth at full width is measured, not inferred."""
+    g = load_golden(name)
+    H, W, V, ps, tks = (int(v) for v in g["meta"][:5])
+    mb = [int(v) for v in g["meta"][5:]]
+    out = hip_scene(BIG_CASES[name], precision, H, W, V, mb)
+    tol = TOL[precision]
+    x, upd, ren, mem = out["x"].cpu(), out["update"].cpu(), out["render"].cpu(), out["mem"]
+    assert upd.shape[0] == V and ren.shape[0] == V and mem[0][0].shape[1] == V * (H // 16) * (W // 16)
+    upd_v = [rel_inf(upd[v, ::ps, ::ps], g["update"][v]) for v in range(V)]
+    ren_v = [rel_inf(ren[v, ::ps, ::ps], g["render"][v]) for v in range(V)]
+    errs = dict(x=rel_inf(x[:, ::tks, ::tks], g["x"]), update=rel_inf(upd[:, ::ps, ::ps], g["update"]),
+                render=rel_inf(ren[:, ::ps, ::ps], g["render"]), render_l2=rel_l2(ren[:, ::ps, ::ps], g["render"]),
+                update_view_max=max(upd_v), render_view_max=max(ren_v), update_last_view=upd_v[-1],
+                mem_first=rel_inf(mem[0][0][0, ::tks, ::tks].float().cpu(), g["mem_first"]),
+                mem_last=rel_inf(mem[0][-1][0, ::tks, ::tks].float().cpu(), g["mem_last"]))
+    record("full_depth_vs_fixture", case=name, precision=precision, views=V, update_per_view=[round(e, 6) for e in upd_v],
+           render_per_view=[round(e, 6) for e in ren_v], **errs)
+    assert np.array_equal(mem[1].cpu().numpy(), g["labels"]) and [int(v) for v in mem[2:]] == [int(v) for v in g["tail"]]
+    assert torch.isfinite(ren).all() and torch.isfinite(upd).all()
+    assert errs["x"] < tol and errs["update"] < tol and errs["render"] < tol, errs
+    assert max(upd_v) < tol and max(ren_v) < tol, (upd_v, ren_v)          # every single view, normalised by its own range
+    u = 2.0 ** -8 if precision == "bf16" else 2.0 ** -11
+    assert errs["mem_first"] < tol + u and errs["mem_last"] < tol + u, errs
+
+
 @pytest.mark.parametrize("precision", list(PRECISIONS))
 def test_mixed_aspect_ratio_list_path(precision):
     g = load_golden("tiny_mixed_ar")

@@ -415,8 +415,9 @@ class _InPlaceMemoryDecoder:
     of prefix views of ``MUSt3R._writable_memory``'s over-allocated buffers and an update appends in place -- the aliasing
     the L3 drivers have to live with on the GPU (refinement scratch rows, in-place compaction, rewind), on CPU."""
 
-    def __init__(self, ref_dec, cfg):
+    def __init__(self, ref_dec, cfg, host_labels=False):
         import must3r_amd.model as M
+        self.host_labels = host_labels   # attach the host mirror of the label layout like MUSt3R._forward_scene does
         self.ref = ref_dec
         self.native = M.MUSt3R(img_size=(cfg.img_size,) * 2, enc_embed_dim=cfg.enc_dim, embed_dim=cfg.dec_dim, depth=cfg.dec_depth,
                                num_heads=cfg.dec_heads, feedback_type="single_mlp", memory_mode="kv")
@@ -448,16 +449,31 @@ class _InPlaceMemoryDecoder:
         for b, v in zip(owner.bufs, new_mem[0]):
             b[:, Nm:Nm + R] = v[:, Nm:]
         owner.valid = Nm + R
-        return (owner.views(Nm + R), new_mem[1], *new_mem[2:]), pm
+        labels = new_mem[1]
+        if self.host_labels:
+            runs = [] if current_mem is None else getattr(current_mem[1], "_m3r_runs", None)
+            if runs is not None and sum(c for _, c in runs) == Nm:
+                runs = list(runs)
+                first = 0 if current_mem is None else int(current_mem[2])
+                for xg in (x if isinstance(x, (list, tuple)) else [x]):
+                    runs += [(first + j, int(xg.shape[2])) for j in range(int(xg.shape[1]))]
+                    first += int(xg.shape[1])
+                assert sum(c for _, c in runs) == Nm + R
+                labels._m3r_runs = runs
+                self.mirrored = getattr(self, "mirrored", 0) + 1
+        return (owner.views(Nm + R), labels, *new_mem[2:]), pm
 
 
+@pytest.mark.parametrize("host_labels", [False, True])
 @pytest.mark.parametrize("video", [False, True])
-def test_drivers_on_in_place_memory_equal_reference(video):
+def test_drivers_on_in_place_memory_equal_reference(video, host_labels):
+    """``host_labels``: the label tensors carry the host mirror of their layout (``_m3r_runs``), so eviction / refresh /
+    restore build their indices on the host (no nonzero read-back); without it the helpers use the reference's boolean masks."""
     RI, MI, enc, dec, pp = _drivers()
     n = 10
     imgs, ts = _mixed_views(n, 5)
     ids = [torch.tensor(v) for v in range(n)]
-    native_like = _InPlaceMemoryDecoder(dec, TINY)
+    native_like = _InPlaceMemoryDecoder(dec, TINY, host_labels)
     with torch.no_grad():
         if video:
             args = ([2] + [1] * (n - 2),)
@@ -474,6 +490,10 @@ def test_drivers_on_in_place_memory_equal_reference(video):
     # the memory stayed in the decoder's buffers the whole way: no update had to copy it out
     assert native_like.appends > 0 and native_like.copies == 0, (native_like.appends, native_like.copies)
     assert getattr(got[0][0][0], "_m3r_owner", None) is not None
+    if host_labels:   # the mirror survived every surgery step and still describes the final labels
+        runs = getattr(got[0][1], "_m3r_runs", None)
+        assert runs is not None and native_like.mirrored == native_like.appends + 1
+        assert torch.equal(torch.cat([torch.full((c,), l) for l, c in runs]).view(1, -1), got[0][1])
     if not video:
         # rewind_mem is an optimisation, never a correctness requirement: without it the refinement passes copy the memory
         # out (the buffers still count the scratch rows) and the results are the same

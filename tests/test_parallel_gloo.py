@@ -11,7 +11,7 @@ import torch.multiprocessing as mp
 
 from must3r_amd.config import TINY
 from must3r_amd import synthetic as S
-from must3r_amd.parallel import all_gather_varlen, run_scene_sharded, shard_range
+from must3r_amd.parallel import all_gather_varlen, run_scene_sharded, run_video_sharded, shard_range
 
 V, H, W = 6, 48, 64
 
@@ -53,6 +53,17 @@ def _worker(rank, world, port, out_dir):
             out = run_scene_sharded(enc, dec, imgs[lo:hi], ts[lo:hi], _keyframes()[lo:hi], gather_outputs=True)
         torch.save({"render_all": out["render_all"], "mem_last": out["mem"][0][-1], "labels": out["mem"][1], "K": out["n_keyframes"]},
                    os.path.join(out_dir, f"r{rank}.pt"))
+        # a rank WITHOUT views (fewer views than ranks): empty encoder batch skipped, [0,H,W,7] render, gather still works
+        lo1, hi1 = shard_range(1, rank, world)
+        with torch.no_grad():
+            o1 = run_scene_sharded(enc, dec, imgs[lo1:hi1], ts[lo1:hi1], torch.ones(hi1 - lo1, dtype=torch.bool), gather_outputs=True)
+        assert o1["render"].shape == (hi1 - lo1, H, W, 7) and o1["render_all"].shape == (1, H, W, 7) and o1["n_keyframes"] == 1
+        # streaming schedule over the sharded sequence (window 3, every 2nd frame a keyframe)
+        with torch.no_grad():
+            ov = run_video_sharded(enc, dec, imgs[lo:hi], ts[lo:hi], local_context_size=3, is_keyframe=lambda i: i % 2 == 0,
+                                   gather_outputs=True)
+        torch.save({"render_all": ov["render_all"], "pm0": ov["pointmaps_0"], "labels": ov["mem"][1], "kf": ov["keyframes"],
+                    "mem_last": ov["mem"][0][-1]}, os.path.join(out_dir, f"v{rank}.pt"))
     finally:
         dist.destroy_process_group()
 
@@ -80,3 +91,13 @@ def test_sharded_scene_equals_single_process(tmp_path):
         one = run_scene_sharded(enc, dec, imgs, ts, _keyframes())
     assert torch.allclose(one["render"], r0["render_all"], atol=1e-6)
     assert torch.allclose(one["mem"][0][-1], r0["mem_last"], atol=1e-6) and torch.equal(one["mem"][1], r0["labels"])
+    # streaming: sharded == single process (engine.run_video + render of every frame against the final memory)
+    from must3r_amd.engine import run_video
+    v0, v1 = torch.load(tmp_path / "v0.pt"), torch.load(tmp_path / "v1.pt")
+    assert torch.equal(v0["render_all"], v1["render_all"]) and torch.equal(v0["pm0"], v1["pm0"]) and v0["kf"] == v1["kf"]
+    with torch.no_grad():
+        memv, pm0, kf = run_video(enc, dec, imgs, ts, local_context_size=3, is_keyframe=lambda i: i % 2 == 0)
+        _, renv = dec(*[t.unsqueeze(0) for t in enc(imgs, ts)], ts.unsqueeze(0), memv, render=True)
+    assert kf == v0["kf"] and torch.equal(memv[1], v0["labels"])
+    assert torch.allclose(pm0, v0["pm0"], atol=1e-6) and torch.allclose(renv[0], v0["render_all"], atol=1e-6)
+    assert torch.allclose(memv[0][-1], v0["mem_last"], atol=1e-6)
