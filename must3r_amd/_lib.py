@@ -11,6 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmust3r_hip.so")
 
 BF16, F16, F16_W2 = 0, 1, 2
+ATTN_FP8 = 0x100   # OR-able: fp8 (e4m3) attention operands, include/must3r_hip.h
 MEM_KV, MEM_NORM_Y, MEM_RAW = 0, 1, 2
 PART_ENCODER, PART_DECODER = 1, 2
 EPI_STORE16, EPI_STORE16_GELU, EPI_QKV_ROPE, EPI_RESID_F32, EPI_F32, EPI_HEAD = range(6)

@@ -11,6 +11,7 @@
 // Block = 4 waves x 32 query rows; K/V tiles of 64 keys DMA'd HBM->LDS (global_load_lds), double
 // buffered, one barrier per tile.  Keys may exclude one contiguous range per view (MUSt3R own-token rule,
 // decoder.py:119-139): fully excluded tiles are never loaded, partially excluded ones are masked.
+#include <cstdlib>
 #include "common.hpp"
 #include "kernels.hpp"
 
@@ -273,6 +274,376 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) a
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// attn2_kernel: the same transposed flash formulation, software-pipelined across key tiles, for 16-bit or fp8 (e4m3) operands.
+//
+// attn_kernel above serialises, per wave and tile, [QK^T MFMAs] -> [softmax VALU, with a data-dependent branch per 16 queries]
+// -> [PV MFMAs]: the matrix pipe idles through the softmax (r01 PMC: MFMA pipe 32 % busy, 36 % of the wave time stalled on the
+// MFMA -> softmax -> MFMA chain).  Here iteration i issues, in this order,
+//     S(next) = K(next) Q^T                       16 MFMAs, independent of everything in flight
+//     O      += V(cur)^T P(cur)  (+ row sums)     20 MFMAs
+//     softmax(S(next)) -> P(next), m, alpha       VALU, in the SAME basic block as the PV MFMAs (no branch inside), so the
+//                                                 compiler interleaves it with them: the matrix pipe stays fed by one wave
+// The online-softmax reference m only moves when a row maximum exceeds it by more than ATT_THR (lazy rescale, P <= 2^6); the
+// decision is per query = per lane (selects, no branch); O *= alpha is applied at the top of the NEXT iteration under one
+// wave-uniform branch that is almost never taken.  K and V are staged separately (K one tile ahead of V), still two buffers
+// each and one barrier per tile.
+//
+// F8: Q, K, V are OCP e4m3 bytes (probe: scripts/probes/fp8_probe.hip -> profiles/r02_fp8_probe.txt).  v_mfma_f32_16x16x32_fp8_fp8
+// takes 8 bytes per lane with the k-slot layout of the 16-bit shape (lane group g, byte e <-> k = 8g + e), so the C layout of
+// S^T is again the B layout of the second product with k-slot (g, e) <-> key {4g + e, 16 + 4g + e - 4} of a 32-key slot; V^T
+// comes from ds_read_b64_tr_b8 (16 lanes pass the 8-byte chunks of an 8 x 16 byte matrix and receive its columns): the 16 lanes
+// of group g pass the chunks of exactly those 8 key rows.  P is rounded to e4m3 (P <= 64 < 448: no clamp needed); the softmax,
+// the accumulators and the output stay fp32 / 16-bit.  Half the LDS and HBM bytes per key of the 16-bit kernel.
+template <class T, bool F8> struct AttnOperand;
+template <class T> struct AttnOperand<T, false> {
+    typedef T elem;
+    typedef typename Vec<T>::v8 frag;
+    static __device__ __forceinline__ f32x4 mma(frag a, frag b, f32x4 c) { return mfma16(a, b, c); }
+};
+template <class T> struct AttnOperand<T, true> {
+    typedef unsigned char elem;
+    typedef long frag;
+    static __device__ __forceinline__ f32x4 mma(long a, long b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(a, b, c, 0, 0, 0); }
+};
+
+// [rows][64 bytes] fp8 tiles: four rows share a 256-byte bank row.  XOR on the 16-byte PAIR index (the DMA granule):
+//   K  ds_read_b64 of 16 consecutive rows x 2 adjacent 8-byte chunks per 32-lane half: rows r, r+4, r+8, r+12 must differ
+//   V  ds_read_b64_tr_b8: a 32-lane half reads rows {4g..4g+3, 16+4g..} for g, g+1: rows r, r+4, r+16, r+20 must differ
+__device__ __forceinline__ int swz8_k(int row) { return (row >> 2) & 3; }
+__device__ __forceinline__ int swz8_v(int row) { return ((row >> 2) & 1) | (((row >> 4) & 1) << 1); }
+
+__device__ __forceinline__ void lds_read_tr8_x4(unsigned a0, unsigned a1, unsigned a2, unsigned a3, long (&out)[4]) {
+    u32x2 r0, r1, r2, r3;
+    asm volatile(
+        "ds_read_b64_tr_b8 %0, %4\n\t"
+        "ds_read_b64_tr_b8 %1, %5\n\t"
+        "ds_read_b64_tr_b8 %2, %6\n\t"
+        "ds_read_b64_tr_b8 %3, %7\n\t"
+        "s_waitcnt lgkmcnt(0)"
+        : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3)
+        : "v"(a0), "v"(a1), "v"(a2), "v"(a3)
+        : "memory");
+    const u32x2 r[4] = {r0, r1, r2, r3};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) __builtin_memcpy(&out[i], &r[i], 8);
+}
+
+template <class T, int QW, bool F8>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) attn2_kernel(const AttnArgs p, const int nqb, const int ngrp, const int nsplit) {
+    typedef AttnOperand<T, F8> OP;
+    typedef typename OP::elem E;
+    typedef typename OP::frag frag;
+    typedef typename Vec<T>::v4 v4;
+    constexpr int QF = QW / 16;
+    constexpr int QB = 4 * QW;
+    constexpr int TILE = ATT_KT * 64;            // elements of one K (or V) tile
+    __shared__ __attribute__((aligned(16))) E smem_kv[2][2][TILE];   // [K|V][buffer][64 keys x 64]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 15, fg = lane >> 4;
+
+    const int xcd = blockIdx.x & 7;
+    int slot = blockIdx.x >> 3;
+    const int split = slot % nsplit;
+    slot /= nsplit;
+    const int grp = (slot / nqb) * 8 + xcd;
+    const int qb = slot % nqb;
+    if (grp >= ngrp) return;
+    const int view = grp / p.heads, head = grp - view * p.heads;
+    const AttnView vw = p.views[view];
+    if (qb * QB >= vw.nq) return;
+
+    const E* __restrict__ Q = reinterpret_cast<const E*>(p.Q);
+    const E* __restrict__ K = reinterpret_cast<const E*>(p.K) + (size_t)vw.kv_row0 * p.ldk + head * 64;
+    const E* __restrict__ V = reinterpret_cast<const E*>(p.V) + (size_t)vw.kv_row0 * p.ldv + head * 64;
+
+    const int qr0 = qb * QB + wave * QW;
+    frag qf_[QF][2];
+#pragma unroll
+    for (int f = 0; f < QF; ++f) {
+        int r = qr0 + f * 16 + fr;
+        r = r < vw.nq ? r : vw.nq - 1;
+        const E* src = Q + (size_t)(vw.q_row0 + r) * p.ldq + head * 64 + fg * 8;
+        qf_[f][0] = *reinterpret_cast<const frag*>(src);
+        qf_[f][1] = *reinterpret_cast<const frag*>(src + 32);
+    }
+
+    const int nk = vw.nk, slo = vw.skip_lo, shi = vw.skip_hi;
+    const int ntiles = (nk + ATT_KT - 1) / ATT_KT;
+    auto fully_skipped = [&](int t) {
+        const int k0 = t * ATT_KT;
+        const int k1 = (k0 + ATT_KT < nk) ? k0 + ATT_KT : nk;
+        return k0 >= slo && k1 <= shi;
+    };
+    const int tps = (ntiles + nsplit - 1) / nsplit;
+    const int t_begin = split * tps;
+    const int t_end = (t_begin + tps < ntiles) ? t_begin + tps : ntiles;
+    auto advance = [&](int t) {
+        ++t;
+        while (t < t_end && fully_skipped(t)) ++t;
+        return t;
+    };
+
+    // ---- staging.  16-bit: a wave instruction moves 8 rows x 128 B, 8 pieces per tile, 2 per wave; fp8: 16 rows x 64 B, 4 pieces
+    // per tile, 1 per wave.  Lane-linear LDS image, swizzle on the source address (and again on the read side).
+    auto stage = [&](const E* __restrict__ base, int ld, int which, int t, int buf) {
+        if constexpr (!F8) {
+            const int srow = lane >> 3, pch = lane & 7;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int piece = wave * 2 + i;
+                const int r = piece * 8 + srow;
+                int key = t * ATT_KT + r;
+                key = key < nk ? key : nk - 1;
+                const int ch = which == 0 ? swz(r, pch) : swz_v(r, pch);
+                glds16(base + (size_t)key * ld + ch * 8, &smem_kv[which][buf][piece * 8 * 64]);
+            }
+        } else {
+            const int srow = lane >> 2, pp = lane & 3;
+            const int r = wave * 16 + srow;
+            int key = t * ATT_KT + r;
+            key = key < nk ? key : nk - 1;
+            const int pr = pp ^ (which == 0 ? swz8_k(r) : swz8_v(r));
+            glds16(base + (size_t)key * ld + pr * 16, &smem_kv[which][buf][wave * 16 * 64]);
+        }
+    };
+
+    f32x4 o_[4][QF], ol_[QF];
+    float m_[QF], alpha_[QF];
+#pragma unroll
+    for (int f = 0; f < QF; ++f) {
+        m_[f] = -INFINITY;
+        alpha_[f] = 1.0f;
+        ol_[f] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int d = 0; d < 4; ++d) o_[d][f] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const float c = p.q_prescaled ? 1.0f : p.scale * 1.44269504088896340736f;
+    const float inv_c = 1.0f / c;
+    frag ones;
+    if constexpr (F8) ones = 0x3838383838383838L;   // e4m3 1.0
+    else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) ones[e] = (T)1.0f;
+    }
+
+    // ---- S^T(t) = K(t) Q^T - m  (base-2 domain), masked
+    auto qk = [&](int t, int buf, f32x4 (&s_)[4][QF]) {
+        const E* k_ = smem_kv[0][buf];
+#pragma unroll
+        for (int f = 0; f < QF; ++f) {
+            const float mref = (m_[f] == -INFINITY) ? 0.f : m_[f];
+            const float ini = -mref * inv_c;
+#pragma unroll
+            for (int kf = 0; kf < 4; ++kf) s_[kf][f] = f32x4{ini, ini, ini, ini};
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+            for (int kf = 0; kf < 4; ++kf) {
+                const int r = kf * 16 + fr;
+                frag kfrag;
+                if constexpr (!F8) kfrag = *reinterpret_cast<const frag*>(k_ + r * 64 + swz(r, ks * 4 + fg) * 8);
+                else kfrag = *reinterpret_cast<const frag*>(k_ + r * 64 + ((ks * 2 + (fg >> 1)) ^ swz8_k(r)) * 16 + (fg & 1) * 8);
+#pragma unroll
+                for (int f = 0; f < QF; ++f) s_[kf][f] = OP::mma(kfrag, qf_[f][ks], s_[kf][f]);
+            }
+        }
+        if (!p.q_prescaled) {
+#pragma unroll
+            for (int kf = 0; kf < 4; ++kf)
+#pragma unroll
+                for (int f = 0; f < QF; ++f) s_[kf][f] *= c;
+        }
+        const int k0 = t * ATT_KT;
+        const bool need_mask = (k0 + ATT_KT > nk) || (k0 < shi && k0 + ATT_KT > slo);
+        if (need_mask) {
+#pragma unroll
+            for (int kf = 0; kf < 4; ++kf)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int key = k0 + kf * 16 + fg * 4 + r;
+                    const bool bad = (key >= nk) | ((key >= slo) & (key < shi));
+                    const float pen = bad ? -INFINITY : 0.f;
+#pragma unroll
+                    for (int f = 0; f < QF; ++f) s_[kf][f][r] += pen;
+                }
+        }
+    };
+    // ---- online softmax of one tile, per query = per lane column, no branch: P = 2^(S - d), reference m moves by d
+    auto softmax = [&](f32x4 (&s_)[4][QF], frag (&pb)[QF][2], bool& any_grow) {
+        any_grow = false;
+#pragma unroll
+        for (int f = 0; f < QF; ++f) {
+            float mx = -INFINITY;
+#pragma unroll
+            for (int kf = 0; kf < 4; ++kf)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s_[kf][f][r]);
+            mx = quad_row_max(mx);
+            // fp8: P is stored with 3 mantissa bits and flushes below 2^-10, so its window is moved up: the reference follows the
+            // running maximum more closely (threshold 2 instead of 6) and P carries a constant factor 2^6 (P <= 2^8 < 448); the
+            // factor is in O and in the row sums alike and cancels in O / l (also across split-KV partials).
+            constexpr float THR = F8 ? 2.0f : ATT_THR;
+            constexpr float PSH = F8 ? 6.0f : 0.0f;
+            const bool first = (m_[f] == -INFINITY);
+            const bool grow = first ? (mx != -INFINITY) : (mx > THR);
+            const float d = grow ? mx : 0.f;
+            const float dp = d - PSH;
+            alpha_[f] = (grow && !first) ? __builtin_amdgcn_exp2f(-d) : 1.0f;
+            m_[f] = grow ? (first ? d : m_[f] + d) : m_[f];
+            any_grow |= (grow && !first);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                float e_[8];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    e_[r] = __builtin_amdgcn_exp2f(s_[2 * ks][f][r] - dp);
+                    e_[4 + r] = __builtin_amdgcn_exp2f(s_[2 * ks + 1][f][r] - dp);
+                }
+                if constexpr (!F8) {
+                    f32x8 pv;
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) pv[r] = e_[r];
+                    pb[f][ks] = cvt8<T>(pv);
+                } else {
+                    int lo = 0, hi = 0;
+                    lo = __builtin_amdgcn_cvt_pk_fp8_f32(e_[0], e_[1], lo, false);
+                    lo = __builtin_amdgcn_cvt_pk_fp8_f32(e_[2], e_[3], lo, true);
+                    hi = __builtin_amdgcn_cvt_pk_fp8_f32(e_[4], e_[5], hi, false);
+                    hi = __builtin_amdgcn_cvt_pk_fp8_f32(e_[6], e_[7], hi, true);
+                    pb[f][ks] = (long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
+                }
+            }
+        }
+        any_grow = __any(any_grow);
+    };
+    // ---- O^T += V(t)^T P^T and the row sums (ones row); k-slot (g, e) <-> keys {4g+e, 16+4g+e-4} of each 32-key slot
+    auto pv_mma = [&](int buf, frag (&pb)[QF][2]) {
+        const E* v_ = smem_kv[1][buf];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+            for (int f = 0; f < QF; ++f) ol_[f] = OP::mma(ones, pb[f][ks], ol_[f]);
+            frag vfrag[4];
+            if constexpr (!F8) {
+                // two d-fragments at a time: 8 live registers of V^T instead of 16 (163 instead of 171 VGPRs: 3 waves per SIMD)
+                const int r0 = ks * 32 + fg * 4 + (fr >> 2), r1 = r0 + 16;
+                const int c0 = (fr & 3) * 4;
+#pragma unroll
+                for (int dh = 0; dh < 2; ++dh) {
+                    v4 tr[4];
+                    const T* a[4];
+#pragma unroll
+                    for (int d = 0; d < 2; ++d) {
+                        const int dc = (dh * 2 + d) * 16 + c0;
+                        a[2 * d] = v_ + r0 * 64 + swz_v(r0, dc >> 3) * 8 + (dc & 7);
+                        a[2 * d + 1] = v_ + r1 * 64 + swz_v(r1, dc >> 3) * 8 + (dc & 7);
+                    }
+                    lds_read_tr4_x4<T>(a[0], a[1], a[2], a[3], tr);
+#pragma unroll
+                    for (int d = 0; d < 2; ++d) {
+                        const frag vf = __builtin_shufflevector(tr[2 * d], tr[2 * d + 1], 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+                        for (int f = 0; f < QF; ++f) o_[dh * 2 + d][f] = OP::mma(vf, pb[f][ks], o_[dh * 2 + d][f]);
+                    }
+                }
+                continue;
+            } else {
+                const int e = fr >> 1;
+                const int row = ks * 32 + (e < 4 ? 4 * fg + e : 16 + 4 * fg + (e - 4));
+                const unsigned base = (unsigned)(size_t)(__attribute__((address_space(3))) const E*)(v_) + row * 64 + (fr & 1) * 8;
+                const int sw = swz8_v(row);
+                long t4[4];
+                lds_read_tr8_x4(base + ((0 ^ sw) << 4), base + ((1 ^ sw) << 4), base + ((2 ^ sw) << 4), base + ((3 ^ sw) << 4), t4);
+#pragma unroll
+                for (int d = 0; d < 4; ++d) vfrag[d] = t4[d];
+            }
+#pragma unroll
+            for (int d = 0; d < 4; ++d)
+#pragma unroll
+                for (int f = 0; f < QF; ++f) o_[d][f] = OP::mma(vfrag[d], pb[f][ks], o_[d][f]);
+        }
+    };
+    auto rescale = [&]() {
+#pragma unroll
+        for (int f = 0; f < QF; ++f) {
+#pragma unroll
+            for (int d = 0; d < 4; ++d) o_[d][f] *= alpha_[f];
+            ol_[f] *= alpha_[f];
+        }
+    };
+
+    // ---- pipeline.  LDS: K(t) lives in K buffer (i & 1) of ITS iteration i, V alike; iteration i multiplies P(cur) V(cur) and
+    // computes S(next): it needs V(cur) and K(next), both issued during iteration i-1 (or the prologue), and refills the buffers
+    // whose tiles were last read in iteration i-1 (K(cur), V(prev)) after the barrier.
+    int cur = advance(t_begin - 1);
+    if (cur < t_end) {
+        int nxt = advance(cur);
+        stage(K, p.ldk, 0, cur, 0);
+        stage(V, p.ldv, 1, cur, 0);
+        if (nxt < t_end) stage(K, p.ldk, 0, nxt, 1);
+        __builtin_amdgcn_s_waitcnt(0x0f70);   // (K(cur) alone would do for the first product; one wait keeps the prologue simple)
+        __syncthreads();
+        frag pcur[QF][2];
+        bool grew = false;
+        {
+            f32x4 s0[4][QF];
+            qk(cur, 0, s0);
+            softmax(s0, pcur, grew);    // first tile: alpha = 1 by construction
+        }
+        int it = 0;
+        while (nxt < t_end) {
+            __builtin_amdgcn_s_waitcnt(0x0f70);   // V(cur), K(nxt) of this wave have landed
+            __syncthreads();                      // ... everyone's have; K(cur) / V(prev) are no longer being read
+            const int nxt2 = advance(nxt);
+            if (nxt2 < t_end) stage(K, p.ldk, 0, nxt2, it & 1);
+            stage(V, p.ldv, 1, nxt, (it + 1) & 1);
+            f32x4 s_[4][QF];
+            qk(nxt, (it + 1) & 1, s_);
+            if (grew) rescale();                  // wave-uniform, rare: O *= alpha before P(cur) is added
+            pv_mma(it & 1, pcur);
+            softmax(s_, pcur, grew);              // same basic block as the PV MFMAs above: interleaved by the scheduler
+            cur = nxt;
+            nxt = nxt2;
+            ++it;
+        }
+        __builtin_amdgcn_s_waitcnt(0x0f70);
+        __syncthreads();
+        if (grew) rescale();
+        pv_mma(it & 1, pcur);
+    }
+
+    // ---- normalise and store: lane (q = fr, g) holds O[q][d = 16 dd + 4 g + r]
+    T* __restrict__ O = reinterpret_cast<T*>(p.O);
+#pragma unroll
+    for (int f = 0; f < QF; ++f) {
+        const float l = ol_[f][0];
+        const int q = qr0 + f * 16 + fr;
+        if (q >= vw.nq) continue;
+        const size_t row = (size_t)(vw.q_row0 + q);
+        if (nsplit <= 1) {
+            const float inv = l > 0.f ? 1.0f / l : 0.f;
+            T* dst = O + row * p.ldo + head * 64 + fg * 4;
+#pragma unroll
+            for (int d = 0; d < 4; ++d) *reinterpret_cast<v4*>(dst + d * 16) = cvt4<T>(o_[d][f] * inv);
+        } else {
+            const size_t D = (size_t)p.heads * 64;
+            float* po = p.part_o + ((size_t)split * p.total_q_rows + row) * D + head * 64 + fg * 4;
+#pragma unroll
+            for (int d = 0; d < 4; ++d) *reinterpret_cast<f32x4*>(po + d * 16) = o_[d][f];
+            if (fg == 0) {
+                float* pm = p.part_ml + (((size_t)split * p.total_q_rows + row) * p.heads + head) * 2;
+                pm[0] = m_[f];
+                pm[1] = l;
+            }
+        }
+    }
+}
+
 // merge of the split-KV partials: O = sum_s 2^(m_s - m*) O_s / sum_s 2^(m_s - m*) l_s ; one thread = 4 columns
 template <class T>
 __global__ void attn_combine_kernel(const AttnArgs p, const int nsplit) {
@@ -353,7 +724,7 @@ int launch_tr_probe(short* out, hipStream_t s) {
 // phase 0: (m,l) pre-fill (split-KV with holes only), 1: main kernel, 2: combine (split-KV only)
 int launch_attention_phase(DType dt, const AttnArgs& a, int phase, hipStream_t s, const char** err) {
     if (a.nviews <= 0 || a.max_nq <= 0) return 0;
-    if ((a.ldq % 8) || (a.ldk % 8) || (a.ldv % 8) || (a.ldo % 4)) { *err = "attention: row strides must be 16-byte aligned"; return 1; }
+    if ((a.ldq % (a.fp8 ? 16 : 8)) || (a.ldk % (a.fp8 ? 16 : 8)) || (a.ldv % (a.fp8 ? 16 : 8)) || (a.ldo % 4)) { *err = "attention: row strides must be 16-byte aligned"; return 1; }
     const int nsplit = a.nsplit > 1 ? a.nsplit : 1;
     if (nsplit > 1 && (!a.part_o || !a.part_ml || a.total_q_rows <= 0)) { *err = "attention: split-KV needs scratch"; return 1; }
     // Launches that cannot fill 256 CUs even with one block each (a single view's self attention in the memory
@@ -371,13 +742,23 @@ int launch_attention_phase(DType dt, const AttnArgs& a, int phase, hipStream_t s
                                a.part_ml, n2);
         }
     } else if (phase == 1) {
-        if (small) {
-            if (dt == DT_BF16) hipLaunchKernelGGL((attn_kernel<bf16_t, 16>), dim3(grid), dim3(256), 0, s, a, nqb, ngrp, nsplit);
-            else hipLaunchKernelGGL((attn_kernel<f16_t, 16>), dim3(grid), dim3(256), 0, s, a, nqb, ngrp, nsplit);
-        } else {
-            if (dt == DT_BF16) hipLaunchKernelGGL((attn_kernel<bf16_t, 32>), dim3(grid), dim3(256), 0, s, a, nqb, ngrp, nsplit);
-            else hipLaunchKernelGGL((attn_kernel<f16_t, 32>), dim3(grid), dim3(256), 0, s, a, nqb, ngrp, nsplit);
+        static int variant = -1;   // M3R_ATTN=0: the round-1 kernel (attn_kernel); default: the pipelined attn2_kernel
+        if (variant < 0) {
+            const char* e = getenv("M3R_ATTN");
+            variant = e ? atoi(e) : 1;
         }
+#define M3R_LAUNCH_ATTN(KERNEL) hipLaunchKernelGGL(KERNEL, dim3(grid), dim3(256), 0, s, a, nqb, ngrp, nsplit)
+        if (a.fp8) {
+            if (small) { if (dt == DT_BF16) M3R_LAUNCH_ATTN((attn2_kernel<bf16_t, 16, true>)); else M3R_LAUNCH_ATTN((attn2_kernel<f16_t, 16, true>)); }
+            else { if (dt == DT_BF16) M3R_LAUNCH_ATTN((attn2_kernel<bf16_t, 32, true>)); else M3R_LAUNCH_ATTN((attn2_kernel<f16_t, 32, true>)); }
+        } else if (variant == 0) {
+            if (small) { if (dt == DT_BF16) M3R_LAUNCH_ATTN((attn_kernel<bf16_t, 16>)); else M3R_LAUNCH_ATTN((attn_kernel<f16_t, 16>)); }
+            else { if (dt == DT_BF16) M3R_LAUNCH_ATTN((attn_kernel<bf16_t, 32>)); else M3R_LAUNCH_ATTN((attn_kernel<f16_t, 32>)); }
+        } else {
+            if (small) { if (dt == DT_BF16) M3R_LAUNCH_ATTN((attn2_kernel<bf16_t, 16, false>)); else M3R_LAUNCH_ATTN((attn2_kernel<f16_t, 16, false>)); }
+            else { if (dt == DT_BF16) M3R_LAUNCH_ATTN((attn2_kernel<bf16_t, 32, false>)); else M3R_LAUNCH_ATTN((attn2_kernel<f16_t, 32, false>)); }
+        }
+#undef M3R_LAUNCH_ATTN
     } else if (nsplit > 1) {
         const size_t total = (size_t)a.total_q_rows * a.heads * 16;
         const unsigned g2 = (unsigned)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);

@@ -35,6 +35,15 @@ __device__ __forceinline__ f32x4 mfma16(f16x8 a, f16x8 b, f32x4 c) {
 template <class T> __device__ __forceinline__ typename Vec<T>::v4 cvt4(f32x4 v) {
     return __builtin_convertvector(v, typename Vec<T>::v4);
 }
+// saturating form for the GEMM epilogues: an fp16 store of |v| > 65504 would be +-inf and turn into NaN downstream (LayerNorm,
+// softmax); the value is clamped to the largest finite fp16 instead (in-range values: same bits).  bf16 has fp32's range.
+template <class T> __device__ __forceinline__ typename Vec<T>::v4 cvt4_sat(f32x4 v) {
+    if constexpr (sizeof(T) == 2 && !__is_same(T, bf16_t)) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = __builtin_amdgcn_fmed3f(v[r], -65504.0f, 65504.0f);
+    }
+    return __builtin_convertvector(v, typename Vec<T>::v4);
+}
 template <class T> __device__ __forceinline__ typename Vec<T>::v8 cvt8(f32x8 v) {
     return __builtin_convertvector(v, typename Vec<T>::v8);
 }
@@ -70,6 +79,26 @@ __device__ __forceinline__ void lds_read_tr4_x8(const T* p0, const T* p1, const 
     const u32x2 r[8] = {r0, r1, r2, r3, r4, r5, r6, r7};
 #pragma unroll
     for (int i = 0; i < 8; ++i) __builtin_memcpy(&out[i], &r[i], 8);
+}
+
+// four transposing reads (two d-fragments of one 32-key slot) -- same contract as lds_read_tr4_x8, half the live registers
+template <class T>
+__device__ __forceinline__ void lds_read_tr4_x4(const T* p0, const T* p1, const T* p2, const T* p3, typename Vec<T>::v4 (&out)[4]) {
+    u32x2 r0, r1, r2, r3;
+#define M3R_LDS_ADDR(p) ((unsigned)(size_t)(__attribute__((address_space(3))) const T*)(p))
+    asm volatile(
+        "ds_read_b64_tr_b16 %0, %4\n\t"
+        "ds_read_b64_tr_b16 %1, %5\n\t"
+        "ds_read_b64_tr_b16 %2, %6\n\t"
+        "ds_read_b64_tr_b16 %3, %7\n\t"
+        "s_waitcnt lgkmcnt(0)"
+        : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3)
+        : "v"(M3R_LDS_ADDR(p0)), "v"(M3R_LDS_ADDR(p1)), "v"(M3R_LDS_ADDR(p2)), "v"(M3R_LDS_ADDR(p3))
+        : "memory");
+#undef M3R_LDS_ADDR
+    const u32x2 r[4] = {r0, r1, r2, r3};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) __builtin_memcpy(&out[i], &r[i], 8);
 }
 
 // async global -> LDS, 16 bytes per lane; LDS destination = (wave-uniform) lds_base + lane*16.

@@ -73,12 +73,12 @@ __device__ __forceinline__ void epilogue_row(const GemmArgs& p, void* const outp
     for (int j = 0; j < NF; ++j) {
         const int n = nb + j * 16;
         if constexpr (EPI == EPI_STORE16 || EPI == EPI_QKV_ROPE) {
-            *reinterpret_cast<v4*>(reinterpret_cast<T*>(outp) + (size_t)m * p.ldc + n) = cvt4<T>(v[j]);
+            *reinterpret_cast<v4*>(reinterpret_cast<T*>(outp) + (size_t)m * p.ldc + n) = cvt4_sat<T>(v[j]);
         } else if constexpr (EPI == EPI_STORE16_GELU) {
             f32x4 g;
 #pragma unroll
             for (int r = 0; r < 4; ++r) g[r] = gelu_erf(v[j][r]);
-            *reinterpret_cast<v4*>(reinterpret_cast<T*>(outp) + (size_t)m * p.ldc + n) = cvt4<T>(g);
+            *reinterpret_cast<v4*>(reinterpret_cast<T*>(outp) + (size_t)m * p.ldc + n) = cvt4_sat<T>(g);
         } else if constexpr (EPI == EPI_RESID_F32) {
             f32x4* o = reinterpret_cast<f32x4*>(reinterpret_cast<float*>(outp) + (size_t)m * p.ldc + n);
             *o = *o + v[j];
@@ -408,7 +408,7 @@ __global__ void __launch_bounds__(512) gemm256_kernel(const GemmArgs p) {
     typedef typename Vec<T>::v8 v8;
     constexpr int BM = 256, BK = 32;
     constexpr int WR = WS * BN;                // rows of the staged weight region: [hi BN rows | lo BN rows] when split
-    constexpr int NST = WR == 512 ? 3 : 4;     // 48 KB stages x 3 (split, BN 256) or 32 KB stages x 4
+    constexpr int NST = WR >= 384 ? 3 : 4;     // 48 / 40 KB stages x 3 (split, BN 256 / 192) or 32 KB stages x 4
     constexpr int WN = BN / 4;                 // wave tile: 128 (m) x WN (n)
     constexpr int MF = 8, NF = WN / 16;        // 16x16 fragments per wave tile
     constexpr int PW = WR / 128;               // weight DMA instructions per wave and K-tile (A: 2)
@@ -558,7 +558,7 @@ __global__ void __launch_bounds__(512) gemm256_kernel(const GemmArgs p) {
 template <class T, int EPI, int WS, int BN>
 static int launch_256(const GemmArgs& a, hipStream_t s) {
     const int nbn = a.N / BN, nbm = (a.M + 255) / 256;
-    const size_t lds = (size_t)(WS * BN == 512 ? 3 : 4) * (256 + WS * BN) * 32 * sizeof(T);
+    const size_t lds = (size_t)(WS * BN >= 384 ? 3 : 4) * (256 + WS * BN) * 32 * sizeof(T);
     static bool attr_set = false;
     if (!attr_set) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256_kernel<T, EPI, WS, BN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -779,16 +779,30 @@ static int launch_epi(const GemmArgs& a, hipStream_t s, const char** err) {
     if (a.wsplit == 2) {
         if constexpr (sizeof(T) == 2 && std::is_same<T, f16_t>::value) {
             const long tiles = (long)((a.M + 127) / 128) * (a.N / 64) * nb;
-            const long t256 = rb256 * (a.N / 256), t128 = rb256 * (a.N / 128);
+            const long t256 = rb256 * (a.N / 256), t192 = rb256 * (a.N / 192), t128 = rb256 * (a.N / 128);
             const bool ok256 = a.N % 256 == 0 && a.K % 32 == 0, ok128 = a.N % 128 == 0 && a.K % 32 == 0;
+            // 192-column tiles (wave tile 128 x 48): N = 768 at M = 15360 is 240 tiles = ONE round at 94 % fill, where 256 columns
+            // give 180 tiles (70 %) and 128 columns two rounds.  Not for the RoPE epilogue (its rotate-half pairs need 32-column
+            // aligned wave tiles).
+            static const bool no192 = getenv("M3R_G256_NO192") != nullptr;   // experiments: the round-1 selection
+            const bool ok192 = a.N % 192 == 0 && a.K % 32 == 0 && EPI != EPI_QKV_ROPE && !no192;
             int pick = 0;
             if (mode == 2) pick = (g256_bn_override() == 128 || !ok256) ? (ok128 ? 128 : 0) : 256;
             else if (mode == 1) {
-                if (ok256 && t256 >= 200 && fill256(t256) >= 80) pick = 256;
-                else if (ok128 && t128 >= 200 && fill256(t128) >= 80) pick = 128;
+                // cost ~ rounds over the 256 CUs x tile width; eligible when its rounds are reasonably full; ties -> wider tile
+                long best = -1;
+                const int bns[3] = {256, 192, 128};
+                const long ts[3] = {t256, t192, t128};
+                const bool oks[3] = {ok256, ok192, ok128};
+                for (int i = 0; i < 3; ++i) {
+                    if (!oks[i] || ts[i] < 200 || fill256(ts[i]) < 80) continue;
+                    const long cost = ((ts[i] + 255) / 256) * bns[i];
+                    if (best < 0 || cost < best) { best = cost; pick = bns[i]; }
+                }
             }
             if (EPI != EPI_QKV_ROPE && EPI != EPI_HEAD && use_48(a, nb)) rc = launch_48<T, EPI == EPI_QKV_ROPE || EPI == EPI_HEAD ? EPI_STORE16 : EPI, 2>(a, s);
             else if (pick == 256) rc = launch_256<T, EPI, 2, 256>(a, s);
+            else if (pick == 192) rc = launch_256<T, EPI == EPI_QKV_ROPE ? EPI_STORE16 : EPI, 2, 192>(a, s);
             else if (pick == 128) rc = launch_256<T, EPI, 2, 128>(a, s);
             else if (tiles >= min_big(true)) rc = launch_cfg<T, 128, 64, 2, 2, EPI, 2, 2>(a, s);
             else if (small8((long)((a.M + 63) / 64) * (a.N / 64) * nb)) rc = launch_cfg<T, 64, 64, SMALL_WGM, 2, EPI, SMALL8_NST_SPLIT, 2, 64, 1>(a, s);

@@ -82,6 +82,7 @@ struct AttnArgs {
     float* part_ml;        // [nsplit][total_q_rows][heads][2] fp32 (running max in log2 domain, row sum)
     int total_q_rows;      // max over views of q_row0 + nq
     int dense_rows;        // every row < total_q_rows belongs to a view of this launch (no (m,l) pre-fill needed)
+    int fp8;               // Q, K, V are OCP e4m3 bytes (row strides in bytes); O stays 16-bit.  attn2_kernel<.., F8 = true>
 };
 // bytes of scratch launch_attention needs for a given split factor
 size_t attention_split_scratch_bytes(int nsplit, int total_q_rows, int heads);
@@ -117,6 +118,9 @@ int launch_layernorm(DType dt, const LnArgs& a, hipStream_t s, const char** err)
 int launch_im2col(DType dt, const float* img, void* out16, int V, int H, int W, hipStream_t s, const char** err);
 // fp32 -> 16-bit (and optional low part)
 int launch_cast(DType dt, const float* in, void* out16, void* out16_lo, size_t n, hipStream_t s, const char** err);
+// 16-bit [rows, ld_in] -> e4m3 bytes [rows, ld_out] (clamped to +-448); optional per-group output table (rows_per_group rows each)
+int launch_quant8(DType dt, const void* in16, int ld_in, void* out8, int ld_out, void* const* out_table, int rows_per_group,
+                  size_t rows, int cols, hipStream_t s, const char** err);
 // pos int64 [V, gh*gw, 2] = (y, x) row-major grid
 int launch_fill_pos(int64_t* pos, int V, int gh, int gw, hipStream_t s, const char** err);
 // pointmaps [npix,7] fp32 -> pts3d [npix,3], pts3d_local [npix,3], conf [npix]

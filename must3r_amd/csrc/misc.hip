@@ -146,6 +146,53 @@ int launch_cast(DType dt, const float* in, void* out16, void* out16_lo, size_t n
 }
 
 // ------------------------------------------------------------------------------------------------
+// 16-bit -> OCP e4m3 (fp8 attention operands, include/must3r_hip.h MUST3R_ATTN_FP8): out8[r][c] = e4m3(clamp(in[r][c], +-448)).
+// v_cvt_pk_fp8_f32 does NOT saturate (1000 -> NaN, profiles/r02_fp8_probe.txt), hence the clamp.  One thread = 8 columns
+// (16 B read, 8 B written).  Rows may be grouped: row r of group g = r / rows_per_group goes to out_table[g] (the per-layer
+// memory buffers of the grouped post-feedback K|V projection).
+// ------------------------------------------------------------------------------------------------
+template <class T>
+__global__ void quant8_kernel(const T* __restrict__ in, int ld_in, unsigned char* __restrict__ out, int ld_out, void* const* out_table,
+                              int rows_per_group, size_t rows, int cols) {
+    typedef typename Vec<T>::v8 v8;
+    const int cpr = cols / 8;
+    const size_t total = rows * (size_t)cpr;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const size_t r = idx / cpr;
+        const int c = (int)(idx - r * cpr) * 8;
+        const f32x8 x = __builtin_convertvector(*reinterpret_cast<const v8*>(in + r * ld_in + c), f32x8);
+        float y[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) y[e] = __builtin_amdgcn_fmed3f(x[e], -448.0f, 448.0f);
+        int lo = 0, hi = 0;
+        lo = __builtin_amdgcn_cvt_pk_fp8_f32(y[0], y[1], lo, false);
+        lo = __builtin_amdgcn_cvt_pk_fp8_f32(y[2], y[3], lo, true);
+        hi = __builtin_amdgcn_cvt_pk_fp8_f32(y[4], y[5], hi, false);
+        hi = __builtin_amdgcn_cvt_pk_fp8_f32(y[6], y[7], hi, true);
+        unsigned char* dst = out;
+        size_t rr = r;
+        if (out_table) {
+            const size_t g = r / rows_per_group;
+            dst = reinterpret_cast<unsigned char*>(out_table[g]);
+            rr = r - g * rows_per_group;
+        }
+        *reinterpret_cast<u32x2*>(dst + rr * ld_out + c) = u32x2{(unsigned)lo, (unsigned)hi};
+    }
+}
+
+int launch_quant8(DType dt, const void* in16, int ld_in, void* out8, int ld_out, void* const* out_table, int rows_per_group,
+                  size_t rows, int cols, hipStream_t s, const char** err) {
+    if (!rows || !cols) return 0;
+    if (cols % 8 || ld_in % 8 || ld_out % 8) { *err = "quant8: cols and row strides must be multiples of 8"; return 1; }
+    const size_t total = rows * (size_t)(cols / 8);
+    const int grid = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    if (dt == DT_BF16) hipLaunchKernelGGL(quant8_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t*)in16, ld_in, (unsigned char*)out8, ld_out, out_table, rows_per_group, rows, cols);
+    else hipLaunchKernelGGL(quant8_kernel<f16_t>, dim3(grid), dim3(256), 0, s, (const f16_t*)in16, ld_in, (unsigned char*)out8, ld_out, out_table, rows_per_group, rows, cols);
+    if (hipGetLastError() != hipSuccess) { *err = "quant8: launch failed"; return 1; }
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
 // positions: pos[v][gy*gw+gx] = (gy, gx)   (croco PositionGetter)
 // ------------------------------------------------------------------------------------------------
 __global__ void fill_pos_kernel(int64_t* pos, int V, int gh, int gw) {

@@ -69,6 +69,7 @@ struct must3r_hip_ctx {
     std::map<std::string, Param> params;
     bool fin_enc = false, fin_dec = false;
     int wsplit = 0;            // 2 while a forward runs in MUST3R_F16_W2 mode
+    int attn8 = 0;             // 1 while a forward runs with MUST3R_ATTN_FP8 (e4m3 attention operands)
     float* rope_tab = nullptr;
     int rope_npos = 0;
     // workspace arena (grow-only)
@@ -198,6 +199,13 @@ static int layernorm_a(must3r_hip_ctx* c, DType dt, const LnArgs& a, hipStream_t
 static int layernorm(must3r_hip_ctx* c, DType dt, const float* x, const float* add, const float* w, const float* b,
                      void* o16, void* o16lo, float* o32, float* copy, int M, int C, float eps, hipStream_t s) {
     return layernorm_a(c, dt, lnargs(x, add, w, b, o16, o16lo, o32, copy, M, C, eps), s);
+}
+static int quant8(must3r_hip_ctx* c, DType dt, const void* in16, int ld_in, void* out8, int ld_out, void* const* out_table,
+                  int rows_per_group, size_t rows, int cols, hipStream_t s) {
+    const char* err = "";
+    ProfScope ps(c, s, PC_MISC, 0.0);
+    if (launch_quant8(dt, in16, ld_in, out8, ld_out, out_table, rows_per_group, rows, cols, s, &err)) return fail("%s", err);
+    return 0;
 }
 static int attention(must3r_hip_ctx* c, DType dt, const AttnArgs& a, double flops, int cat, hipStream_t s) {
     const char* err = "";
@@ -529,6 +537,7 @@ static int encode_chunk(must3r_hip_ctx* c, DType dt, const float* img, int V, in
     need = ws_need(need, (size_t)R * 3 * C, 2);
     need = ws_need(need, (size_t)R * C, 2);
     need = ws_need(need, (size_t)R * F, 2);
+    need = ws_need(need, c->attn8 ? (size_t)R * 3 * C : 0, 1);
     M3R_OK(ws_reserve(c, need, s));
     uint16_t* P16 = ws_take<uint16_t>(c, (size_t)R * 768);
     float* x = ws_take<float>(c, (size_t)R * C);
@@ -536,7 +545,8 @@ static int encode_chunk(must3r_hip_ctx* c, DType dt, const float* img, int V, in
     uint16_t* qkv = ws_take<uint16_t>(c, (size_t)R * 3 * C);
     uint16_t* a16 = ws_take<uint16_t>(c, (size_t)R * C);
     uint16_t* g16 = ws_take<uint16_t>(c, (size_t)R * F);
-    if (!g16) return fail("encode: workspace sizing bug");
+    uint8_t* q8 = c->attn8 ? ws_take<uint8_t>(c, (size_t)R * 3 * C) : nullptr;
+    if (!g16 || (c->attn8 && !q8)) return fail("encode: workspace sizing bug");
 
     {
         ProfScope ps(c, s, PC_MISC, 0.0);
@@ -566,6 +576,10 @@ static int encode_chunk(must3r_hip_ctx* c, DType dt, const float* img, int V, in
         aa.ldq = aa.ldk = aa.ldv = 3 * C; aa.ldo = C; aa.heads = Hh;
         aa.views = reinterpret_cast<const AttnView*>(views_dev); aa.nviews = V; aa.max_nq = N; aa.scale = 0.125f;
         aa.q_prescaled = 1;
+        if (c->attn8) {   // e4m3 copies of q | k | v (same row layout, one byte per element)
+            M3R_OK(quant8(c, dt, qkv, 3 * C, q8, 3 * C, nullptr, 0, (size_t)R, 3 * C, s));
+            aa.Q = q8; aa.K = q8 + C; aa.V = q8 + 2 * C; aa.fp8 = 1;
+        }
         M3R_OK(attention(c, dt, aa, 4.0 * V * (double)N * N * C, PC_ATTN_SA, s));
         M3R_OK(w16(c, b + ".attn.proj.weight", dt, &w, s));
         M3R_OK(gemm(c, dt, EPI_RESID_F32, gargs(a16, w, p32(c, b + ".attn.proj.bias"), x, R, C, C, C, C), s));
@@ -585,6 +599,8 @@ extern "C" int must3r_hip_encode(must3r_hip_ctx* c, int dtype, const float* img,
                                  float* out_tokens, int64_t* out_pos, void* stream) {
     if (!c || !img || !out_tokens || !out_pos) return fail("encode: null argument");
     if (!c->fin_enc) return fail("encode: encoder weights not finalized");
+    c->attn8 = (dtype & MUST3R_ATTN_FP8) ? 1 : 0;
+    dtype &= ~MUST3R_ATTN_FP8;
     if (dtype != MUST3R_BF16 && dtype != MUST3R_F16 && dtype != MUST3R_F16_W2) return fail("encode: bad dtype %d", dtype);
     c->wsplit = dtype == MUST3R_F16_W2 ? 2 : 0;
     if (dtype == MUST3R_F16_W2) dtype = MUST3R_F16;
@@ -610,8 +626,10 @@ extern "C" int must3r_hip_encode(must3r_hip_ctx* c, int dtype, const float* img,
 extern "C" int must3r_hip_decode(must3r_hip_ctx* c, const must3r_hip_decode_args* A, void* stream) {
     if (!c || !A || !A->groups || !A->mem) return fail("decode: null argument");
     if (!c->fin_dec) return fail("decode: decoder weights not finalized");
-    if (A->dtype != MUST3R_BF16 && A->dtype != MUST3R_F16 && A->dtype != MUST3R_F16_W2) return fail("decode: bad dtype %d", A->dtype);
-    c->wsplit = A->dtype == MUST3R_F16_W2 ? 2 : 0;
+    const int adt = A->dtype & ~MUST3R_ATTN_FP8;
+    c->attn8 = (A->dtype & MUST3R_ATTN_FP8) ? 1 : 0;
+    if (adt != MUST3R_BF16 && adt != MUST3R_F16 && adt != MUST3R_F16_W2) return fail("decode: bad dtype %d", A->dtype);
+    c->wsplit = adt == MUST3R_F16_W2 ? 2 : 0;
     if (A->mem_mode != MUST3R_MEM_KV && A->mem_mode != MUST3R_MEM_NORM_Y && A->mem_mode != MUST3R_MEM_RAW)
         return fail("decode: bad mem_mode %d", A->mem_mode);
     if (A->n_groups <= 0) return fail("decode: no input group");
@@ -619,7 +637,8 @@ extern "C" int must3r_hip_decode(must3r_hip_ctx* c, const must3r_hip_decode_args
     if (A->first_call && A->n_mem != 0) return fail("decode: first_call with a non-empty memory");
     HIP_OK(hipSetDevice(c->device));
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    const DType dt = A->dtype == MUST3R_F16_W2 ? DT_F16 : (DType)A->dtype;
+    const DType dt = adt == MUST3R_F16_W2 ? DT_F16 : (DType)adt;
+    const bool a8 = c->attn8 != 0;
     const must3r_hip_config& g = c->cfg;
     const int C = g.enc_dim, D = g.dec_dim, Hh = g.dec_heads, F = g.mlp_ratio * D, L = g.dec_depth, Nm = A->n_mem;
     const int OUT = g.patch_size * g.patch_size * 7;
@@ -670,9 +689,16 @@ extern "C" int must3r_hip_decode(must3r_hip_ctx* c, const must3r_hip_decode_args
     // per layer per call into scratch (the reference re-projects them per query view, layers.py:92-96)
     const int mode = A->mem_mode;
     const int memD = mode == MUST3R_MEM_KV ? 2 * D : D;
+    const int memES = (a8 && mode == MUST3R_MEM_KV) ? 1 : 2;   // bytes per memory element: e4m3 K|V rows in fp8-attention mode
     const size_t kvs_rows = mode == MUST3R_MEM_KV ? 0 : (size_t)max_nk_ca;
     need = ws_need(need, kvs_rows * 2 * D, 2);
     need = ws_need(need, mode == MUST3R_MEM_RAW ? kvs_rows * D : 0, 2);
+    // fp8 attention: e4m3 copies of q|k|v (self) / q (cross), 16-bit staging of freshly projected K|V rows before they are
+    // quantised into the memory, e4m3 copy of the per-call K|V projection of the 'norm_y' / 'raw' modes
+    const size_t kv16_rows = (a8 && mode == MUST3R_MEM_KV && update) ? (size_t)L * R : 0;
+    need = ws_need(need, a8 ? (size_t)R * 3 * D : 0, 1);
+    need = ws_need(need, kv16_rows * 2 * D, 2);
+    need = ws_need(need, a8 ? kvs_rows * 2 * D : 0, 1);
     M3R_OK(ws_reserve(c, need, s));
     uint16_t* t16 = ws_take<uint16_t>(c, (size_t)R * C);
     float* x = ws_take<float>(c, (size_t)R * D);
@@ -688,7 +714,11 @@ extern "C" int must3r_hip_decode(must3r_hip_ctx* c, const must3r_hip_decode_args
     char* split_ws = split_bytes ? ws_take<char>(c, split_bytes) : nullptr;
     uint16_t* kvs = kvs_rows ? ws_take<uint16_t>(c, kvs_rows * 2 * D) : nullptr;
     uint16_t* ytmp = (mode == MUST3R_MEM_RAW && kvs_rows) ? ws_take<uint16_t>(c, kvs_rows * D) : nullptr;
-    if (!g16 || (update && !off32) || (split_bytes && !split_ws)) return fail("decode: workspace sizing bug");
+    uint8_t* q8 = a8 ? ws_take<uint8_t>(c, (size_t)R * 3 * D) : nullptr;
+    uint16_t* kv16 = kv16_rows ? ws_take<uint16_t>(c, kv16_rows * 2 * D) : nullptr;
+    uint8_t* kvs8 = (a8 && kvs_rows) ? ws_take<uint8_t>(c, kvs_rows * 2 * D) : nullptr;
+    if (!g16 || (update && !off32) || (split_bytes && !split_ws) || (a8 && !q8) || (kv16_rows && !kv16) || (a8 && kvs_rows && !kvs8))
+        return fail("decode: workspace sizing bug");
 
     // ---- per-view tables: self-attention, cross-attention; positions gathered into one [R,2] array
     std::vector<AttnView> tab(2 * (size_t)total_views);
@@ -749,7 +779,7 @@ extern "C" int must3r_hip_decode(must3r_hip_ctx* c, const must3r_hip_decode_args
     //   'kv'     LN(norm_y) -> [projk | projv]       'norm_y'  LN(norm_y)        'raw'  the tokens themselves
     auto kv_project = [&](int l, const float* src, const float* add, float* copy, hipStream_t st) -> int {
         const std::string b = "decoder.blocks_dec." + std::to_string(l);
-        uint16_t* dst = reinterpret_cast<uint16_t*>(A->mem[l]) + (size_t)Nm * memD;
+        uint16_t* dst = reinterpret_cast<uint16_t*>(reinterpret_cast<char*>(A->mem[l]) + (size_t)Nm * memD * memES);
         LnArgs la = lnargs(src, add, p32(c, b + ".norm_y.weight"), p32(c, b + ".norm_y.bias"), h16, nullptr, nullptr, copy, R, D, 1e-6f);
         if (mode == MUST3R_MEM_NORM_Y) la.out16 = dst;
         if (mode == MUST3R_MEM_RAW) { la.out16 = nullptr; la.raw16 = dst; }
@@ -757,12 +787,14 @@ extern "C" int must3r_hip_decode(must3r_hip_ctx* c, const must3r_hip_decode_args
         if (mode != MUST3R_MEM_KV) return 0;
         const void* wk;
         M3R_OK(w16(c, b + ".cross_attn.projkv.weight", dt, &wk, st));
-        M3R_OK(gemm(c, dt, EPI_STORE16, gargs(h16, wk, p32(c, b + ".cross_attn.projkv.bias"), dst, R, 2 * D, D, D, 2 * D), st));
-        return 0;
+        if (!a8) return gemm(c, dt, EPI_STORE16, gargs(h16, wk, p32(c, b + ".cross_attn.projkv.bias"), dst, R, 2 * D, D, D, 2 * D), st);
+        // fp8 memory: project into the 16-bit staging rows, quantise into the memory rows
+        M3R_OK(gemm(c, dt, EPI_STORE16, gargs(h16, wk, p32(c, b + ".cross_attn.projkv.bias"), kv16, R, 2 * D, D, D, 2 * D), st));
+        return quant8(c, dt, kv16, 2 * D, dst, 2 * D, nullptr, 0, (size_t)R, 2 * D, st);
     };
     // K|V rows the cross attention of layer l reads: the memory itself ('kv') or a projection of it into scratch
-    auto kv_source = [&](int l, const uint16_t** kptr, hipStream_t st) -> int {
-        if (mode == MUST3R_MEM_KV) { *kptr = reinterpret_cast<const uint16_t*>(A->mem[l]); return 0; }
+    auto kv_source = [&](int l, const void** kptr, hipStream_t st) -> int {
+        if (mode == MUST3R_MEM_KV) { *kptr = A->mem[l]; return 0; }
         const std::string b = "decoder.blocks_dec." + std::to_string(l);
         const uint16_t* src = reinterpret_cast<const uint16_t*>(A->mem[l]);
         const int rows = (int)kvs_rows;
@@ -777,6 +809,10 @@ extern "C" int must3r_hip_decode(must3r_hip_ctx* c, const must3r_hip_decode_args
         M3R_OK(w16(c, b + ".cross_attn.projkv.weight", dt, &wk, st));
         M3R_OK(gemm(c, dt, EPI_STORE16, gargs(src, wk, p32(c, b + ".cross_attn.projkv.bias"), kvs, rows, 2 * D, D, D, 2 * D), st));
         *kptr = kvs;
+        if (a8) {
+            M3R_OK(quant8(c, dt, kvs, 2 * D, kvs8, 2 * D, nullptr, 0, (size_t)rows, 2 * D, st));
+            *kptr = kvs8;
+        }
         return 0;
     };
 
@@ -796,6 +832,10 @@ extern "C" int must3r_hip_decode(must3r_hip_ctx* c, const must3r_hip_decode_args
         aa.Q = qkv; aa.K = qkv + D; aa.V = qkv + 2 * D; aa.O = a16;
         aa.ldq = aa.ldk = aa.ldv = 3 * D; aa.ldo = D; aa.heads = Hh;
         aa.views = sa_views; aa.nviews = total_views; aa.max_nq = max_n; aa.scale = 0.125f; aa.q_prescaled = 1;
+        if (a8) {
+            M3R_OK(quant8(c, dt, qkv, 3 * D, q8, 3 * D, nullptr, 0, (size_t)R, 3 * D, s));
+            aa.Q = q8; aa.K = q8 + D; aa.V = q8 + 2 * D; aa.fp8 = 1;
+        }
         M3R_OK(attention(c, dt, aa, sa_flops, PC_ATTN_SA, s));
         M3R_OK(w16(c, b + ".attn.proj.weight", dt, &w, s));
         M3R_OK(gemm(c, dt, EPI_RESID_F32, gargs(a16, w, p32(c, b + ".attn.proj.bias"), x, R, D, D, D, D), s));
@@ -808,11 +848,15 @@ extern "C" int must3r_hip_decode(must3r_hip_ctx* c, const must3r_hip_decode_args
             gq.out_scale = kQScale; gq.scale_cols = D;
             M3R_OK(gemm(c, dt, EPI_STORE16, gq, s));
         }
-        const uint16_t* mk = nullptr;
+        const void* mk = nullptr;
         M3R_OK(kv_source(l, &mk, s));
         memset(&aa, 0, sizeof(aa));
-        aa.Q = q16; aa.K = mk; aa.V = mk + D; aa.O = a16;
+        aa.Q = q16; aa.K = mk; aa.V = reinterpret_cast<const uint16_t*>(mk) + D; aa.O = a16;
         aa.ldq = D; aa.ldk = aa.ldv = 2 * D; aa.ldo = D; aa.heads = Hh;
+        if (a8) {
+            M3R_OK(quant8(c, dt, q16, D, q8, D, nullptr, 0, (size_t)R, D, s));
+            aa.Q = q8; aa.V = reinterpret_cast<const uint8_t*>(mk) + D; aa.fp8 = 1;
+        }
         aa.views = ca_views; aa.nviews = total_views; aa.max_nq = max_n; aa.scale = 0.125f; aa.q_prescaled = 1;
         if (ca_split > 1) {
             aa.nsplit = ca_split; aa.total_q_rows = R; aa.dense_rows = 1;
@@ -860,16 +904,23 @@ extern "C" int must3r_hip_decode(must3r_hip_ctx* c, const must3r_hip_decode_args
                                nullptr, nullptr, L * R, D, 1e-6f);
             la.rows_per_group = R; la.add_groups = L - 1;
             M3R_OK(layernorm_a(c, dt, la, s));
-            std::vector<void*> outs(L);
-            for (int l = 0; l < L; ++l) outs[l] = reinterpret_cast<uint16_t*>(A->mem[l]) + (size_t)Nm * 2 * D;
+            // fp8 memory: the GEMM writes the 16-bit staging rows [L][R][2D], one grouped quantisation scatters them into the
+            // layers' memory rows
+            std::vector<void*> outs(2 * (size_t)L);
+            for (int l = 0; l < L; ++l) {
+                void* memrow = reinterpret_cast<char*>(A->mem[l]) + (size_t)Nm * 2 * D * memES;
+                outs[l] = a8 ? static_cast<void*>(kv16 + (size_t)l * R * 2 * D) : memrow;
+                outs[L + l] = memrow;
+            }
             void* outs_dev = nullptr;
-            M3R_OK(upload_table(c, outs.data(), sizeof(void*) * L, &outs_dev, s));
+            M3R_OK(upload_table(c, outs.data(), sizeof(void*) * 2 * L, &outs_dev, s));
             const void* wk;
             M3R_OK(w16(c, "decoder.projkv_all.weight", dt, &wk, s));
             GemmArgs gk = gargs(yall, wk, p32(c, "decoder.projkv_all.bias"), nullptr, R, 2 * D, D, D, 2 * D);
             gk.batch = L; gk.strideA = (long long)R * D; gk.strideW = (long long)2 * D * D * (c->wsplit == 2 ? 2 : 1);
             gk.strideB = 2 * D; gk.out_table = reinterpret_cast<void* const*>(outs_dev);
             M3R_OK(gemm(c, dt, EPI_STORE16, gk, s));
+            if (a8) M3R_OK(quant8(c, dt, kv16, 2 * D, nullptr, 2 * D, reinterpret_cast<void* const*>(outs_dev) + L, R, (size_t)L * R, 2 * D, s));
         } else {
             for (int l = 0; l < L; ++l)
                 M3R_OK(kv_project(l, newmem + (size_t)l * R * D, l < L - 1 ? off32 : nullptr, nullptr, s));
@@ -1004,9 +1055,12 @@ extern "C" size_t must3r_hip_attention_scratch_bytes(int nsplit, int total_q_row
 extern "C" int must3r_hip_op_attention(int dtype, const void* Q, const void* K, const void* V, void* O, int ldq, int ldk, int ldv,
                                        int ldo, int heads, const int32_t* views_dev, int n_views, int max_nq, int nsplit,
                                        void* scratch, int total_q_rows, void* stream) {
+    const int fp8 = (dtype & MUST3R_ATTN_FP8) ? 1 : 0;   // Q, K, V are e4m3 bytes (strides in bytes); O in the 16-bit type
+    dtype &= ~MUST3R_ATTN_FP8;
     if (dtype != MUST3R_BF16 && dtype != MUST3R_F16) return fail("op_attention: bad dtype");
     AttnArgs a;
     memset(&a, 0, sizeof(a));
+    a.fp8 = fp8;
     a.Q = Q; a.K = K; a.V = V; a.O = O; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo; a.heads = heads;
     a.views = reinterpret_cast<const AttnView*>(views_dev); a.nviews = n_views; a.max_nq = max_nq; a.scale = 0.125f;
     if (nsplit > 1) {

@@ -216,6 +216,8 @@ class MUSt3R(HipModule):
         device = torch.device("cuda", dev)
         odt = self._operand()
         tdt = _TORCH_DT[odt]
+        if self.attention_fp8 and self.memory_mode == "kv":
+            tdt = torch.float8_e4m3fn      # the memory holds e4m3 K|V rows: half the footprint, half the cross-attention traffic
         D = self.embed_dim
         assert not render or current_mem is not None  # decoder.py:278
 
@@ -266,7 +268,8 @@ class MUSt3R(HipModule):
         # return_feats (decoder.py:344-347): [encoder tokens, residual stream after blocks 0..depth-2, norm_dec(last)] -- fp32
         # here (the residual stream is fp32 on this path, bf16 in the reference under autocast)
         feats_buf = torch.empty((self.depth, R, D), dtype=torch.float32, device=device) if return_feats else None
-        args = _lib.DecodeArgs(odt, _MEM_MODE[self.memory_mode], 1 if render else 0, 1 if current_mem is None else 0,
+        args = _lib.DecodeArgs(odt | (_lib.ATTN_FP8 if self.attention_fp8 else 0), _MEM_MODE[self.memory_mode],
+                               1 if render else 0, 1 if current_mem is None else 0,
                                len(xs), groups, Nm, ptrs, feats_buf.data_ptr() if return_feats else None)
         _lib.check(ctx.lib.must3r_hip_decode(ctx.handle, C.byref(args), self._stream(dev)))
 

@@ -74,7 +74,8 @@ class Dust3rEncoder(HipModule):
         N = (H // 16) * (W // 16)
         x = torch.empty((B, N, self.embed_dim), dtype=torch.float32, device=img.device)
         pos = torch.empty((B, N, 2), dtype=torch.int64, device=img.device)
-        _lib.check(ctx.lib.must3r_hip_encode(ctx.handle, operand_dtype(self.precision), img.data_ptr(), B, H, W,
+        code = operand_dtype(self.precision) | (_lib.ATTN_FP8 if self.attention_fp8 else 0)
+        _lib.check(ctx.lib.must3r_hip_encode(ctx.handle, code, img.data_ptr(), B, H, W,
                                              x.data_ptr(), pos.data_ptr(), self._stream(dev)))
         return x, pos
 

@@ -1,34 +1,51 @@
-"""Microbenchmark of the attention kernel on the scene's big shapes (render cross attention, encoder self attention)."""
-import sys, torch, ctypes as C
-sys.path.insert(0, '/root/repo')
+"""Microbenchmark of the attention kernels on the scene's shapes.  M3R_ATTN=0 selects the round-1 kernel, default the
+pipelined attn2_kernel; FP8=1 times the e4m3 operand variant.  Prints median / min over interleaved rounds."""
+import os, sys, torch, ctypes as C
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from must3r_amd import _lib as lib
 L = lib.load()
 P = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
 st = torch.cuda.current_stream().cuda_stream
-def run(name, heads, nviews, nq, nk, self_attn, iters=5):
+FP8 = int(os.environ.get("FP8", "0"))
+def make(name, heads, nviews, nq, nk, self_attn, nsplit=0):
     D = heads * 64
+    dt = torch.float8_e4m3fn if FP8 else torch.float16
+    torch.manual_seed(0)
     if self_attn:
-        qkv = (torch.randn((nviews * nq, 3 * D), device="cuda")).bfloat16()
+        qkv = (torch.randn((nviews * nq, 3 * D), device="cuda")).to(dt)
         q, k, v = qkv[:, :D], qkv[:, D:2*D], qkv[:, 2*D:]
         views = [(i * nq, nq, i * nq, nq, 0, 0) for i in range(nviews)]
     else:
-        q = torch.randn((nviews * nq, D), device="cuda").bfloat16()
-        kv = torch.randn((nk, 2 * D), device="cuda").bfloat16()
+        q = torch.randn((nviews * nq, D), device="cuda").to(dt)
+        kv = torch.randn((nk, 2 * D), device="cuda").to(dt)
         k, v = kv[:, :D], kv[:, D:]
         views = [(i * nq, nq, 0, nk, 0, 0) for i in range(nviews)]
-    o = torch.empty((nviews * nq, D), device="cuda", dtype=torch.bfloat16)
+    o = torch.empty((nviews * nq, D), device="cuda", dtype=torch.float16)
     tab = torch.tensor(views, dtype=torch.int32, device="cuda")
+    ws = None
+    if nsplit > 1:
+        ws = torch.empty((L.must3r_hip_attention_scratch_bytes(nsplit, nviews * nq, heads),), dtype=torch.uint8, device="cuda")
+    code = lib.F16 | (lib.ATTN_FP8 if FP8 else 0)
     def go():
-        lib.check(L.must3r_hip_op_attention(0, P(q), P(k), P(v), P(o), q.stride(0), k.stride(0), v.stride(0), o.stride(0), heads, P(tab),
-                                            len(views), nq, 0, None, 0, st))
-    go(); torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(iters): go()
-    e1.record(); torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / iters
-    fl = 4.0 * nviews * nq * nk * D
-    print(f"{name:22s} {ms*1e3:9.1f} us {fl/ms/1e9:8.1f} TF/s", flush=True)
-run("render CA 20v nk15360", 12, 20, 768, 15360, False)
-run("enc SA 20v n768", 16, 20, 768, 768, True)
-run("update CA 1v nk7680", 12, 1, 768, 7680, False)
+        lib.check(L.must3r_hip_op_attention(code, P(q), P(k), P(v), P(o), q.stride(0), k.stride(0), v.stride(0), o.stride(0), heads, P(tab),
+                                            len(views), nq, nsplit, P(ws), nviews * nq if nsplit > 1 else 0, st))
+    return name, go, 4.0 * nviews * nq * nk * D, (q, k, v, o, tab, ws)
+cases = [make("render CA 20v nk15360", 12, 20, 768, 15360, False), make("enc SA 20v n768", 16, 20, 768, 768, True),
+         make("update CA 1v nk7680 s7", 12, 1, 768, 7680, False, 7), make("update CA 1v nk14592 s8", 12, 1, 768, 14592, False, 8),
+         make("update SA 1v n768", 12, 1, 768, 768, True), make("render CA 20v nk1960 (224)", 12, 10, 196, 1960, False)]
+for name, go, fl, _ in cases:
+    go()
+torch.cuda.synchronize()
+res = {c[0]: [] for c in cases}
+for rnd in range(5):
+    for name, go, fl, _ in cases:
+        iters = 5 if fl > 5e10 else 30
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters): go()
+        e1.record(); torch.cuda.synchronize()
+        res[name].append(e0.elapsed_time(e1) / iters)
+print(f"M3R_ATTN={os.environ.get('M3R_ATTN','1')} FP8={FP8}")
+for name, go, fl, _ in cases:
+    r = sorted(res[name]); med, mn = r[len(r)//2], r[0]
+    print(f"  {name:28s} median {med*1e3:9.1f} us {fl/med/1e9:8.1f} TF/s   min {mn*1e3:9.1f} us {fl/mn/1e9:8.1f} TF/s", flush=True)

@@ -251,6 +251,40 @@ def test_attention(lib, dt, case):
     record("attention", dt=dt, case=case, err=e, split_err=es)
 
 
+@pytest.mark.parametrize("case", ["sa_196x2", "sa_768", "sa_tiny12", "ca_tail_skip", "ca_aligned_skip", "ca_skip_from_start", "ca_long"])
+def test_attention_fp8(lib, case):
+    """fp8 (e4m3) attention operands (BASELINE.json configs[4]): Q, K, V are e4m3 bytes, P is rounded to e4m3, everything
+    else fp32.  Reference: fp64 attention on the SAME (dequantised) operands, so what is measured is the P rounding (3
+    mantissa bits: 2^-4 relative per element, averaged over the keys of a row) plus accumulation order."""
+    heads, views, Rq, Rk, is_self = ATT_CASES[case]
+    D = heads * 64
+    g = torch.Generator(device="cuda").manual_seed(17)
+    f8 = torch.float8_e4m3fn
+    if is_self:
+        qkv = (torch.randn((Rq, 3 * D), device="cuda", generator=g) * 1.5).to(f8)
+        q, k, v = qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:]
+    else:
+        q = (torch.randn((Rq, D), device="cuda", generator=g) * 1.5).to(f8)
+        kvm = (torch.randn((Rk, 2 * D), device="cuda", generator=g) * 1.5).to(f8)
+        k, v = kvm[:, :D], kvm[:, D:]
+    ref = attn_ref(q.float().cpu(), k.float().cpu(), v.float().cpu(), views, heads)
+    tab = torch.tensor(views, dtype=torch.int32, device="cuda")
+    errs = {}
+    for ns in (0, 3):
+        o = torch.full((Rq, D), float("nan"), device="cuda", dtype=torch.float16)
+        ws = None
+        if ns:
+            ws = torch.empty((lib.load().must3r_hip_attention_scratch_bytes(ns, Rq, heads),), dtype=torch.uint8, device="cuda")
+        lib.check(lib.load().must3r_hip_op_attention(lib.F16 | lib.ATTN_FP8, P(q), P(k), P(v), P(o), q.stride(0), k.stride(0),
+                                                     v.stride(0), o.stride(0), heads, P(tab), len(views), max(vw[1] for vw in views),
+                                                     ns, P(ws) if ns else None, Rq if ns else 0, stream()))
+        torch.cuda.synchronize()
+        assert torch.isfinite(o.float()).all()
+        errs[ns] = rel_inf(o.cpu(), ref)
+    record("attention_fp8", case=case, err=errs[0], split_err=errs[3])
+    assert max(errs.values()) < 3e-2, errs      # stated tolerance of the fp8 path at operator level (measured: see profiles/)
+
+
 @pytest.mark.parametrize("dt", ["bf16", "fp16"])
 def test_attention_running_max_jump(lib, dt):
     """Force the online-softmax rescale branch: one key late in the sequence dominates one query row."""
