@@ -22,6 +22,38 @@ constexpr int ATT_QB = 4 * ATT_QW;       // per block (default geometry, used by
 constexpr int ATT_KT = 64;               // keys per tile
 constexpr float ATT_THR = 6.0f;          // lazy-rescale threshold in log2 units (P <= 64)
 
+#ifdef ATTN_TRACE   // scripts/probes/attn_trace.hip: shader-cycle stamps of one wave of one block, per key tile
+__device__ unsigned long long g_attn_trace[4 * 64 * 8];
+#define ATT_STAMP(slot) do { if (blockIdx.x == ATTN_TRACE && lane == 0 && itc < 64) g_attn_trace[(wave * 64 + itc) * 8 + (slot)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define ATT_STAMP(slot) do { } while (0)
+#endif
+
+
+// blockIdx -> (group = view x head, key split, query block).  The blocks that share K/V tiles are the query blocks of one
+// (group, split) PAIR; a pair stays on one XCD (blockIdx % 8: observed placement, speed only) so its tiles are L2 hits, and the
+// pairs are dealt round-robin over the XCDs.  (Round 1 dealt whole groups: the 12 heads of a one-view launch -- every cross /
+// self attention of the memory update -- gave XCDs 0-3 two heads and XCDs 4-7 one, i.e. a third of the chip idle for half the
+// kernel.)  When even the pairs do not divide evenly (12 heads, no split: the one-view self attention, whose K/V is 196 KB
+// per head anyway) the blocks themselves are dealt round-robin: nqb < 0 on entry selects that map.
+__device__ __forceinline__ bool attn_block_coords(int nqb_signed, int ngrp, int nsplit, int& grp, int& split, int& qb) {
+    const int npairs = ngrp * nsplit;
+    int pair;
+    if (nqb_signed < 0) {
+        const int nqb = -nqb_signed;
+        qb = blockIdx.x % nqb;
+        pair = blockIdx.x / nqb;
+    } else {
+        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        qb = slot % nqb_signed;
+        pair = (slot / nqb_signed) * 8 + xcd;
+    }
+    if (pair >= npairs) return false;
+    grp = pair / nsplit;
+    split = pair - grp * nsplit;
+    return true;
+}
+
 template <class T, int QW>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) attn_kernel(const AttnArgs p, const int nqb, const int ngrp, const int nsplit) {
     typedef typename Vec<T>::v8 v8;
@@ -37,14 +69,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) a
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fr = lane & 15, fg = lane >> 4;
 
-    // blocks of one (view, head) group stay on one XCD (blockIdx % 8) so its K/V tiles are L2 hits
-    const int xcd = blockIdx.x & 7;
-    int slot = blockIdx.x >> 3;
-    const int split = slot % nsplit;
-    slot /= nsplit;
-    const int grp = (slot / nqb) * 8 + xcd;
-    const int qb = slot % nqb;
-    if (grp >= ngrp) return;
+    int grp, split, qb;
+    if (!attn_block_coords(nqb, ngrp, nsplit, grp, split, qb)) return;
     const int view = grp / p.heads, head = grp - view * p.heads;
     const AttnView vw = p.views[view];
     if (qb * QB >= vw.nq) return;
@@ -123,11 +149,18 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) a
     t = advance(t);
     if (t < t_end) stage(t, 0);
     int buf = 0;
+#ifdef ATTN_TRACE
+    int itc = 0;
+#endif
     while (t < t_end) {
+        ATT_STAMP(0);
         __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0)
+        ATT_STAMP(1);
         __syncthreads();
+        ATT_STAMP(2);
         const int tn = advance(t);
         if (tn < t_end) stage(tn, buf ^ 1);
+        ATT_STAMP(3);
 
         const T* k_ = smem_kv[buf][0];
         const T* v_ = smem_kv[buf][1];
@@ -157,6 +190,13 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) a
 #pragma unroll
                 for (int f = 0; f < QF; ++f) s_[kf][f] *= c;
         }
+#ifdef ATTN_TRACE
+#pragma unroll
+        for (int kf = 0; kf < 4; ++kf)
+#pragma unroll
+            for (int f = 0; f < QF; ++f) asm volatile("" ::"v"(s_[kf][f]));
+#endif
+        ATT_STAMP(4);
         // ---- exclusion / tail mask: s_[kf][f][r] is key k0 + 16 kf + 4 fg + r
         const int k0 = t * ATT_KT;
         const bool need_mask = (k0 + ATT_KT > nk) || (k0 < shi && k0 + ATT_KT > slo);
@@ -207,6 +247,13 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) a
                     for (int r = 0; r < 4; ++r) s_[kf][f][r] = __builtin_amdgcn_exp2f(s_[kf][f][r]);
             }
         }
+#ifdef ATTN_TRACE
+#pragma unroll
+        for (int kf = 0; kf < 4; ++kf)
+#pragma unroll
+            for (int f = 0; f < QF; ++f) asm volatile("" ::"v"(s_[kf][f]));
+#endif
+        ATT_STAMP(5);
         // ---- O^T += V^T P^T ; k-slot e of lane group g <-> keys {4g+e (e<4), 16+4g+e-4 (e>=4)} of the 32-key slot
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
@@ -243,6 +290,14 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) a
                 for (int f = 0; f < QF; ++f) o_[d][f] = mfma16(vfrag, pb[f], o_[d][f]);
             }
         }
+#ifdef ATTN_TRACE
+#pragma unroll
+        for (int d = 0; d < 4; ++d)
+#pragma unroll
+            for (int f = 0; f < QF; ++f) asm volatile("" ::"v"(o_[d][f]));
+        ATT_STAMP(6);
+        ++itc;
+#endif
         t = tn;
         buf ^= 1;
     }
@@ -345,13 +400,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) a
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fr = lane & 15, fg = lane >> 4;
 
-    const int xcd = blockIdx.x & 7;
-    int slot = blockIdx.x >> 3;
-    const int split = slot % nsplit;
-    slot /= nsplit;
-    const int grp = (slot / nqb) * 8 + xcd;
-    const int qb = slot % nqb;
-    if (grp >= ngrp) return;
+    int grp, split, qb;
+    if (!attn_block_coords(nqb, ngrp, nsplit, grp, split, qb)) return;
     const int view = grp / p.heads, head = grp - view * p.heads;
     const AttnView vw = p.views[view];
     if (qb * QB >= vw.nq) return;
@@ -685,9 +735,12 @@ size_t attention_split_scratch_bytes(int nsplit, int total_q_rows, int heads) {
 }
 
 int attention_pick_split(int nviews, int heads, int max_nq, int max_nk) {
-    // Cost model (256 CUs, up to 3 resident blocks per CU share its pipes): a CU's time ~ (blocks it receives) x (key
-    // tiles per block); the combine pass and the fp32 partials grow with the split factor.  Choosing the factor from
-    // the block count alone put 792 blocks on 256 CUs (3.09 per CU -> a fourth, almost empty round).
+    // Measured model (r02, scripts/bench_attn.py + scripts/probes/attn_trace.hip): a block needs ~1.4 us per 64-key tile whether
+    // two or three blocks share its CU (the wave's own QK -> softmax -> PV chain, not the CU's throughput, sets the pace), three
+    // blocks fit a CU (163 VGPRs), and a split launch pays ~26 us of fixed cost (prologue, fp32 partials, combine launch) plus the
+    // partial traffic that grows with the factor.  So: as many blocks as the 768 slots take in ONE round, i.e. as few tiles per
+    // block as possible, never a second round.  One view x 12 heads x 6 query blocks: s = 10 (720 blocks; nk = 7680: 43 us against
+    // 52 us at s = 7 and 47 us at s = 14).
     const long base = (long)nviews * heads * ((max_nq + ATT_QB - 1) / ATT_QB);
     const int ntiles = (max_nk + ATT_KT - 1) / ATT_KT;
     if (base >= 384 || ntiles < 8) return 1;
@@ -696,11 +749,9 @@ int attention_pick_split(int nviews, int heads, int max_nq, int max_nk) {
     const int smax = ntiles / 4 < 16 ? ntiles / 4 : 16;   // at least 4 key tiles per block
     for (int s = 1; s <= smax; ++s) {
         const long blocks = base * s;
-        const long per_cu = (blocks + 255) / 256;
+        const long rounds = (blocks + 767) / 768;
         const int tiles = (ntiles + s - 1) / s;
-        double cost = (double)per_cu * tiles;
-        if (blocks < 512) cost *= 1.0 + 0.5 * (512 - blocks) / 512.0;   // under two blocks per CU latencies are exposed
-        cost += (s > 1 ? 3.0 + 0.4 * s : 0.0);                           // combine launch + partial traffic, in tile units
+        const double cost = (double)rounds * tiles + (s > 1 ? 3.0 + 0.5 * s : 0.0);   // in tile units (~1.4 us)
         if (cost < best_cost) { best_cost = cost; best = s; }
     }
     return best;
@@ -732,9 +783,19 @@ int launch_attention_phase(DType dt, const AttnArgs& a, int phase, hipStream_t s
     const int ngrp = a.nviews * a.heads;
     // (measured: for the split-KV cross attention the 16-row variant is slower, 24.0 vs 22.7 ms per scene)
     const bool small = nsplit == 1 && (long)ngrp * ((a.max_nq + ATT_QB - 1) / ATT_QB) < 192;
-    const int qb_rows = small ? 64 : ATT_QB;
-    const int nqb = (a.max_nq + qb_rows - 1) / qb_rows;
-    const int grid = ((ngrp + 7) / 8) * 8 * nqb * nsplit;
+    static int qw_big = -1;   // experiments: M3R_ATTN_QW = 48 / 64 query rows per wave for the launches that are not `small`
+    if (qw_big < 0) {
+        const char* e = getenv("M3R_ATTN_QW");
+        qw_big = e ? atoi(e) : 32;
+    }
+    const int qb_rows = small ? 64 : 4 * qw_big;
+    const int nqb_abs = (a.max_nq + qb_rows - 1) / qb_rows;
+    const int npairs = ngrp * nsplit;
+    // pairs dealt over the 8 XCDs; per-block round robin when that would leave the XCDs more than 10 % apart (see attn_block_coords)
+    static const bool old_map = getenv("M3R_ATTN_OLDMAP") != nullptr;   // experiments: never use the per-block map
+    const bool per_block = !old_map && ((npairs + 7) / 8) * 8 * 10 > npairs * 11;
+    const int nqb = per_block ? -nqb_abs : nqb_abs;
+    const int grid = per_block ? npairs * nqb_abs : ((npairs + 7) / 8) * 8 * nqb_abs;
     if (phase == 0) {
         if (nsplit > 1 && !a.dense_rows) {
             const size_t n2 = (size_t)nsplit * a.total_q_rows * a.heads;
@@ -742,16 +803,21 @@ int launch_attention_phase(DType dt, const AttnArgs& a, int phase, hipStream_t s
                                a.part_ml, n2);
         }
     } else if (phase == 1) {
-        static int variant = -1;   // M3R_ATTN=0: the round-1 kernel (attn_kernel); default: the pipelined attn2_kernel
+        // 16-bit operands: attn_kernel by default.  The pipelined attn2_kernel (M3R_ATTN=1) measured 1-3 % slower on every shape
+        // of the scene (render cross attention 689 vs 702-712 TF/s, gpurun_out r02 A/B); it is the only fp8 kernel.
+        static int variant = -1;
         if (variant < 0) {
             const char* e = getenv("M3R_ATTN");
-            variant = e ? atoi(e) : 1;
+            variant = e ? atoi(e) : 0;
         }
 #define M3R_LAUNCH_ATTN(KERNEL) hipLaunchKernelGGL(KERNEL, dim3(grid), dim3(256), 0, s, a, nqb, ngrp, nsplit)
         if (a.fp8) {
             if (small) { if (dt == DT_BF16) M3R_LAUNCH_ATTN((attn2_kernel<bf16_t, 16, true>)); else M3R_LAUNCH_ATTN((attn2_kernel<f16_t, 16, true>)); }
             else { if (dt == DT_BF16) M3R_LAUNCH_ATTN((attn2_kernel<bf16_t, 32, true>)); else M3R_LAUNCH_ATTN((attn2_kernel<f16_t, 32, true>)); }
         } else if (variant == 0) {
+            if (!small && qw_big == 48 && dt == DT_F16) M3R_LAUNCH_ATTN((attn_kernel<f16_t, 48>));
+            else if (!small && qw_big == 64 && dt == DT_F16) M3R_LAUNCH_ATTN((attn_kernel<f16_t, 64>));
+            else
             if (small) { if (dt == DT_BF16) M3R_LAUNCH_ATTN((attn_kernel<bf16_t, 16>)); else M3R_LAUNCH_ATTN((attn_kernel<f16_t, 16>)); }
             else { if (dt == DT_BF16) M3R_LAUNCH_ATTN((attn_kernel<bf16_t, 32>)); else M3R_LAUNCH_ATTN((attn_kernel<f16_t, 32>)); }
         } else {

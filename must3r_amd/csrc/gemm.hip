@@ -698,6 +698,157 @@ static int launch_48(const GemmArgs& a, hipStream_t s) {
     return hipGetLastError() == hipSuccess ? 0 : 1;
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// M = 768 launches with N >= 2304 (qkv, fc1 of the memory update; feedback fc1): 96 x 96 tiles, ONE block per CU, 9 waves
+// (3 x 3, wave tile 32 x 32), split weights.  Why this shape: these launches are bound by the CU's L2 -> LDS path (one 1 KB
+// LDS-DMA instruction costs its wave ~60-80 issue cycles = ~64 B/clk/CU) and by the tail of the grid, not by MFMA rate.
+//   64 x 64 tiles: 24 KB staged per 4096 MACs/k, 576 (fc1) / 432 (qkv) tiles on 512 block slots -> 2 rounds / uneven CUs
+//   96 x 96 tiles: 36 KB staged per 9216 MACs/k (1.5 x the bytes for 2.25 x the work), 768 x 3072 = exactly 256 tiles
+// Per K-tile a wave issues 4 DMA pieces, 12 ds_read_b128 and 16 MFMAs; 4-slot ring (144 KB), counted vmcnt, one barrier
+// per tile.  The fragment reads of tile kt are issued BEFORE the DMA of tile kt+3 so that they are in flight while the
+// DMA instructions issue.  Accumulation order per output (k ascending, hi before lo per 32-deep step) as everywhere else:
+// same bits as the other tile shapes.
+// gridDim.z > 1: split-K.  Block z multiplies K-tiles [z nk, (z+1) nk) and stores its fp32 partial tile, without bias, into
+// slab z (out + z * slab_stride); the consumer (LayerNorm with LnArgs::slabs) adds the slabs in a fixed order.
+template <class T, int EPI, int NST>
+__global__ void __launch_bounds__(576) gemm96_kernel(const GemmArgs p) {
+    typedef typename Vec<T>::v8 v8;
+    constexpr int BM = 96, BN = 96, BK = 64, NW = 9, RPP = 8, WS = 2;
+    constexpr int ROWS = BM + WS * BN;                 // 288 rows per stage: A, W_hi, W_lo
+    constexpr int TP = ROWS / RPP / NW;                // 4 DMA pieces per wave and K-tile
+    static_assert(TP * NW * RPP == ROWS, "every wave issues the same number of DMA pieces (counted vmcnt)");
+    constexpr int STAGE = ROWS * BK;
+    constexpr int MF = 2, NF = 2;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    T* const lds = reinterpret_cast<T*>(smem);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / 3, wn = wave - wm * 3;
+    const int nbn = p.N / BN;
+    const int nbm = (p.M + BM - 1) / BM;
+    const int nwg = nbm * nbn;
+    int bid = blockIdx.x;
+    {
+        const int xcd = bid & 7, slot = bid >> 3;
+        const int q = nwg >> 3, r = nwg & 7;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+    }
+    const int m0 = (bid % nbm) * BM;                    // row-block fastest: the blocks of an XCD share weight panels
+    const int n0 = (bid / nbm) * BN;
+    const int grp = blockIdx.y;
+    const int nk = p.K / BK / (int)gridDim.z;           // K-tiles of this block
+    const int kt0 = blockIdx.z * nk;
+    const T* __restrict__ A = reinterpret_cast<const T*>(p.A) + (size_t)grp * p.strideA + (size_t)kt0 * BK;
+    const T* __restrict__ W = reinterpret_cast<const T*>(p.W) + (size_t)grp * p.strideW + (size_t)kt0 * BK;
+    const float* __restrict__ bias = p.bias ? p.bias + (size_t)grp * p.strideB : nullptr;
+    void* outp = p.out_table ? p.out_table[grp] : p.out;
+    if (gridDim.z > 1) outp = reinterpret_cast<float*>(outp) + (size_t)blockIdx.z * p.slab_stride;
+
+    // pieces dealt round-robin: piece = t * NW + wave; rows [0,96) = A, [96,192) = W_hi, [192,288) = W_lo
+    const int srow = lane >> 3, pch = lane & 7;
+    const T* src[TP];
+#pragma unroll
+    for (int t = 0; t < TP; ++t) {
+        const int r = (t * NW + wave) * RPP + srow;
+        if (r < BM) {
+            int gr = m0 + r;
+            gr = gr < p.M ? gr : p.M - 1;
+            src[t] = A + (size_t)gr * p.lda + swz(r, pch) * 8;
+        } else {
+            const int rr = r - BM, part = rr / BN, wrow = rr - part * BN;
+            src[t] = W + (size_t)(n0 + wrow) * (size_t)(p.K * WS) + (size_t)part * p.K + swz(rr, pch) * 8;
+        }
+    }
+    auto stage = [&](int kt, int buf) {
+        T* base = lds + buf * STAGE;
+#pragma unroll
+        for (int t = 0; t < TP; ++t) glds16(src[t] + kt * BK, base + (t * NW + wave) * RPP * BK);
+    };
+    f32x4 acc[MF][NF];
+#pragma unroll
+    for (int i = 0; i < MF; ++i)
+#pragma unroll
+        for (int j = 0; j < NF; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int fr = lane & 15, fg = lane >> 4;
+    int a_off[2][MF], w_off[2][WS][NF];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+        for (int i = 0; i < MF; ++i) {
+            const int r = wm * 32 + i * 16 + fr;
+            a_off[ks][i] = r * BK + swz(r, ks * 4 + fg) * 8;
+        }
+#pragma unroll
+        for (int part = 0; part < WS; ++part)
+#pragma unroll
+            for (int j = 0; j < NF; ++j) {
+                const int rr = part * BN + wn * 32 + j * 16 + fr;
+                w_off[ks][part][j] = (BM + rr) * BK + swz(rr, ks * 4 + fg) * 8;
+            }
+    }
+#pragma unroll
+    for (int t = 0; t < NST - 1; ++t)
+        if (t < nk) stage(t, t);
+    int buf = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        // tile kt landed: at most NST-2 younger tiles x TP loads may still be in flight (tail: drain)
+        if (kt + NST - 2 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * TP) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        const T* base = lds + buf * STAGE;
+        v8 af[2][MF], wf[2][WS][NF];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+            for (int part = 0; part < WS; ++part)
+#pragma unroll
+                for (int j = 0; j < NF; ++j) wf[ks][part][j] = *reinterpret_cast<const v8*>(base + w_off[ks][part][j]);
+#pragma unroll
+            for (int i = 0; i < MF; ++i) af[ks][i] = *reinterpret_cast<const v8*>(base + a_off[ks][i]);
+        }
+        const int nt = kt + NST - 1;
+        if (nt < nk) {
+            int nb = buf + NST - 1;
+            nb = nb >= NST ? nb - NST : nb;
+            stage(nt, nb);                              // the buffer read in iteration kt-1
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int part = 0; part < WS; ++part)
+#pragma unroll
+                for (int i = 0; i < MF; ++i)
+#pragma unroll
+                    for (int j = 0; j < NF; ++j) acc[i][j] = mfma16(wf[ks][part][j], af[ks][i], acc[i][j]);
+        buf = buf + 1 == NST ? 0 : buf + 1;
+    }
+#pragma unroll
+    for (int i = 0; i < MF; ++i) {
+        const int m = m0 + wm * 32 + i * 16 + fr;
+        if (m >= p.M) continue;
+        f32x4 v[NF];
+#pragma unroll
+        for (int j = 0; j < NF; ++j) v[j] = acc[i][j];
+        epilogue_row<T, EPI, NF>(p, outp, bias, m, n0 + wn * 32, fg, v);
+    }
+}
+
+template <class T, int EPI>
+static int launch_96(const GemmArgs& a, hipStream_t s) {
+    constexpr int NST = 4;
+    const int nbn = a.N / 96, nbm = (a.M + 95) / 96;
+    const size_t lds = (size_t)NST * (96 + 2 * 96) * 64 * sizeof(T);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm96_kernel<T, EPI, NST>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((gemm96_kernel<T, EPI, NST>), dim3(nbm * nbn, a.batch > 1 ? a.batch : 1, a.ksplit > 1 ? a.ksplit : 1), dim3(576), lds, s, a);
+    return hipGetLastError() == hipSuccess ? 0 : 1;
+}
+
 // Tile selection (measured on MI355X, scripts/bench_gemm.py): two resident blocks per CU beat every larger tile that
 // leaves one (128x128 3-stage, 256x128 with 4 or 8 waves: 465-613 TF/s vs 644 TF/s on the scene's big-batch shapes).
 //   plain weights : 128x128x64, 2 stages (64 KB)  for chip-filling grids, 64x64x64 4-stage ring (64 KB) otherwise
@@ -745,6 +896,21 @@ static bool use_48(const GemmArgs& a, long nb) {
     if (!v || a.N % 48 || a.K % 64 || a.rope_tab != nullptr) return false;
     const long tiles = (long)((a.M + 47) / 48) * (a.N / 48) * nb;
     return tiles <= 256 && tiles >= 192;
+}
+
+// 96 x 96 tiles: split weights, one round of 224..256 tiles (M = 768: fc1 / feedback fc1 = 256 tiles; measured 17.8 -> 13.3 us);
+// explicit split-K launches (ksplit > 1) always run here.  M3R_GEMM96=0 disables it (experiments).
+static bool use_96(const GemmArgs& a, long nb) {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("M3R_GEMM96");
+        v = e ? atoi(e) : 1;
+    }
+    if (a.N % 96 || a.K % 64) return false;
+    if (a.ksplit > 1) return true;
+    if (!v) return false;
+    const long tiles = (long)((a.M + 95) / 96) * (a.N / 96) * nb;
+    return tiles <= 256 && tiles >= 224;   // (qkv at M = 768 is 192 tiles = 75 % of the CUs: measured 12.3 us vs 11.2 us on 64 x 64 tiles)
 }
 
 // M3R_GEMM256: 0 = never use the 8-wave kernel, 1 = by the fill rule below (default), 2 = whenever the shape allows it
@@ -800,7 +966,8 @@ static int launch_epi(const GemmArgs& a, hipStream_t s, const char** err) {
                     if (best < 0 || cost < best) { best = cost; pick = bns[i]; }
                 }
             }
-            if (EPI != EPI_QKV_ROPE && EPI != EPI_HEAD && use_48(a, nb)) rc = launch_48<T, EPI == EPI_QKV_ROPE || EPI == EPI_HEAD ? EPI_STORE16 : EPI, 2>(a, s);
+            if (EPI != EPI_HEAD && use_96(a, nb)) rc = launch_96<T, EPI == EPI_HEAD ? EPI_STORE16 : EPI>(a, s);
+            else if (EPI != EPI_QKV_ROPE && EPI != EPI_HEAD && use_48(a, nb)) rc = launch_48<T, EPI == EPI_QKV_ROPE || EPI == EPI_HEAD ? EPI_STORE16 : EPI, 2>(a, s);
             else if (pick == 256) rc = launch_256<T, EPI, 2, 256>(a, s);
             else if (pick == 192) rc = launch_256<T, EPI == EPI_QKV_ROPE ? EPI_STORE16 : EPI, 2, 192>(a, s);
             else if (pick == 128) rc = launch_256<T, EPI, 2, 128>(a, s);
@@ -846,6 +1013,13 @@ int launch_gemm(DType dt, Epi epi, const GemmArgs& a, hipStream_t s, const char*
         *err = "gemm: rope epilogue needs pos, table and 64-aligned rope_cols"; return 1;
     }
     if (epi == EPI_HEAD && (a.N % 112 != 0 || a.ntok <= 0 || a.gw <= 0)) { *err = "gemm: head epilogue geometry"; return 1; }
+    if (a.ksplit > 1) {   // split-K: fp32 partial slabs, no bias, 96 x 96 tiles with split weights only
+        if (epi != EPI_F32 || a.bias != nullptr || a.bias2 != nullptr || a.accumulate || a.wsplit != 2 || dt != DT_F16 || a.N % 96 ||
+            (a.K / 64) % a.ksplit || a.slab_stride < (long long)a.M * a.ldc) {
+            *err = "gemm: split-K needs EPI_F32 without bias, split fp16 weights, N % 96 == 0, K-tiles divisible by ksplit, slab_stride >= M*ldc";
+            return 1;
+        }
+    }
     return dt == DT_BF16 ? launch_t<bf16_t>(epi, a, s, err) : launch_t<f16_t>(epi, a, s, err);
 }
 

@@ -680,6 +680,14 @@ extern "C" int must3r_hip_decode(must3r_hip_ctx* c, const must3r_hip_decode_args
         need = ws_need(need, (size_t)R * D, 4);       // feedback offset
         need = ws_need(need, (size_t)L * R * D, 2);   // norm_y of all layers (grouped K|V projection)
     }
+    // One-view update calls: the K = 4 D fc2 of every block runs as a split-K GEMM on 96 x 96 tiles (64 tiles x 4 K-ranges = one
+    // block per CU instead of 256 blocks of 48 x 48 over the whole K) that leaves fp32 partial slabs; the residual update
+    // x += b + slabs is done by the LayerNorm that reads x next (norm1 of the next block / norm_dec), in a fixed order.
+    const int KS = 4;
+    static const bool fc2_splitk_on = !(getenv("M3R_FC2_SPLITK") && atoi(getenv("M3R_FC2_SPLITK")) == 0);
+    const bool fc2_splitk = fc2_splitk_on && c->wsplit == 2 && dt == DT_F16 && !need_pre_kv && !A->feats && D % 96 == 0 &&
+                            (F / 64) % KS == 0 && (long)((R + 95) / 96) * (D / 96) * KS <= 256;
+    need = ws_need(need, fc2_splitk ? (size_t)KS * R * D : 0, 4);   // slabs
     // split-KV cross attention when the launch cannot fill the chip (sequential memory update: one view per call)
     const int max_nk_ca = A->render ? Nm : Nm + (lone_view ? 0 : R);
     const int ca_split = attention_pick_split(total_views, Hh, max_n, max_nk_ca);
@@ -711,6 +719,7 @@ extern "C" int must3r_hip_decode(must3r_hip_ctx* c, const must3r_hip_decode_args
     float* newmem = update ? ws_take<float>(c, (size_t)L * R * D) : nullptr;
     float* off32 = update ? ws_take<float>(c, (size_t)R * D) : nullptr;
     uint16_t* yall = update ? ws_take<uint16_t>(c, (size_t)L * R * D) : nullptr;
+    float* slabs = fc2_splitk ? ws_take<float>(c, (size_t)KS * R * D) : nullptr;
     char* split_ws = split_bytes ? ws_take<char>(c, split_bytes) : nullptr;
     uint16_t* kvs = kvs_rows ? ws_take<uint16_t>(c, kvs_rows * 2 * D) : nullptr;
     uint16_t* ytmp = (mode == MUST3R_MEM_RAW && kvs_rows) ? ws_take<uint16_t>(c, kvs_rows * D) : nullptr;
@@ -816,12 +825,20 @@ extern "C" int must3r_hip_decode(must3r_hip_ctx* c, const must3r_hip_decode_args
         return 0;
     };
 
+    const float* pending_bias = nullptr;   // fc2 bias of the previous block while its split-K slabs await the next LayerNorm of x
+    auto with_slabs = [&](LnArgs la) {
+        if (pending_bias) {
+            la.slabs = slabs; la.nslabs = KS; la.slab_stride = (long long)R * D; la.slab_bias = pending_bias; la.xw = x;
+            pending_bias = nullptr;
+        }
+        return la;
+    };
     for (int l = 0; l < L; ++l) {
         const std::string b = "decoder.blocks_dec." + std::to_string(l);
         if (need_pre_kv) M3R_OK(kv_project(l, x, nullptr, nullptr, s));
         // --- self attention (layers.py:91)
-        M3R_OK(layernorm(c, dt, x, nullptr, p32(c, b + ".norm1.weight"), p32(c, b + ".norm1.bias"), h16, nullptr, nullptr,
-                         update ? newmem + (size_t)l * R * D : nullptr, R, D, 1e-6f, s));
+        M3R_OK(layernorm_a(c, dt, with_slabs(lnargs(x, nullptr, p32(c, b + ".norm1.weight"), p32(c, b + ".norm1.bias"), h16, nullptr, nullptr,
+                                                   update ? newmem + (size_t)l * R * D : nullptr, R, D, 1e-6f)), s));
         M3R_OK(w16(c, b + ".attn.qkv.weight", dt, &w, s));
         GemmArgs ga = gargs(h16, w, p32(c, b + ".attn.qkv.bias"), qkv, R, 3 * D, D, D, 3 * D);
         ga.pos = pos_all; ga.rope_tab = c->rope_tab; ga.rope_cols = 2 * D; ga.rope_npos = c->rope_npos;
@@ -872,7 +889,14 @@ extern "C" int must3r_hip_decode(must3r_hip_ctx* c, const must3r_hip_decode_args
         M3R_OK(w16(c, b + ".mlp.fc1.weight", dt, &w, s));
         M3R_OK(gemm(c, dt, EPI_STORE16_GELU, gargs(h16, w, p32(c, b + ".mlp.fc1.bias"), g16, R, F, D, D, F), s));
         M3R_OK(w16(c, b + ".mlp.fc2.weight", dt, &w, s));
-        M3R_OK(gemm(c, dt, EPI_RESID_F32, gargs(g16, w, p32(c, b + ".mlp.fc2.bias"), x, R, D, F, F, D), s));
+        if (fc2_splitk) {
+            GemmArgs gs = gargs(g16, w, nullptr, slabs, R, D, F, F, D);
+            gs.ksplit = KS; gs.slab_stride = (long long)R * D;
+            M3R_OK(gemm(c, dt, EPI_F32, gs, s));
+            pending_bias = p32(c, b + ".mlp.fc2.bias");
+        } else {
+            M3R_OK(gemm(c, dt, EPI_RESID_F32, gargs(g16, w, p32(c, b + ".mlp.fc2.bias"), x, R, D, F, F, D), s));
+        }
         if (A->feats && l < L - 1)   // return_feats: the residual stream after block l (decoder.py:321)
             HIP_OK(hipMemcpyAsync(A->feats + (size_t)l * R * D, x, (size_t)R * D * sizeof(float), hipMemcpyDeviceToDevice, s));
     }
@@ -929,9 +953,8 @@ extern "C" int must3r_hip_decode(must3r_hip_ctx* c, const must3r_hip_decode_args
 
     // --- prediction head in split precision (fp32-equivalent; decoder.py:149-156 runs it in fp32):
     //     y = LN(x); out = y_hi W_hi + y_lo W_hi + y_hi W_lo + b, pixel-shuffled to [n,H,W,7]
-    M3R_OK(layernorm(c, dt, x, nullptr, p32(c, "decoder.norm_dec.weight"), p32(c, "decoder.norm_dec.bias"), h16, hlo,
-                     A->feats ? A->feats + (size_t)(L - 1) * R * D : nullptr, nullptr,
-                     R, D, 1e-6f, s));
+    M3R_OK(layernorm_a(c, dt, with_slabs(lnargs(x, nullptr, p32(c, "decoder.norm_dec.weight"), p32(c, "decoder.norm_dec.bias"), h16, hlo,
+                                               A->feats ? A->feats + (size_t)(L - 1) * R * D : nullptr, nullptr, R, D, 1e-6f)), s));
     const void *whi, *wlo;
     M3R_OK(p16(c, "decoder.head_dec.proj_ps.weight", dt, true, &whi, &wlo, s));
     for (int gi = 0; gi < A->n_groups; ++gi) {
@@ -1048,6 +1071,17 @@ extern "C" int must3r_hip_op_gemm(int dtype, int epi, const void* A, const void*
     return 0;
 }
 
+extern "C" int must3r_hip_op_gemm_splitk(int dtype, const void* A, const void* W2, float* slabs, int M, int N, int K, int lda, int ldc,
+                                         int ksplit, long long slab_stride, void* stream) {
+    if (dtype != MUST3R_F16) return fail("op_gemm_splitk: fp16 operands with split weights only");
+    if (ksplit < 2 || ksplit > 16) return fail("op_gemm_splitk: ksplit must be 2..16");
+    GemmArgs a = gargs(A, W2, nullptr, slabs, M, N, K, lda, ldc);
+    a.wsplit = 2; a.ksplit = ksplit; a.slab_stride = slab_stride;
+    const char* err = "";
+    if (launch_gemm(DT_F16, EPI_F32, a, reinterpret_cast<hipStream_t>(stream), &err)) return fail("%s", err);
+    return 0;
+}
+
 extern "C" size_t must3r_hip_attention_scratch_bytes(int nsplit, int total_q_rows, int heads) {
     return attention_split_scratch_bytes(nsplit, total_q_rows, heads);
 }
@@ -1078,6 +1112,18 @@ extern "C" int must3r_hip_op_layernorm(int dtype, const float* x, const float* a
                                        void* out16_lo, float* out32, float* copy32, int M, int C, float eps, void* stream) {
     if (dtype != MUST3R_BF16 && dtype != MUST3R_F16) return fail("op_layernorm: bad dtype");
     LnArgs a = lnargs(x, add, w, b, out16, out16_lo, out32, copy32, M, C, eps);
+    const char* err = "";
+    if (launch_layernorm((DType)dtype, a, reinterpret_cast<hipStream_t>(stream), &err)) return fail("%s", err);
+    return 0;
+}
+
+extern "C" int must3r_hip_op_layernorm_slabs(int dtype, float* x, const float* slabs, int nslabs, long long slab_stride,
+                                             const float* slab_bias, const float* w, const float* b, void* out16, float* copy32, int M,
+                                             int C, float eps, void* stream) {
+    if (dtype != MUST3R_BF16 && dtype != MUST3R_F16) return fail("op_layernorm_slabs: bad dtype");
+    if (nslabs < 1 || !slabs || !x) return fail("op_layernorm_slabs: needs x and at least one slab");
+    LnArgs a = lnargs(x, nullptr, w, b, out16, nullptr, nullptr, copy32, M, C, eps);
+    a.slabs = slabs; a.nslabs = nslabs; a.slab_stride = slab_stride; a.slab_bias = slab_bias; a.xw = x;
     const char* err = "";
     if (launch_layernorm((DType)dtype, a, reinterpret_cast<hipStream_t>(stream), &err)) return fail("%s", err);
     return 0;

@@ -32,7 +32,9 @@ def make(name, heads, nviews, nq, nk, self_attn, nsplit=0):
     return name, go, 4.0 * nviews * nq * nk * D, (q, k, v, o, tab, ws)
 cases = [make("render CA 20v nk15360", 12, 20, 768, 15360, False), make("enc SA 20v n768", 16, 20, 768, 768, True),
          make("update CA 1v nk7680 s7", 12, 1, 768, 7680, False, 7), make("update CA 1v nk14592 s8", 12, 1, 768, 14592, False, 8),
-         make("update SA 1v n768", 12, 1, 768, 768, True), make("render CA 20v nk1960 (224)", 12, 10, 196, 1960, False)]
+         make("update SA 1v n768", 12, 1, 768, 768, True), make("render CA 20v nk1960 (224)", 12, 10, 196, 1960, False),
+         make("update CA 1v nk7680 s10", 12, 1, 768, 7680, False, 10), make("update CA 1v nk7680 s14", 12, 1, 768, 7680, False, 14),
+         make("update CA 1v nk14592 s14", 12, 1, 768, 14592, False, 14), make("render CA 20v nk15360 s2", 12, 20, 768, 15360, False, 2)]
 for name, go, fl, _ in cases:
     go()
 torch.cuda.synchronize()
@@ -45,7 +47,7 @@ for rnd in range(5):
         for _ in range(iters): go()
         e1.record(); torch.cuda.synchronize()
         res[name].append(e0.elapsed_time(e1) / iters)
-print(f"M3R_ATTN={os.environ.get('M3R_ATTN','1')} FP8={FP8}")
+print(f"M3R_ATTN={os.environ.get('M3R_ATTN','0')} QW={os.environ.get('M3R_ATTN_QW','32')} FP8={FP8}")
 for name, go, fl, _ in cases:
     r = sorted(res[name]); med, mn = r[len(r)//2], r[0]
     print(f"  {name:28s} median {med*1e3:9.1f} us {fl/med/1e9:8.1f} TF/s   min {mn*1e3:9.1f} us {fl/mn/1e9:8.1f} TF/s", flush=True)
