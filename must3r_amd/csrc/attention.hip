@@ -12,6 +12,7 @@
 // buffered, one barrier per tile.  Keys may exclude one contiguous range per view (MUSt3R own-token rule,
 // decoder.py:119-139): fully excluded tiles are never loaded, partially excluded ones are masked.
 #include <cstdlib>
+#include <type_traits>
 #include "common.hpp"
 #include "kernels.hpp"
 
@@ -694,6 +695,324 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) a
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// attn3_kernel: attn_kernel with the per-tile instruction count cut down.  The r02 cycle trace (scripts/probes/attn_trace.hip)
+// and the QW / pipelining experiments say that a SIMD spends ~1500 cycles per (wave, key tile) however many waves share it and
+// however the work is arranged: 576 of them are the 36 MFMAs, the rest is the ~265 other instructions the loop body issues
+// (177 VALU, 28 LDS / DMA, ~60 scalar) -- the kernel is bound by what it ISSUES, and most of that was bookkeeping:
+//   * K/V staging: `buffer_load_dwordx4 ... lds` with a per-lane voffset computed once and the tile position in the SCALAR
+//     offset: no per-tile 64-bit address arithmetic, no clamping (rows past nk are out of the descriptor's range and read as
+//     zero; they are masked like before).
+//   * LDS addresses: the swizzles are XORs with per-lane constants, so every fragment address is one of a few per-lane VGPRs
+//     plus an immediate (buffer, k-slot, row block): 2 VGPRs for the K fragments, 4 for the transposing V reads; the loop is
+//     unrolled over the two buffers so that the buffer is part of the immediate.
+//   * softmax fast path: the cross-lane row maximum is only needed when the reference moves.  Whether it has to move is decided
+//     from the PER-LANE maxima (`any lane above the threshold`, one compare per 16 queries), the permlane exchanges, the
+//     first-tile selects and the rescale live in one wave-uniform slow block that updates S, O, the row sums and m IN PLACE
+//     (no second register version of the accumulators, no copies at a join).
+// Same arithmetic as attn_kernel on the fast path (S - m from the accumulator init, exp2, P rounded to T, row sums from the
+// ones MFMA); the slow path subtracts the shift before the exp2 like attn_kernel does.
+template <int O0, int O1>
+__device__ __forceinline__ void lds_tr_x8_imm(unsigned a0, unsigned a1, unsigned a2, unsigned a3, u32x2 (&r)[8]) {
+    asm volatile(
+        "ds_read_b64_tr_b16 %0, %8 offset:%12\n\t"
+        "ds_read_b64_tr_b16 %1, %8 offset:%13\n\t"
+        "ds_read_b64_tr_b16 %2, %9 offset:%12\n\t"
+        "ds_read_b64_tr_b16 %3, %9 offset:%13\n\t"
+        "ds_read_b64_tr_b16 %4, %10 offset:%12\n\t"
+        "ds_read_b64_tr_b16 %5, %10 offset:%13\n\t"
+        "ds_read_b64_tr_b16 %6, %11 offset:%12\n\t"
+        "ds_read_b64_tr_b16 %7, %11 offset:%13\n\t"
+        "s_waitcnt lgkmcnt(0)"
+        : "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]), "=&v"(r[3]), "=&v"(r[4]), "=&v"(r[5]), "=&v"(r[6]), "=&v"(r[7])
+        : "v"(a0), "v"(a1), "v"(a2), "v"(a3), "n"(O0), "n"(O1)
+        : "memory");
+}
+
+__device__ __forceinline__ float max3f(float a, float b, float c) {   // v_max3_f32 without fmaxf's NaN-quieting v_max x, x, x
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
+template <class T, int QW, int ABL = 0>   // ABL: timing ablations for experiments (1 no exp2, 2 no max / slow path, 3 no P.V MFMAs, 4 no cvt)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(QW == 32 ? 3 : 2))) attn3_kernel(const AttnArgs p, const int nqb, const int ngrp, const int nsplit) {
+    typedef typename Vec<T>::v8 v8;
+    typedef typename Vec<T>::v4 v4;
+    constexpr int QF = QW / 16;
+    constexpr int QB = 4 * QW;
+    constexpr int TILE = ATT_KT * 64;                                    // elements of one K (or V) tile
+    __shared__ __attribute__((aligned(16))) T smem_kv[2][2][TILE];       // [buffer][K|V][64 keys x 64]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 15, fg = lane >> 4;
+
+    int grp, split, qb;
+    if (!attn_block_coords(nqb, ngrp, nsplit, grp, split, qb)) return;
+    const int view = grp / p.heads, head = grp - view * p.heads;
+    const AttnView vw = p.views[view];
+    if (qb * QB >= vw.nq) return;
+
+    const T* __restrict__ Q = reinterpret_cast<const T*>(p.Q);
+    const T* __restrict__ K = reinterpret_cast<const T*>(p.K) + (size_t)vw.kv_row0 * p.ldk + head * 64;
+    const T* __restrict__ V = reinterpret_cast<const T*>(p.V) + (size_t)vw.kv_row0 * p.ldv + head * 64;
+
+    const int qr0 = qb * QB + wave * QW;
+    v8 qf_[QF][2];
+#pragma unroll
+    for (int f = 0; f < QF; ++f) {
+        int r = qr0 + f * 16 + fr;
+        r = r < vw.nq ? r : vw.nq - 1;
+        const T* src = Q + (size_t)(vw.q_row0 + r) * p.ldq + head * 64 + fg * 8;
+        qf_[f][0] = *reinterpret_cast<const v8*>(src);
+        qf_[f][1] = *reinterpret_cast<const v8*>(src + 32);
+    }
+
+    const int nk = vw.nk, slo = vw.skip_lo, shi = vw.skip_hi;
+    const int ntiles = (nk + ATT_KT - 1) / ATT_KT;
+    auto fully_skipped = [&](int t) {
+        const int k0 = t * ATT_KT;
+        const int k1 = (k0 + ATT_KT < nk) ? k0 + ATT_KT : nk;
+        return k0 >= slo && k1 <= shi;
+    };
+    const int tps = (ntiles + nsplit - 1) / nsplit;
+    const int t_begin = split * tps;
+    const int t_end = (t_begin + tps < ntiles) ? t_begin + tps : ntiles;
+    auto advance = [&](int t) {
+        ++t;
+        if (shi > slo)
+            while (t < t_end && fully_skipped(t)) ++t;
+        return t;
+    };
+
+    // ---- staging through buffer descriptors: rows >= nk lie outside the descriptor and read as zero
+    const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(K), 0, ((nk - 1) * p.ldk + 64) * 2, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(V), 0, ((nk - 1) * p.ldv + 64) * 2, 0x00020000);
+    int vok[2], vov[2];
+    {
+        const int srow = lane >> 3, pch = lane & 7;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int r = (wave * 2 + i) * 8 + srow;
+            vok[i] = (r * p.ldk + swz(r, pch) * 8) * 2;
+            vov[i] = (r * p.ldv + swz_v(r, pch) * 8) * 2;
+        }
+    }
+    const int tstride_k = ATT_KT * p.ldk * 2, tstride_v = ATT_KT * p.ldv * 2;
+    auto stage = [&](int t, auto bufc) {
+        constexpr int buf = decltype(bufc)::value;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rk, (__attribute__((address_space(3))) void*)&smem_kv[buf][0][(wave * 2 + i) * 8 * 64], 16, vok[i],
+                                                     t * tstride_k, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, (__attribute__((address_space(3))) void*)&smem_kv[buf][1][(wave * 2 + i) * 8 * 64], 16, vov[i],
+                                                     t * tstride_v, 0, 0);
+        }
+    };
+
+    // ---- per-lane LDS offsets (elements for the K fragments, byte addresses for the transposing V reads)
+    //   K fragment (ks, kf): row 16 kf + fr, chunk (4 ks + fg) ^ ((fr >> 1) & 7) = z ^ (4 ks)
+    //   V^T read (ks, d, half h): row 32 ks + 16 h + 4 fg + (fr >> 2), chunk pair (d ^ x), x = (2 fg + (fr >> 3)) & 3
+    int koff[2];
+    {
+        const int z = fg ^ ((fr >> 1) & 7);
+        koff[0] = fr * 64 + z * 8;
+        koff[1] = fr * 64 + (z ^ 4) * 8;
+    }
+    unsigned vaddr[4];
+    {
+        const int x = (2 * fg + (fr >> 3)) & 3;
+        const unsigned base = (unsigned)(size_t)(__attribute__((address_space(3))) const T*)(&smem_kv[0][1][0]);
+        const unsigned lane_base = (unsigned)((4 * fg + (fr >> 2)) * 128 + ((fr >> 1) & 1) * 16 + (fr & 1) * 8);
+#pragma unroll
+        for (int d = 0; d < 4; ++d) vaddr[d] = base + lane_base + (unsigned)((d ^ x) * 32);
+    }
+
+    // nm_[f] = -m/c splat: the C operand of the first S MFMA of every key fragment (S - m for free); it only changes in the slow
+    // block.  any_first: some query of this wave has not seen a valid key yet (wave-uniform, re-evaluated in the slow block).
+    f32x4 o_[4][QF], ol_[QF], nm_[QF];
+    float m_[QF];
+    bool any_first = true;
+#pragma unroll
+    for (int f = 0; f < QF; ++f) {
+        m_[f] = -INFINITY;
+        ol_[f] = f32x4{0.f, 0.f, 0.f, 0.f};
+        nm_[f] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int d = 0; d < 4; ++d) o_[d][f] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const bool has_skip = shi > slo;
+    const float c = p.q_prescaled ? 1.0f : p.scale * 1.44269504088896340736f;
+    const float inv_c = 1.0f / c;
+    v8 ones;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ones[e] = (T)1.0f;
+
+    auto compute = [&](int t, auto bufc) {
+        constexpr int buf = decltype(bufc)::value;
+        const T* k_ = smem_kv[buf][0];
+        // ---- S^T = K Q^T - m
+        f32x4 s_[4][QF];
+#pragma unroll
+        for (int kf = 0; kf < 4; ++kf) {
+            const v8 kfrag = *reinterpret_cast<const v8*>(k_ + koff[0] + kf * 16 * 64);
+#pragma unroll
+            for (int f = 0; f < QF; ++f) s_[kf][f] = mfma16(kfrag, qf_[f][0], nm_[f]);
+        }
+#pragma unroll
+        for (int kf = 0; kf < 4; ++kf) {
+            const v8 kfrag = *reinterpret_cast<const v8*>(k_ + koff[1] + kf * 16 * 64);
+#pragma unroll
+            for (int f = 0; f < QF; ++f) s_[kf][f] = mfma16(kfrag, qf_[f][1], s_[kf][f]);
+        }
+        if (!p.q_prescaled) {
+#pragma unroll
+            for (int kf = 0; kf < 4; ++kf)
+#pragma unroll
+                for (int f = 0; f < QF; ++f) s_[kf][f] *= c;
+        }
+        const int k0 = t * ATT_KT;
+        const bool need_mask = (k0 + ATT_KT > nk) || (has_skip && k0 < shi && k0 + ATT_KT > slo);
+        if (need_mask) {
+#pragma unroll
+            for (int kf = 0; kf < 4; ++kf)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int key = k0 + kf * 16 + fg * 4 + r;
+                    const bool bad = (key >= nk) | ((key >= slo) & (key < shi));
+                    const float pen = bad ? -INFINITY : 0.f;
+#pragma unroll
+                    for (int f = 0; f < QF; ++f) s_[kf][f][r] += pen;
+                }
+        }
+        // ---- does any reference have to move?  decided from ONE per-lane maximum over all the lane's scores
+        float mxa = max3f(s_[0][0][0], s_[0][0][1], s_[0][0][2]);
+        mxa = fmaxf(mxa, s_[0][0][3]);
+#pragma unroll
+        for (int kf = 0; kf < 4; ++kf)
+#pragma unroll
+            for (int f = 0; f < QF; ++f) {
+                if (ABL == 2) continue;
+                if (kf == 0 && f == 0) continue;
+                mxa = max3f(mxa, s_[kf][f][0], s_[kf][f][1]);
+                mxa = max3f(mxa, s_[kf][f][2], s_[kf][f][3]);
+            }
+        if (ABL != 2 && (any_first || __any(mxa > ATT_THR))) {   // wave-uniform, rare after the first tile: everything updated in place
+            bool fst = false;
+#pragma unroll
+            for (int f = 0; f < QF; ++f) {
+                float mx = fmaxf(s_[0][f][0], s_[0][f][1]);
+#pragma unroll
+                for (int kf = 0; kf < 4; ++kf)
+#pragma unroll
+                    for (int r = (kf == 0 ? 2 : 0); r < 4; ++r) mx = fmaxf(mx, s_[kf][f][r]);
+                mx = quad_row_max(mx);
+                const bool first = (m_[f] == -INFINITY);
+                float d = first ? mx : fmaxf(mx, 0.f);
+                d = (d == -INFINITY) ? 0.f : d;                       // row still has no valid key
+                const float alpha = first ? 1.0f : __builtin_amdgcn_exp2f(-d);
+#pragma unroll
+                for (int kf = 0; kf < 4; ++kf) s_[kf][f] -= d;
+#pragma unroll
+                for (int dd = 0; dd < 4; ++dd) o_[dd][f] *= alpha;
+                ol_[f] *= alpha;
+                m_[f] = first ? ((mx == -INFINITY) ? -INFINITY : d) : m_[f] + d;
+                const float nm = (m_[f] == -INFINITY) ? 0.f : -m_[f] * inv_c;
+                nm_[f] = f32x4{nm, nm, nm, nm};
+                fst |= (m_[f] == -INFINITY);
+            }
+            any_first = __any(fst);
+        }
+#pragma unroll
+        for (int kf = 0; kf < 4; ++kf)
+#pragma unroll
+            for (int f = 0; f < QF; ++f)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) s_[kf][f][r] = ABL == 1 ? s_[kf][f][r] * 0.001f : __builtin_amdgcn_exp2f(s_[kf][f][r]);
+        // ---- O^T += V^T P^T ; k-slot e of lane group g <-> keys {4g+e (e<4), 16+4g+e-4 (e>=4)} of the 32-key slot
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            v8 pb[QF];
+#pragma unroll
+            for (int f = 0; f < QF; ++f) {
+                f32x8 pv;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    pv[r] = s_[2 * ks][f][r];
+                    pv[4 + r] = s_[2 * ks + 1][f][r];
+                }
+                if (ABL == 4) __builtin_memcpy(&pb[f], &pv, 16);   // first four fp32 words as the fragment: no conversion
+                else pb[f] = cvt8<T>(pv);
+                if (ABL == 3) { asm volatile("" ::"v"(pb[f])); continue; }
+                ol_[f] = mfma16(ones, pb[f], ol_[f]);
+            }
+            if (ABL == 3) continue;
+            u32x2 tr[8];
+            if (ks == 0) lds_tr_x8_imm<buf * 4 * TILE, buf * 4 * TILE + 16 * 128>(vaddr[0], vaddr[1], vaddr[2], vaddr[3], tr);
+            else lds_tr_x8_imm<buf * 4 * TILE + 32 * 128, buf * 4 * TILE + 48 * 128>(vaddr[0], vaddr[1], vaddr[2], vaddr[3], tr);
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                v4 lo, hi;
+                __builtin_memcpy(&lo, &tr[2 * d], 8);
+                __builtin_memcpy(&hi, &tr[2 * d + 1], 8);
+                const v8 vfrag = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+                for (int f = 0; f < QF; ++f) o_[d][f] = mfma16(vfrag, pb[f], o_[d][f]);
+            }
+        }
+    };
+
+    int t = advance(t_begin - 1);
+    if (t < t_end) stage(t, std::integral_constant<int, 0>{});
+    while (t < t_end) {
+        {
+            __builtin_amdgcn_s_waitcnt(0x0f70);
+            __syncthreads();
+            const int tn = advance(t);
+            if (tn < t_end) stage(tn, std::integral_constant<int, 1>{});
+            compute(t, std::integral_constant<int, 0>{});
+            t = tn;
+        }
+        if (t >= t_end) break;
+        {
+            __builtin_amdgcn_s_waitcnt(0x0f70);
+            __syncthreads();
+            const int tn = advance(t);
+            if (tn < t_end) stage(tn, std::integral_constant<int, 0>{});
+            compute(t, std::integral_constant<int, 1>{});
+            t = tn;
+        }
+    }
+
+    // ---- normalise and store: lane (q = fr, g) holds O[q][d = 16 dd + 4 g + r]
+    T* __restrict__ O = reinterpret_cast<T*>(p.O);
+#pragma unroll
+    for (int f = 0; f < QF; ++f) {
+        const float l = ol_[f][0];
+        const int q = qr0 + f * 16 + fr;
+        if (q >= vw.nq) continue;
+        const size_t row = (size_t)(vw.q_row0 + q);
+        if (nsplit <= 1) {
+            const float inv = l > 0.f ? 1.0f / l : 0.f;
+            T* dst = O + row * p.ldo + head * 64 + fg * 4;
+#pragma unroll
+            for (int d = 0; d < 4; ++d) *reinterpret_cast<v4*>(dst + d * 16) = cvt4<T>(o_[d][f] * inv);
+        } else {
+            const size_t D = (size_t)p.heads * 64;
+            float* po = p.part_o + ((size_t)split * p.total_q_rows + row) * D + head * 64 + fg * 4;
+#pragma unroll
+            for (int d = 0; d < 4; ++d) *reinterpret_cast<f32x4*>(po + d * 16) = o_[d][f];
+            if (fg == 0) {
+                float* pm = p.part_ml + (((size_t)split * p.total_q_rows + row) * p.heads + head) * 2;
+                pm[0] = m_[f];
+                pm[1] = l;
+            }
+        }
+    }
+}
+
 // merge of the split-KV partials: O = sum_s 2^(m_s - m*) O_s / sum_s 2^(m_s - m*) l_s ; one thread = 4 columns
 template <class T>
 __global__ void attn_combine_kernel(const AttnArgs p, const int nsplit) {
@@ -803,17 +1122,28 @@ int launch_attention_phase(DType dt, const AttnArgs& a, int phase, hipStream_t s
                                a.part_ml, n2);
         }
     } else if (phase == 1) {
-        // 16-bit operands: attn_kernel by default.  The pipelined attn2_kernel (M3R_ATTN=1) measured 1-3 % slower on every shape
-        // of the scene (render cross attention 689 vs 702-712 TF/s, gpurun_out r02 A/B); it is the only fp8 kernel.
+        // 16-bit operands: attn3_kernel (M3R_ATTN=2, default): render cross attention 892 TF/s against 739 for attn_kernel (M3R_ATTN=0)
+        // and 689-720 for the pipelined attn2_kernel (M3R_ATTN=1), which stays the fp8 kernel (profiles/r02_attn_ab.txt).
         static int variant = -1;
         if (variant < 0) {
             const char* e = getenv("M3R_ATTN");
-            variant = e ? atoi(e) : 0;
+            variant = e ? atoi(e) : 2;
         }
 #define M3R_LAUNCH_ATTN(KERNEL) hipLaunchKernelGGL(KERNEL, dim3(grid), dim3(256), 0, s, a, nqb, ngrp, nsplit)
         if (a.fp8) {
             if (small) { if (dt == DT_BF16) M3R_LAUNCH_ATTN((attn2_kernel<bf16_t, 16, true>)); else M3R_LAUNCH_ATTN((attn2_kernel<f16_t, 16, true>)); }
             else { if (dt == DT_BF16) M3R_LAUNCH_ATTN((attn2_kernel<bf16_t, 32, true>)); else M3R_LAUNCH_ATTN((attn2_kernel<f16_t, 32, true>)); }
+        } else if (variant == 2) {
+            static const int abl = getenv("M3R_ATTN_ABL") ? atoi(getenv("M3R_ATTN_ABL")) : 0;   // timing ablations (wrong results)
+            if (!small && dt == DT_F16 && abl == 1) M3R_LAUNCH_ATTN((attn3_kernel<f16_t, 32, 1>));
+            else if (!small && dt == DT_F16 && abl == 2) M3R_LAUNCH_ATTN((attn3_kernel<f16_t, 32, 2>));
+            else if (!small && dt == DT_F16 && abl == 3) M3R_LAUNCH_ATTN((attn3_kernel<f16_t, 32, 3>));
+            else if (!small && dt == DT_F16 && abl == 4) M3R_LAUNCH_ATTN((attn3_kernel<f16_t, 32, 4>));
+            else if (!small && dt == DT_F16 && qw_big == 48) M3R_LAUNCH_ATTN((attn3_kernel<f16_t, 48>));
+            else if (!small && dt == DT_F16 && qw_big == 64) M3R_LAUNCH_ATTN((attn3_kernel<f16_t, 64>));
+            else
+            if (small) { if (dt == DT_BF16) M3R_LAUNCH_ATTN((attn3_kernel<bf16_t, 16>)); else M3R_LAUNCH_ATTN((attn3_kernel<f16_t, 16>)); }
+            else { if (dt == DT_BF16) M3R_LAUNCH_ATTN((attn3_kernel<bf16_t, 32>)); else M3R_LAUNCH_ATTN((attn3_kernel<f16_t, 32>)); }
         } else if (variant == 0) {
             if (!small && qw_big == 48 && dt == DT_F16) M3R_LAUNCH_ATTN((attn_kernel<f16_t, 48>));
             else if (!small && qw_big == 64 && dt == DT_F16) M3R_LAUNCH_ATTN((attn_kernel<f16_t, 64>));
