@@ -183,12 +183,12 @@ def main():
     classes = {k: {"ms": round(v["ms"], 3), "calls": int(v["calls"]),
                    "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1) if v["ms"] > 0 and v["flops"] > 0 else None}
                for k, v in prof.items()}
-    # roofline of the dominant KERNEL = one symbol of the rocprofv3 trace.  attn_kernel (self + cross launches) is the top
+    # roofline of the dominant KERNEL = one symbol of the rocprofv3 trace.  attn3_kernel (self + cross launches) is the top
     # symbol in every precision; the GEMM template is spread over one symbol per epilogue, so its two tile classes are
     # reported next to it under "roofline_gemm".
-    kern = {"attn_kernel": (["attn_self", "attn_cross"], ("attn_kernel",)),
+    kern = {"attn3_kernel": (["attn_self", "attn_cross"], ("attn3_kernel", "attn_kernel", "attn2_kernel")),
             "gemm_kernel<big tile>": (["gemm128"], ("gemm256_kernel", "Li128ELi64E", "Li128ELi128E")),
-            "gemm_kernel<small-M>": (["gemm64"], ("Li64ELi64E", "gemm48_kernel", "gemms_kernel"))}
+            "gemm_kernel<small-M>": (["gemm64"], ("Li64ELi64E", "gemm48_kernel", "gemm96_kernel", "gemms_kernel"))}
     try:
         import glob
         pmc_file = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))[-1]
@@ -215,7 +215,7 @@ def main():
             r["traffic_source"] = os.path.relpath(pmc_file, ROOT) + " (separate --pmc passes of this command; not this run)"
         return r
 
-    roofline = roof("attn_kernel")
+    roofline = roof("attn3_kernel")
     roofline_gemm = [roof("gemm_kernel<big tile>"), roof("gemm_kernel<small-M>")]
     # stage split (untimed extra step, single GPU only)
     if world == 1:

@@ -999,6 +999,17 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(QW == 
             T* dst = O + row * p.ldo + head * 64 + fg * 4;
 #pragma unroll
             for (int d = 0; d < 4; ++d) *reinterpret_cast<v4*>(dst + d * 16) = cvt4<T>(o_[d][f] * inv);
+        } else if (p.part16) {   // normalised partial O_s / l_s in the 16-bit type: half the partial traffic
+            const size_t D = (size_t)p.heads * 64;
+            const float inv = l > 0.f ? 1.0f / l : 0.f;
+            T* po = reinterpret_cast<T*>(p.part_o) + ((size_t)split * p.total_q_rows + row) * D + head * 64 + fg * 4;
+#pragma unroll
+            for (int d = 0; d < 4; ++d) *reinterpret_cast<v4*>(po + d * 16) = cvt4<T>(o_[d][f] * inv);
+            if (fg == 0) {
+                float* pm = p.part_ml + (((size_t)split * p.total_q_rows + row) * p.heads + head) * 2;
+                pm[0] = m_[f];
+                pm[1] = l;
+            }
         } else {
             const size_t D = (size_t)p.heads * 64;
             float* po = p.part_o + ((size_t)split * p.total_q_rows + row) * D + head * 64 + fg * 4;
@@ -1031,9 +1042,14 @@ __global__ void attn_combine_kernel(const AttnArgs p, const int nsplit) {
         float L = 0.f;
         for (int s = 0; s < nsplit; ++s) {
             const float* ml = p.part_ml + (((size_t)s * p.total_q_rows + row) * p.heads + head) * 2;
-            const float w = __builtin_amdgcn_exp2f(ml[0] - mstar);
+            float w = __builtin_amdgcn_exp2f(ml[0] - mstar);
             L += w * ml[1];
-            acc += *reinterpret_cast<const f32x4*>(p.part_o + ((size_t)s * p.total_q_rows + row) * D + col) * w;
+            if (p.part16) {   // partial holds O_s / l_s
+                w *= ml[1];
+                acc += __builtin_convertvector(*reinterpret_cast<const v4*>(reinterpret_cast<const T*>(p.part_o) + ((size_t)s * p.total_q_rows + row) * D + col), f32x4) * w;
+            } else {
+                acc += *reinterpret_cast<const f32x4*>(p.part_o + ((size_t)s * p.total_q_rows + row) * D + col) * w;
+            }
         }
         const float inv = L > 0.f ? 1.0f / L : 0.f;
         *reinterpret_cast<v4*>(reinterpret_cast<T*>(p.O) + row * p.ldo + col) = cvt4<T>(acc * inv);
@@ -1092,8 +1108,14 @@ int launch_tr_probe(short* out, hipStream_t s) {
 }
 
 // phase 0: (m,l) pre-fill (split-KV with holes only), 1: main kernel, 2: combine (split-KV only)
-int launch_attention_phase(DType dt, const AttnArgs& a, int phase, hipStream_t s, const char** err) {
+int launch_attention_phase(DType dt, const AttnArgs& a_in, int phase, hipStream_t s, const char** err) {
+    AttnArgs a = a_in;
     if (a.nviews <= 0 || a.max_nq <= 0) return 0;
+    {   // split-KV partials of the fp16 attn3 path are written normalised, in fp16 (the bf16 / fp8 / older kernels keep fp32)
+        static const int variant0 = getenv("M3R_ATTN") ? atoi(getenv("M3R_ATTN")) : 2;
+        static const bool p16 = !(getenv("M3R_ATTN_PART16") && atoi(getenv("M3R_ATTN_PART16")) == 0);
+        a.part16 = (p16 && variant0 == 2 && dt == DT_F16 && !a.fp8 && a.nsplit > 1) ? 1 : 0;
+    }
     if ((a.ldq % (a.fp8 ? 16 : 8)) || (a.ldk % (a.fp8 ? 16 : 8)) || (a.ldv % (a.fp8 ? 16 : 8)) || (a.ldo % 4)) { *err = "attention: row strides must be 16-byte aligned"; return 1; }
     const int nsplit = a.nsplit > 1 ? a.nsplit : 1;
     if (nsplit > 1 && (!a.part_o || !a.part_ml || a.total_q_rows <= 0)) { *err = "attention: split-KV needs scratch"; return 1; }

@@ -710,7 +710,7 @@ static int launch_48(const GemmArgs& a, hipStream_t s) {
 // same bits as the other tile shapes.
 // gridDim.z > 1: split-K.  Block z multiplies K-tiles [z nk, (z+1) nk) and stores its fp32 partial tile, without bias, into
 // slab z (out + z * slab_stride); the consumer (LayerNorm with LnArgs::slabs) adds the slabs in a fixed order.
-template <class T, int EPI, int NST>
+template <class T, int EPI, int NST, int PF>
 __global__ void __launch_bounds__(576) gemm96_kernel(const GemmArgs p) {
     typedef typename Vec<T>::v8 v8;
     constexpr int BM = 96, BN = 96, BK = 64, NW = 9, RPP = 8, WS = 2;
@@ -788,6 +788,83 @@ __global__ void __launch_bounds__(576) gemm96_kernel(const GemmArgs p) {
                 w_off[ks][part][j] = (BM + rr) * BK + swz(rr, ks * 4 + fg) * 8;
             }
     }
+    if constexpr (PF) {
+        // Software-pipelined form.  In the loop below every wave does, per K-tile, [4 DMA][12 LDS reads][16 MFMAs] one after the other
+        // and all nine waves do it in lock step behind the barrier: the DMA burst alone keeps the CU's L2->LDS path busy for ~600
+        // cycles (36 KB at ~64 B/clk) during which no MFMA issues.  Here the three instruction streams are interleaved inside each
+        // wave: the MFMAs of tile kt (fragments read one iteration earlier) are issued in four groups of four, and after each group
+        // one DMA piece of tile kt+NST and three fragment reads of tile kt+1 -- the matrix pipe works through a group while the
+        // wave sits in the memory instructions.  All NST slots are prefetch depth (tile kt's slot is refilled while tile kt is
+        // multiplied from registers).  Same accumulation order (k-slot 0 hi, 0 lo, 1 hi, 1 lo) -> same bits.
+        v8 fa[2][2][MF], fw[2][2][WS][NF];   // [set][ks]
+        auto read_group = [&](auto setc, int buf, auto gc) {   // 3 of the 12 fragment reads of a tile: group g = (ks, part)
+            constexpr int set = decltype(setc)::value, g = decltype(gc)::value, ks = g >> 1, part = g & 1;
+            const T* base = lds + buf * STAGE;
+#pragma unroll
+            for (int j = 0; j < NF; ++j) fw[set][ks][part][j] = *reinterpret_cast<const v8*>(base + w_off[ks][part][j]);
+            fa[set][ks][part] = *reinterpret_cast<const v8*>(base + a_off[ks][part]);   // MF == WS == 2: one activation fragment per group
+        };
+        auto mma_group = [&](auto setc, auto gc) {
+            constexpr int set = decltype(setc)::value, g = decltype(gc)::value, ks = g >> 1, part = g & 1;
+#pragma unroll
+            for (int i = 0; i < MF; ++i)
+#pragma unroll
+                for (int j = 0; j < NF; ++j) acc[i][j] = mfma16(fw[set][ks][part][j], fa[set][ks][i], acc[i][j]);
+        };
+        static_assert(MF == 2 && WS == 2 && TP == 4, "group split");
+#pragma unroll
+        for (int t = 0; t < NST; ++t)
+            if (t < nk) stage(t, t);
+        // tile 0 landed: up to NST-1 younger tiles in flight
+        if (nk >= NST) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 1) * TP) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        read_group(std::integral_constant<int, 0>{}, 0, std::integral_constant<int, 0>{});
+        read_group(std::integral_constant<int, 0>{}, 0, std::integral_constant<int, 1>{});
+        read_group(std::integral_constant<int, 0>{}, 0, std::integral_constant<int, 2>{});
+        read_group(std::integral_constant<int, 0>{}, 0, std::integral_constant<int, 3>{});
+        int buf = 0;
+        auto body = [&](auto curc, auto tailc, int kt) {
+            constexpr int cur = decltype(curc)::value;
+            constexpr bool tail = decltype(tailc)::value;   // main iterations: more tiles to stage and to read, no branches in the body
+            typedef std::integral_constant<int, cur ^ 1> Nxt;
+            const int nbuf = buf + 1 == NST ? 0 : buf + 1;
+            // tile kt+1 landed (its reads start below): tiles kt+2 .. kt+NST-1 may still be in flight; everybody's reads of tile kt
+            // (issued one iteration ago) have returned before the barrier, so its slot can be refilled after it
+            if (!tail) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * TP) : "memory");
+            else if (kt + 1 < nk) {
+                if (kt + NST - 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * TP) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            const bool more = !tail || kt + NST < nk, nxt = !tail || kt + 1 < nk;
+            T* sbase = lds + buf * STAGE;
+#define M3R_G96_GROUP(G)                                                                                                   \
+            mma_group(curc, std::integral_constant<int, G>{});                                                              \
+            if (more) glds16(src[G] + (kt + NST) * BK, sbase + (G * NW + wave) * RPP * BK);                                 \
+            if (nxt) read_group(Nxt{}, nbuf, std::integral_constant<int, G>{});                                             \
+            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);                                                              \
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                                                              \
+            __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+            M3R_G96_GROUP(0)
+            M3R_G96_GROUP(1)
+            M3R_G96_GROUP(2)
+            M3R_G96_GROUP(3)
+#undef M3R_G96_GROUP
+            buf = nbuf;
+        };
+        int kt = 0;
+        for (; kt + 1 + NST < nk; kt += 2) {   // both iterations stage a tile and read the next one
+            body(std::integral_constant<int, 0>{}, std::false_type{}, kt);
+            body(std::integral_constant<int, 1>{}, std::false_type{}, kt + 1);
+        }
+        for (; kt + 1 < nk; kt += 2) {
+            body(std::integral_constant<int, 0>{}, std::true_type{}, kt);
+            body(std::integral_constant<int, 1>{}, std::true_type{}, kt + 1);
+        }
+        if (kt < nk) body(std::integral_constant<int, 0>{}, std::true_type{}, kt);
+    } else {
 #pragma unroll
     for (int t = 0; t < NST - 1; ++t)
         if (t < nk) stage(t, t);
@@ -824,6 +901,7 @@ __global__ void __launch_bounds__(576) gemm96_kernel(const GemmArgs p) {
                     for (int j = 0; j < NF; ++j) acc[i][j] = mfma16(wf[ks][part][j], af[ks][i], acc[i][j]);
         buf = buf + 1 == NST ? 0 : buf + 1;
     }
+    }
 #pragma unroll
     for (int i = 0; i < MF; ++i) {
         const int m = m0 + wm * 32 + i * 16 + fr;
@@ -835,18 +913,23 @@ __global__ void __launch_bounds__(576) gemm96_kernel(const GemmArgs p) {
     }
 }
 
-template <class T, int EPI>
-static int launch_96(const GemmArgs& a, hipStream_t s) {
+template <class T, int EPI, int PF>
+static int launch_96pf(const GemmArgs& a, hipStream_t s) {
     constexpr int NST = 4;
     const int nbn = a.N / 96, nbm = (a.M + 95) / 96;
     const size_t lds = (size_t)NST * (96 + 2 * 96) * 64 * sizeof(T);
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm96_kernel<T, EPI, NST>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm96_kernel<T, EPI, NST, PF>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm96_kernel<T, EPI, NST>), dim3(nbm * nbn, a.batch > 1 ? a.batch : 1, a.ksplit > 1 ? a.ksplit : 1), dim3(576), lds, s, a);
+    hipLaunchKernelGGL((gemm96_kernel<T, EPI, NST, PF>), dim3(nbm * nbn, a.batch > 1 ? a.batch : 1, a.ksplit > 1 ? a.ksplit : 1), dim3(576), lds, s, a);
     return hipGetLastError() == hipSuccess ? 0 : 1;
+}
+template <class T, int EPI>
+static int launch_96(const GemmArgs& a, hipStream_t s) {
+    static const int pf = getenv("M3R_GEMM96_PF") ? atoi(getenv("M3R_GEMM96_PF")) : 1;   // 0: the lock-step loop (experiments)
+    return pf ? launch_96pf<T, EPI, 1>(a, s) : launch_96pf<T, EPI, 0>(a, s);
 }
 
 // Tile selection (measured on MI355X, scripts/bench_gemm.py): two resident blocks per CU beat every larger tile that

@@ -86,6 +86,7 @@ struct AttnArgs {
     float* part_ml;        // [nsplit][total_q_rows][heads][2] fp32 (running max in log2 domain, row sum)
     int total_q_rows;      // max over views of q_row0 + nq
     int dense_rows;        // every row < total_q_rows belongs to a view of this launch (no (m,l) pre-fill needed)
+    int part16;            // set by the launcher: part_o holds O_s / l_s in the 16-bit operand type instead of fp32 O_s
     int fp8;               // Q, K, V are OCP e4m3 bytes (row strides in bytes); O stays 16-bit.  attn2_kernel<.., F8 = true>
 };
 // bytes of scratch launch_attention needs for a given split factor

@@ -1,0 +1,88 @@
+// Probe: what does one CU sustain per "K-tile" of a small-M GEMM?  A block of NW waves loops; per iteration every wave issues
+// P LDS-DMA pieces (1 KB each, from an L2-resident region private to the block), R ds_read_b128 and M MFMAs (16x16x32 f16), then
+// waits for its DMA (counted: one iteration stays in flight) and passes a barrier -- the structure of gemm96 / gemm48 / the 64x64
+// ring without any address arithmetic in the loop.  Prints shader cycles per iteration (s_memtime of wave 0) and the wall time.
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 scripts/probes/pipe_rates.hip -o scripts/probes/build/pipe_rates && scripts/probes/build/pipe_rates
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <int P, int R, int M, int BAR>
+__global__ void __launch_bounds__(1024) probe(const char* __restrict__ src, int iters, unsigned long long* cyc, float* sink, int stride) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int nw = blockDim.x >> 6;
+    // per-block 256 KB region (L2 resident); piece p of wave w in iteration it: contiguous 1 KB chunks, cycling over 4 slots
+    // stride 0: a piece is 1 KB contiguous; else 8 rows x 128 B at `stride` bytes (the GEMM operand tiles)
+    const char* base = src + (size_t)blockIdx.x * (256 << 10) + (stride ? (lane >> 3) * stride + (lane & 7) * 16 : lane * 16);
+    f32x4 acc[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+    f16x8 a = {1, 1, 1, 1, 1, 1, 1, 1}, b = {1, 1, 1, 1, 1, 1, 1, 1};
+    f16x8 rd[4];
+    for (int i = 0; i < 4; ++i) rd[i] = a;
+    const unsigned lbase = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds + lane * 16;
+    unsigned long long t0 = 0;
+    for (int it = 0; it < iters; ++it) {
+        if (it == 8) t0 = __builtin_readcyclecounter();
+        const int slot = it & 3;
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            const int piece = (slot * P + p) * nw + wave;   // < 4 * P * nw <= 144 KB
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + (stride ? (size_t)((it * P + p) & 7) * 128 + (size_t)(wave & 7) * 8 * stride : (size_t)((it * P + p) & 63) * 4096 + wave * 128)),
+                                             (__attribute__((address_space(3))) void*)(lds + piece * 1024), 16, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            f16x8 v;
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(lbase + (unsigned)(wave * 4096)), "n"((r & 3) * 1024));
+            rd[r & 3] = v;
+        }
+        if (R) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int m = 0; m < M; ++m) acc[m & 3] = __builtin_amdgcn_mfma_f32_16x16x32_f16(rd[m & 3], b, acc[m & 3], 0, 0, 0);
+        if (P) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(P) : "memory");
+        if (BAR) __builtin_amdgcn_s_barrier();
+    }
+    const unsigned long long t1 = __builtin_readcyclecounter();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (threadIdx.x == 0 && blockIdx.x == 0) cyc[0] = t1 - t0;
+    float s = 0;
+    for (int i = 0; i < 4; ++i) s += acc[i][0] + (float)rd[i][0];
+    if (s == 12345.678f) sink[0] = s;
+}
+
+template <int P, int R, int M, int BAR>
+void run(const char* buf, int nw, unsigned long long* cyc, float* sink, int stride = 0) {
+    const int iters = 2008;
+    const size_t ldsb = 150 * 1024;   // one block per CU
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&probe<P, R, M, BAR>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    probe<P, R, M, BAR><<<256, nw * 64, ldsb>>>(buf, 64, cyc, sink, stride);
+    hipDeviceSynchronize();
+    hipEventRecord(e0);
+    probe<P, R, M, BAR><<<256, nw * 64, ldsb>>>(buf, iters, cyc, sink, stride);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms = 0;
+    hipEventElapsedTime(&ms, e0, e1);
+    unsigned long long c = 0;
+    hipMemcpy(&c, cyc, 8, hipMemcpyDeviceToHost);
+    const double per = (double)c / (iters - 8);
+    printf("stride %5d waves %2d  DMA %2d KB  reads %3d KB  MFMA/wave %2d  barrier %d : %7.0f cycles/iter  %6.3f us/iter  (DMA %5.1f B/clk, LDS rd %5.1f B/clk, MFMA pipe %4.0f%%)\n",
+           stride, nw, P * nw, R * nw, M, BAR, per, ms * 1e3 / iters, P * nw * 1024.0 / per, R * nw * 1024.0 / per, 100.0 * M * nw / 4.0 * 16 / per);
+}
+
+int main() {
+    char* buf; float* sink; unsigned long long* cyc;
+    hipMalloc(&buf, 256ull * (256 << 10)); hipMalloc(&sink, 64); hipMalloc(&cyc, 64);
+    hipMemset(buf, 0x3c, 256ull * (256 << 10));
+    for (int stride : {0, 1536, 3072, 2048, 1664}) {
+        printf("-- stride %d, 9 waves\n", stride);
+        run<4, 0, 0, 1>(buf, 9, cyc, sink, stride);
+        run<4, 12, 16, 1>(buf, 9, cyc, sink, stride);
+        run<3, 10, 8, 1>(buf, 8, cyc, sink, stride);
+    }
+    return 0;
+}
