@@ -729,9 +729,21 @@ __device__ __forceinline__ void lds_tr_x8_imm(unsigned a0, unsigned a1, unsigned
         : "memory");
 }
 
-__device__ __forceinline__ float max3f(float a, float b, float c) {   // v_max3_f32 without fmaxf's NaN-quieting v_max x, x, x
-    float r;
-    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+// maximum of 16 floats: four independent v_max3 chains merged at the end (depth 4, 8 instructions, ONE asm statement: hipcc pads
+// separate asm statements with s_nop and fmaxf chains with NaN-quieting v_max x, x, x -- both are issue slots the loop cannot afford)
+__device__ __forceinline__ float max16f(const f32x4& a, const f32x4& b, const f32x4& c, const f32x4& d) {
+    float r, t1, t2, t3;
+    asm("v_max3_f32 %0, %4, %5, %6\n\t"
+        "v_max3_f32 %1, %7, %8, %9\n\t"
+        "v_max3_f32 %2, %10, %11, %12\n\t"
+        "v_max3_f32 %3, %13, %14, %15\n\t"
+        "v_max3_f32 %0, %0, %16, %17\n\t"
+        "v_max3_f32 %1, %1, %18, %19\n\t"
+        "v_max3_f32 %0, %0, %1, %2\n\t"
+        "v_max_f32 %0, %0, %3"
+        : "=&v"(r), "=&v"(t1), "=&v"(t2), "=&v"(t3)
+        : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]), "v"(c[0]), "v"(c[1]), "v"(c[2]), "v"(c[3]),
+          "v"(d[0]), "v"(d[1]), "v"(d[2]), "v"(d[3]));
     return r;
 }
 
@@ -888,17 +900,14 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(QW == 
                 }
         }
         // ---- does any reference have to move?  decided from ONE per-lane maximum over all the lane's scores
-        float mxa = max3f(s_[0][0][0], s_[0][0][1], s_[0][0][2]);
-        mxa = fmaxf(mxa, s_[0][0][3]);
-#pragma unroll
-        for (int kf = 0; kf < 4; ++kf)
+        float mxa = -INFINITY;
+        if (ABL != 2) {
 #pragma unroll
             for (int f = 0; f < QF; ++f) {
-                if (ABL == 2) continue;
-                if (kf == 0 && f == 0) continue;
-                mxa = max3f(mxa, s_[kf][f][0], s_[kf][f][1]);
-                mxa = max3f(mxa, s_[kf][f][2], s_[kf][f][3]);
+                const float mf = max16f(s_[0][f], s_[1][f], s_[2][f], s_[3][f]);
+                mxa = f == 0 ? mf : fmaxf(mxa, mf);
             }
+        }
         if (ABL != 2 && (any_first || __any(mxa > ATT_THR))) {   // wave-uniform, rare after the first tile: everything updated in place
             bool fst = false;
 #pragma unroll

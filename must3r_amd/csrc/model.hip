@@ -91,6 +91,19 @@ struct must3r_hip_ctx {
     long long prof_calls[PC_COUNT] = {0};
 };
 
+// The entry points run on the context's device and leave the caller's current device as they found it (a process that
+// drives several GPUs keeps its own current device; torch's notion of it is not changed behind its back).
+struct DeviceGuard {
+    int prev = -1, want;
+    explicit DeviceGuard(int d) : want(d) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != want) (void)hipSetDevice(want);
+    }
+    ~DeviceGuard() {
+        if (prev >= 0 && prev != want) (void)hipSetDevice(prev);
+    }
+};
+
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 static int ws_reserve(must3r_hip_ctx* c, size_t bytes, hipStream_t s) {
@@ -355,7 +368,7 @@ extern "C" int must3r_hip_create(const must3r_hip_config* cfg, int device, must3
     HIP_OK(hipGetDeviceCount(&ndev));
     if (ndev <= 0) return fail("create: no HIP device visible (the HIP path has no CPU fallback)");
     if (device < 0 || device >= ndev) return fail("create: bad device %d", device);
-    HIP_OK(hipSetDevice(device));
+    DeviceGuard dev_guard(device);
     hipDeviceProp_t prop;
     HIP_OK(hipGetDeviceProperties(&prop, device));
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
@@ -379,7 +392,7 @@ extern "C" int must3r_hip_create(const must3r_hip_config* cfg, int device, must3
 
 extern "C" void must3r_hip_destroy(must3r_hip_ctx* c) {
     if (!c) return;
-    (void)hipSetDevice(c->device);
+    DeviceGuard dev_guard(c->device);
     (void)hipDeviceSynchronize();
     for (auto& kv : c->params) {
         Param& p = kv.second;
@@ -408,7 +421,7 @@ extern "C" int must3r_hip_load_weight(must3r_hip_ctx* c, const char* name, const
     bool same = (int)p->shape.size() == ndim;
     for (int i = 0; same && i < ndim; ++i) same = p->shape[i] == shape[i];
     if (!same) return fail("load_weight: shape mismatch for '%s'", name);
-    HIP_OK(hipSetDevice(c->device));
+    DeviceGuard dev_guard(c->device);
     if (!p->d) HIP_OK(hipMalloc(reinterpret_cast<void**>(&p->d), p->n * sizeof(float)));
     HIP_OK(hipMemcpy(p->d, data, p->n * sizeof(float), is_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
     for (int i = 0; i < 2; ++i) {  // invalidate packed copies
@@ -447,7 +460,7 @@ static int fetch(must3r_hip_ctx* c, const std::string& name, std::vector<float>&
 extern "C" int must3r_hip_finalize_weights(must3r_hip_ctx* c, int parts) {
     if (!c) return fail("finalize: null context");
     if (!(parts & 3)) return fail("finalize: parts must include MUST3R_PART_ENCODER and/or MUST3R_PART_DECODER");
-    HIP_OK(hipSetDevice(c->device));
+    DeviceGuard dev_guard(c->device);
     for (auto& kv : c->params) {
         const bool is_enc = kv.first.compare(0, 8, "encoder.") == 0;
         if (!((is_enc && (parts & 1)) || (!is_enc && (parts & 2)))) continue;
@@ -607,7 +620,7 @@ extern "C" int must3r_hip_encode(must3r_hip_ctx* c, int dtype, const float* img,
     if (n_views <= 0) return 0;
     if (H <= 0 || W <= 0 || H % 16 || W % 16) return fail("encode: H=%d W=%d must be positive multiples of 16", H, W);
     if (H / 16 > c->rope_npos || W / 16 > c->rope_npos) return fail("encode: image too large for the RoPE table");
-    HIP_OK(hipSetDevice(c->device));
+    DeviceGuard dev_guard(c->device);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const int N = (H / 16) * (W / 16);
     int per = 24576 / N;  // bound the workspace: ~24k token rows per chunk
@@ -635,7 +648,7 @@ extern "C" int must3r_hip_decode(must3r_hip_ctx* c, const must3r_hip_decode_args
     if (A->n_groups <= 0) return fail("decode: no input group");
     if (A->render && (A->first_call || A->n_mem <= 0)) return fail("decode: render needs a memory (decoder.py:278)");
     if (A->first_call && A->n_mem != 0) return fail("decode: first_call with a non-empty memory");
-    HIP_OK(hipSetDevice(c->device));
+    DeviceGuard dev_guard(c->device);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const DType dt = adt == MUST3R_F16_W2 ? DT_F16 : (DType)adt;
     const bool a8 = c->attn8 != 0;

@@ -35,7 +35,8 @@ def postprocess(pointmaps, pointmaps_activation=ActivationType.NORM_EXP, compute
     stream = torch.cuda.current_stream(pm.device).cuda_stream
     out = {"pts3d": p3, "pts3d_local": pl, "conf": cf}
     if not compute_cam:
-        _lib.check(lib.must3r_hip_postprocess(pm.data_ptr(), p3.data_ptr(), pl.data_ptr(), cf.data_ptr(), npix, stream))
+        with torch.cuda.device(pm.device):   # launch from the tensor's device whatever the caller's current device is
+            _lib.check(lib.must3r_hip_postprocess(pm.data_ptr(), p3.data_ptr(), pl.data_ptr(), cf.data_ptr(), npix, stream))
         return out
     if pm.dim() < 3:
         raise ValueError("compute_cam needs pointmaps of shape [..., H, W, 7]")

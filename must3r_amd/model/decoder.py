@@ -211,6 +211,23 @@ class MUSt3R(HipModule):
 
     def _forward_scene(self, xs, poss, shapes, current_mem, render, return_feats):
         """One scene (B = 1): the native decode call.  Returns (memory, [pointmaps per group], [feats per group] | None)."""
+        # The per-call view tables travel through a 64 KiB pinned slot (48 B per view: 1365 views).  The reference renders every
+        # view of an aspect ratio in ONE call when the caller sets no max_bs (engine/inference.py:489-522), so a large collection
+        # is cut here: rendered views are independent of each other, the chunks give the same pointmaps.
+        MAXV = 1024
+        if render and sum(int(x.shape[1]) for x in xs) > MAXV:
+            outs, feats = [], []
+            for xi, pi, ti in zip(xs, poss, shapes):
+                pms, fts = [], []
+                tsi = ti.reshape(1, -1, 2)
+                for a in range(0, int(xi.shape[1]), MAXV):
+                    _, o, f = self._forward_scene([xi[:, a:a + MAXV]], [pi[:, a:a + MAXV]], [tsi[:, a:a + MAXV]], current_mem, True,
+                                                  return_feats)
+                    pms.append(o[0])
+                    fts.append(f[0] if f is not None else None)
+                outs.append(torch.cat(pms, dim=1))
+                feats.append([torch.cat([f[l] for f in fts], dim=1) for l in range(len(fts[0]))] if return_feats else None)
+            return current_mem, outs, (feats if return_feats else None)
         ctx = self._context()
         dev = self._ctx_dev
         device = torch.device("cuda", dev)

@@ -13,7 +13,7 @@ agg = collections.defaultdict(lambda: collections.defaultdict(float))
 cnt = collections.Counter()
 for f in glob.glob("gpurun_out/pmc_attn/**/*counter_collection.csv", recursive=True):
     for row in csv.DictReader(open(f)):
-        if "attn_kernel" not in row["Kernel_Name"]: continue
+        if "attn3_kernel" not in row["Kernel_Name"]: continue
         key = (row["Grid_Size"] if "Grid_Size" in row else "")
         agg[key][row["Counter_Name"]] += float(row["Counter_Value"])
         cnt[(key, row["Counter_Name"])] += 1

@@ -479,3 +479,26 @@ def test_feedback_types_vs_oracle(fb):
     errs = [rel_inf(pm.cpu(), pmo), rel_inf(pm2.cpu(), pmo2), rel_inf(ren.cpu(), reno)]
     record("feedback_types", fb=str(fb), errs=errs)
     assert max(errs) < TOL["fp16w2"], errs
+
+
+def test_render_of_more_views_than_one_view_table_holds():
+    """The reference renders every view of an aspect ratio in ONE decoder call when no max_bs is given (engine/inference.py:489-522).
+    The native call's view tables hold 1365 views; larger calls are cut into chunks of 1024 by the module (rendered views are
+    independent).  2100 views of 48x64 against a 3-view memory: same pointmaps as rendering sampled views alone, and the current
+    device of the caller is left alone by the native entry points."""
+    enc, dec = build(TINY, "fp16w2")
+    imgs, ts = S.make_images(3, 48, 64, 5)
+    x, pos = enc(imgs.cuda(), ts.cuda())
+    mem, _ = dec(x.unsqueeze(0), pos.unsqueeze(0), ts.unsqueeze(0), None)
+    V = 2100
+    g = torch.Generator(device="cuda").manual_seed(1)
+    xs = x[torch.randint(0, 3, (V,), device="cuda", generator=g)] + 0.05 * torch.randn((V,) + tuple(x.shape[1:]), device="cuda", generator=g)
+    ps = pos[:1].expand(V, -1, -1).contiguous()
+    tsv = ts[:1].expand(V, -1).contiguous()
+    dev_before = torch.cuda.current_device()
+    mem_r, ren = dec(xs.unsqueeze(0), ps.unsqueeze(0), tsv.unsqueeze(0), mem, render=True)
+    assert torch.cuda.current_device() == dev_before
+    assert ren.shape == (1, V, 48, 64, 7) and mem_r is mem and torch.isfinite(ren).all()
+    for v in (0, 1023, 1024, 2047, 2048, V - 1):
+        _, one = dec(xs[v:v + 1].unsqueeze(0), ps[v:v + 1].unsqueeze(0), tsv[v:v + 1].unsqueeze(0), mem, render=True)
+        assert rel_inf(one[0, 0].cpu(), ren[0, v].cpu()) < 0.5 * TOL["fp16w2"], v
