@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MUST3R_HIP_ABI_VERSION 2
+#define MUST3R_HIP_ABI_VERSION 3
 
 typedef struct must3r_hip_ctx must3r_hip_ctx;
 

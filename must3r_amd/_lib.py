@@ -15,7 +15,7 @@ ATTN_FP8 = 0x100   # OR-able: fp8 (e4m3) attention operands, include/must3r_hip.
 MEM_KV, MEM_NORM_Y, MEM_RAW = 0, 1, 2
 PART_ENCODER, PART_DECODER = 1, 2
 EPI_STORE16, EPI_STORE16_GELU, EPI_QKV_ROPE, EPI_RESID_F32, EPI_F32, EPI_HEAD = range(6)
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 # every symbol include/must3r_hip.h declares
 EXPORTS = (
