@@ -119,6 +119,25 @@ __device__ __forceinline__ float quad_row_max(float x) {
     return fmaxf(__uint_as_float(q[0]), __uint_as_float(q[1]));
 }
 
+// sum over the 64 lanes without LDS round trips: four DPP row rotations (every lane of a 16-lane row ends with the row sum), then the
+// two cross-row swaps of quad_row_max.  ~8 VALU instructions against six ds_bpermute round trips (~100+ cycles each) of the
+// __shfl_xor form below; the one-row-per-wave LayerNorm of the memory update is latency-bound, so this is wall time there.
+template <int CTRL> __device__ __forceinline__ float dpp_mov(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+    v += dpp_mov<0x128>(v);   // row_ror:8
+    v += dpp_mov<0x124>(v);   // row_ror:4
+    v += dpp_mov<0x122>(v);   // row_ror:2
+    v += dpp_mov<0x121>(v);   // row_ror:1
+    unsigned u = __float_as_uint(v);
+    auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    u = __float_as_uint(v);
+    auto q = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return __uint_as_float(q[0]) + __uint_as_float(q[1]);
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

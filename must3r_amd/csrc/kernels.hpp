@@ -108,6 +108,8 @@ struct LnArgs {
     const float* w; const float* b;
     void* out16;         // optional 16-bit [M,C]
     void* out16_lo;      // optional 16-bit residual part: T(y - float(T(y)))  (split-precision head GEMM)
+    void* out16_dup;     // optional second copy of out16 (the head GEMM reads [y_hi | y_lo | y_hi] as one K = 3C operand)
+    int ld16;            // row stride (elements) of out16 / out16_lo / out16_dup; 0 = C
     float* out32;        // optional fp32 [M,C]
     float* copy32;       // optional raw copy of x (+add) (memorised layer input, decoder.py:304-305)
     int M, C;

@@ -46,7 +46,7 @@ __global__ void __launch_bounds__(256) ln_kernel(const LnArgs p) {
             s += v[i][0] + v[i][1] + v[i][2] + v[i][3];
         }
     }
-    const float mean = wave_sum(s) / (float)p.C;
+    const float mean = wave_sum_dpp(s) / (float)p.C;
     float q = 0.f;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -56,7 +56,7 @@ __global__ void __launch_bounds__(256) ln_kernel(const LnArgs p) {
             q += v[i][0] * v[i][0] + v[i][1] * v[i][1] + v[i][2] * v[i][2] + v[i][3] * v[i][3];
         }
     }
-    const float rstd = rsqrtf(wave_sum(q) / (float)p.C + p.eps);
+    const float rstd = rsqrtf(wave_sum_dpp(q) / (float)p.C + p.eps);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int c = (i * 64 + lane) * 4;
@@ -66,11 +66,13 @@ __global__ void __launch_bounds__(256) ln_kernel(const LnArgs p) {
             const f32x4 y = v[i] * rstd * w + b;
             if (p.out32) *reinterpret_cast<f32x4*>(p.out32 + (size_t)row * p.C + c) = y;
             if (p.out16) {
+                const size_t ld = p.ld16 ? (size_t)p.ld16 : (size_t)p.C;
                 const v4 h = cvt4<T>(y);
-                *reinterpret_cast<v4*>(reinterpret_cast<T*>(p.out16) + (size_t)row * p.C + c) = h;
+                *reinterpret_cast<v4*>(reinterpret_cast<T*>(p.out16) + row * ld + c) = h;
+                if (p.out16_dup) *reinterpret_cast<v4*>(reinterpret_cast<T*>(p.out16_dup) + row * ld + c) = h;
                 if (p.out16_lo) {
                     const f32x4 hf = __builtin_convertvector(h, f32x4);
-                    *reinterpret_cast<v4*>(reinterpret_cast<T*>(p.out16_lo) + (size_t)row * p.C + c) = cvt4<T>(y - hf);
+                    *reinterpret_cast<v4*>(reinterpret_cast<T*>(p.out16_lo) + row * ld + c) = cvt4<T>(y - hf);
                 }
             }
         }

@@ -51,6 +51,7 @@ struct Param {
     void* h16[2] = {nullptr, nullptr};   // packed 16-bit copy per dtype (lazy)
     void* l16[2] = {nullptr, nullptr};   // low part (split precision), lazy, only where needed
     void* x2[2] = {nullptr, nullptr};    // [rows][hi(K) | lo(K)] layout for the split-weight GEMM, lazy
+    void* x3[2] = {nullptr, nullptr};    // [rows][hi | hi | lo] layout: one K = 3 in launch of the split-precision head, lazy
     bool loaded = false;
     bool derived = false;     // built by finalize, not loaded
     bool optional = false;    // may legitimately be absent (feedback layer variants)
@@ -339,6 +340,24 @@ static int w16(must3r_hip_ctx* c, const std::string& name, DType dt, const void*
     return 0;
 }
 
+// [W_hi | W_hi | W_lo] rows: with the activation laid out as [y_hi | y_lo | y_hi] the three products of the split-precision head
+// (y_hi W_hi + y_lo W_hi + y_hi W_lo) are ONE plain GEMM over K = 3 in
+static int w3(must3r_hip_ctx* c, const std::string& name, DType dt, const void** out, hipStream_t s) {
+    Param& p = c->params.at(name);
+    if (!p.x3[dt]) {
+        const void *h, *l;
+        M3R_OK(p16(c, name, dt, true, &h, &l, s));
+        const size_t rows = (size_t)p.shape[0], K = p.n / rows;
+        HIP_OK(hipMalloc(&p.x3[dt], p.n * 6));
+        char* d = reinterpret_cast<char*>(p.x3[dt]);
+        HIP_OK(hipMemcpy2DAsync(d, K * 6, h, K * 2, K * 2, rows, hipMemcpyDeviceToDevice, s));
+        HIP_OK(hipMemcpy2DAsync(d + K * 2, K * 6, h, K * 2, K * 2, rows, hipMemcpyDeviceToDevice, s));
+        HIP_OK(hipMemcpy2DAsync(d + K * 4, K * 6, l, K * 2, K * 2, rows, hipMemcpyDeviceToDevice, s));
+    }
+    *out = p.x3[dt];
+    return 0;
+}
+
 extern "C" int must3r_hip_rope_table(float freq, float f0, int npos, float* out) {
     // angle(p, i) = p * f0 * freq^(-i/16), i in [0,16)  (croco RoPE2D, head dim 64)
     for (int p = 0; p < npos; ++p)
@@ -401,6 +420,7 @@ extern "C" void must3r_hip_destroy(must3r_hip_ctx* c) {
             if (p.h16[i]) (void)hipFree(p.h16[i]);
             if (p.l16[i]) (void)hipFree(p.l16[i]);
             if (p.x2[i]) (void)hipFree(p.x2[i]);
+            if (p.x3[i]) (void)hipFree(p.x3[i]);
         }
     }
     if (c->rope_tab) (void)hipFree(c->rope_tab);
@@ -428,6 +448,7 @@ extern "C" int must3r_hip_load_weight(must3r_hip_ctx* c, const char* name, const
         if (p->h16[i]) { (void)hipFree(p->h16[i]); p->h16[i] = nullptr; }
         if (p->l16[i]) { (void)hipFree(p->l16[i]); p->l16[i] = nullptr; }
         if (p->x2[i]) { (void)hipFree(p->x2[i]); p->x2[i] = nullptr; }
+        if (p->x3[i]) { (void)hipFree(p->x3[i]); p->x3[i] = nullptr; }
     }
     p->loaded = true;
     if (strncmp(name, "encoder.", 8) == 0) c->fin_enc = false; else c->fin_dec = false;
@@ -441,6 +462,7 @@ static int derive(must3r_hip_ctx* c, const std::string& name, std::vector<int64_
         if (p.h16[i]) { (void)hipFree(p.h16[i]); p.h16[i] = nullptr; }
         if (p.l16[i]) { (void)hipFree(p.l16[i]); p.l16[i] = nullptr; }
         if (p.x2[i]) { (void)hipFree(p.x2[i]); p.x2[i] = nullptr; }
+        if (p.x3[i]) { (void)hipFree(p.x3[i]); p.x3[i] = nullptr; }
     }
     p.shape = shape;
     p.n = host.size();
@@ -683,7 +705,7 @@ extern "C" int must3r_hip_decode(must3r_hip_ctx* c, const must3r_hip_decode_args
     need = ws_need(need, (size_t)R * C, 2);           // t16
     need = ws_need(need, (size_t)R * D, 4);           // x
     need = ws_need(need, (size_t)R * D, 2);           // h16
-    need = ws_need(need, (size_t)R * D, 2);           // hlo (head split)
+    need = ws_need(need, (size_t)R * 3 * D, 2);       // [y_hi | y_lo | y_hi] operand of the head
     need = ws_need(need, (size_t)R * 3 * D, 2);       // qkv
     need = ws_need(need, (size_t)R * D, 2);           // q16
     need = ws_need(need, (size_t)R * D, 2);           // a16
@@ -697,7 +719,9 @@ extern "C" int must3r_hip_decode(must3r_hip_ctx* c, const must3r_hip_decode_args
     // block per CU instead of 256 blocks of 48 x 48 over the whole K) that leaves fp32 partial slabs; the residual update
     // x += b + slabs is done by the LayerNorm that reads x next (norm1 of the next block / norm_dec), in a fixed order.
     const int KS = 4;
-    static const bool fc2_splitk_on = !(getenv("M3R_FC2_SPLITK") && atoi(getenv("M3R_FC2_SPLITK")) == 0);
+    // Measured in the scene (r02, same box, interleaved): the GEMM class loses 0.9 ms and the LayerNorm class gains 0.9 ms (the four
+    // 2.4 MB slabs per launch) -- a wash, so the route is OFF by default (M3R_FC2_SPLITK=1 enables it; operator-level tests cover it).
+    static const bool fc2_splitk_on = getenv("M3R_FC2_SPLITK") && atoi(getenv("M3R_FC2_SPLITK")) != 0;
     const bool fc2_splitk = fc2_splitk_on && c->wsplit == 2 && dt == DT_F16 && !need_pre_kv && !A->feats && D % 96 == 0 &&
                             (F / 64) % KS == 0 && (long)((R + 95) / 96) * (D / 96) * KS <= 256;
     need = ws_need(need, fc2_splitk ? (size_t)KS * R * D : 0, 4);   // slabs
@@ -724,7 +748,7 @@ extern "C" int must3r_hip_decode(must3r_hip_ctx* c, const must3r_hip_decode_args
     uint16_t* t16 = ws_take<uint16_t>(c, (size_t)R * C);
     float* x = ws_take<float>(c, (size_t)R * D);
     uint16_t* h16 = ws_take<uint16_t>(c, (size_t)R * D);
-    uint16_t* hlo = ws_take<uint16_t>(c, (size_t)R * D);
+    uint16_t* hcat = ws_take<uint16_t>(c, (size_t)R * 3 * D);
     uint16_t* qkv = ws_take<uint16_t>(c, (size_t)R * 3 * D);
     uint16_t* q16 = ws_take<uint16_t>(c, (size_t)R * D);
     uint16_t* a16 = ws_take<uint16_t>(c, (size_t)R * D);
@@ -966,22 +990,21 @@ extern "C" int must3r_hip_decode(must3r_hip_ctx* c, const must3r_hip_decode_args
 
     // --- prediction head in split precision (fp32-equivalent; decoder.py:149-156 runs it in fp32):
     //     y = LN(x); out = y_hi W_hi + y_lo W_hi + y_hi W_lo + b, pixel-shuffled to [n,H,W,7]
-    M3R_OK(layernorm_a(c, dt, with_slabs(lnargs(x, nullptr, p32(c, "decoder.norm_dec.weight"), p32(c, "decoder.norm_dec.bias"), h16, hlo,
-                                               A->feats ? A->feats + (size_t)(L - 1) * R * D : nullptr, nullptr, R, D, 1e-6f)), s));
-    const void *whi, *wlo;
-    M3R_OK(p16(c, "decoder.head_dec.proj_ps.weight", dt, true, &whi, &wlo, s));
+    {
+        LnArgs la = with_slabs(lnargs(x, nullptr, p32(c, "decoder.norm_dec.weight"), p32(c, "decoder.norm_dec.bias"), hcat, hcat + D,
+                                      A->feats ? A->feats + (size_t)(L - 1) * R * D : nullptr, nullptr, R, D, 1e-6f));
+        la.out16_dup = hcat + 2 * D;
+        la.ld16 = 3 * D;
+        M3R_OK(layernorm_a(c, dt, la, s));
+    }
+    const void* wcat;
+    M3R_OK(w3(c, "decoder.head_dec.proj_ps.weight", dt, &wcat, s));
     for (int gi = 0; gi < A->n_groups; ++gi) {
         const must3r_hip_group& G = A->groups[gi];
         const int Rg = G.n_views * G.n_tokens;
-        const uint16_t* yh = h16 + (size_t)grow0[gi] * D;
-        const uint16_t* yl = hlo + (size_t)grow0[gi] * D;
-        for (int pass = 0; pass < 3; ++pass) {
-            GemmArgs ga = gargs(pass == 1 ? yl : yh, pass == 2 ? wlo : whi, p32(c, "decoder.head_dec.proj_ps.bias"), G.pointmaps,
-                                Rg, OUT, D, D, 0);
-            ga.accumulate = pass > 0;
-            ga.ntok = G.n_tokens; ga.gw = G.W / 16; ga.H = G.H; ga.Wimg = G.W;
-            M3R_OK(gemm(c, dt, EPI_HEAD, ga, s));
-        }
+        GemmArgs ga = gargs(hcat + (size_t)grow0[gi] * 3 * D, wcat, p32(c, "decoder.head_dec.proj_ps.bias"), G.pointmaps, Rg, OUT, 3 * D, 3 * D, 0);
+        ga.ntok = G.n_tokens; ga.gw = G.W / 16; ga.H = G.H; ga.Wimg = G.W;
+        M3R_OK(gemm(c, dt, EPI_HEAD, ga, s));
     }
     return 0;
 }

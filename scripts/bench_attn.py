@@ -35,6 +35,9 @@ cases = [make("render CA 20v nk15360", 12, 20, 768, 15360, False), make("enc SA 
          make("update SA 1v n768", 12, 1, 768, 768, True), make("render CA 20v nk1960 (224)", 12, 10, 196, 1960, False),
          make("update CA 1v nk7680 s10", 12, 1, 768, 7680, False, 10), make("update CA 1v nk7680 s14", 12, 1, 768, 7680, False, 14),
          make("update CA 1v nk14592 s14", 12, 1, 768, 14592, False, 14), make("render CA 20v nk15360 s2", 12, 20, 768, 15360, False, 2)]
+if os.environ.get("FIXED_COST"):   # fixed cost of a split launch: 1, 2, 6, 12 tiles per block at s = 10
+    cases = [make(f"update CA nk{nk} s10", 12, 1, 768, nk, False, 10) for nk in (640, 1280, 3840, 7680, 15360)] + \
+            [make(f"update CA nk{nk} s1", 12, 1, 768, nk, False, 0) for nk in (64, 640)]
 for name, go, fl, _ in cases:
     go()
 torch.cuda.synchronize()
