@@ -938,6 +938,30 @@ extern "C" int must3r_hip_decode(must3r_hip_ctx* c, const must3r_hip_decode_args
             HIP_OK(hipMemcpyAsync(A->feats + (size_t)l * R * D, x, (size_t)R * D * sizeof(float), hipMemcpyDeviceToDevice, s));
     }
 
+    // (Measured and rejected in r02: forking this head onto a second stream so that it overlaps the feedback / memory-write chain that ends
+    // an update call -- the two chains are independent -- costs 2.5 ms per scene instead of saving 0.5: the head's blocks take CUs from
+    // the latency-critical chain.  273 vs 282 views/s, interleaved runs on one box.)
+    hipStream_t hs_ = s;
+    {
+    // --- prediction head in split precision (fp32-equivalent; decoder.py:149-156 runs it in fp32):
+        //     y = LN(x); out = y_hi W_hi + y_lo W_hi + y_hi W_lo + b, pixel-shuffled to [n,H,W,7]
+        {
+            LnArgs la = with_slabs(lnargs(x, nullptr, p32(c, "decoder.norm_dec.weight"), p32(c, "decoder.norm_dec.bias"), hcat, hcat + D,
+                                          A->feats ? A->feats + (size_t)(L - 1) * R * D : nullptr, nullptr, R, D, 1e-6f));
+            la.out16_dup = hcat + 2 * D;
+            la.ld16 = 3 * D;
+            M3R_OK(layernorm_a(c, dt, la, hs_));
+        }
+        const void* wcat;
+        M3R_OK(w3(c, "decoder.head_dec.proj_ps.weight", dt, &wcat, hs_));
+        for (int gi = 0; gi < A->n_groups; ++gi) {
+            const must3r_hip_group& G = A->groups[gi];
+            const int Rg = G.n_views * G.n_tokens;
+            GemmArgs ga = gargs(hcat + (size_t)grow0[gi] * 3 * D, wcat, p32(c, "decoder.head_dec.proj_ps.bias"), G.pointmaps, Rg, OUT, 3 * D, 3 * D, 0);
+            ga.ntok = G.n_tokens; ga.gw = G.W / 16; ga.H = G.H; ga.Wimg = G.W;
+            M3R_OK(gemm(c, dt, EPI_HEAD, ga, hs_));
+        }
+    }
     if (update) {
         // --- feedback (feedback_mechanism.py:39-53): offset = layer(LN_1e-5(new_mem[L-1])), added to layers 0..L-2;
         //     layer = Mlp ('single_mlp'), Linear ('single_linear') or nothing (feedback_type None: no offset)
@@ -988,24 +1012,6 @@ extern "C" int must3r_hip_decode(must3r_hip_ctx* c, const must3r_hip_decode_args
         }
     }
 
-    // --- prediction head in split precision (fp32-equivalent; decoder.py:149-156 runs it in fp32):
-    //     y = LN(x); out = y_hi W_hi + y_lo W_hi + y_hi W_lo + b, pixel-shuffled to [n,H,W,7]
-    {
-        LnArgs la = with_slabs(lnargs(x, nullptr, p32(c, "decoder.norm_dec.weight"), p32(c, "decoder.norm_dec.bias"), hcat, hcat + D,
-                                      A->feats ? A->feats + (size_t)(L - 1) * R * D : nullptr, nullptr, R, D, 1e-6f));
-        la.out16_dup = hcat + 2 * D;
-        la.ld16 = 3 * D;
-        M3R_OK(layernorm_a(c, dt, la, s));
-    }
-    const void* wcat;
-    M3R_OK(w3(c, "decoder.head_dec.proj_ps.weight", dt, &wcat, s));
-    for (int gi = 0; gi < A->n_groups; ++gi) {
-        const must3r_hip_group& G = A->groups[gi];
-        const int Rg = G.n_views * G.n_tokens;
-        GemmArgs ga = gargs(hcat + (size_t)grow0[gi] * 3 * D, wcat, p32(c, "decoder.head_dec.proj_ps.bias"), G.pointmaps, Rg, OUT, 3 * D, 3 * D, 0);
-        ga.ntok = G.n_tokens; ga.gw = G.W / 16; ga.H = G.H; ga.Wimg = G.W;
-        M3R_OK(gemm(c, dt, EPI_HEAD, ga, s));
-    }
     return 0;
 }
 
