@@ -403,12 +403,14 @@ static int launch_cfg(const GemmArgs& a, hipStream_t s) {
 //        in (#2t, #2t+1), group 1 in (#2t+1, #2t+2).
 // The accumulation order per output (k ascending, hi before lo inside each 32-deep step) is the same as in gemm_kernel,
 // so the two kernels produce identical bits.
-template <class T, int EPI, int WS, int BN>
-__global__ void __launch_bounds__(512) gemm256_kernel(const GemmArgs p) {
+// OCC = 2 (experiment, split BN = 128 only): a 2-slot ring (64 KB) and at most 128 VGPRs, so that TWO blocks share a CU -- one block's
+// epilogue / prologue then runs under the other's K loop, and 16 waves per CU overlap the three pipes better (profiles/r02_pipe_rates.txt).
+template <class T, int EPI, int WS, int BN, int OCC = 1>
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(OCC == 2 ? 4 : 2, OCC == 2 ? 4 : 2))) gemm256_kernel(const GemmArgs p) {
     typedef typename Vec<T>::v8 v8;
     constexpr int BM = 256, BK = 32;
     constexpr int WR = WS * BN;                // rows of the staged weight region: [hi BN rows | lo BN rows] when split
-    constexpr int NST = WR >= 384 ? 3 : 4;     // 48 / 40 KB stages x 3 (split, BN 256 / 192) or 32 KB stages x 4
+    constexpr int NST = OCC == 2 ? 2 : (WR >= 384 ? 3 : 4);     // 48 / 40 KB stages x 3 (split, BN 256 / 192) or 32 KB stages x 4
     constexpr int WN = BN / 4;                 // wave tile: 128 (m) x WN (n)
     constexpr int MF = 8, NF = WN / 16;        // 16x16 fragments per wave tile
     constexpr int PW = WR / 128;               // weight DMA instructions per wave and K-tile (A: 2)
@@ -499,7 +501,7 @@ __global__ void __launch_bounds__(512) gemm256_kernel(const GemmArgs p) {
     auto wait_tile = [&](int u) {
         const int younger = nk - 1 - u;
         if (NST >= 4 && younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * IPT) : "memory");
-        else if (younger >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(IPT) : "memory");
+        else if (NST >= 3 && younger >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(IPT) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     };
 
@@ -555,16 +557,16 @@ __global__ void __launch_bounds__(512) gemm256_kernel(const GemmArgs p) {
     }
 }
 
-template <class T, int EPI, int WS, int BN>
+template <class T, int EPI, int WS, int BN, int OCC = 1>
 static int launch_256(const GemmArgs& a, hipStream_t s) {
     const int nbn = a.N / BN, nbm = (a.M + 255) / 256;
-    const size_t lds = (size_t)(WS * BN >= 384 ? 3 : 4) * (256 + WS * BN) * 32 * sizeof(T);
+    const size_t lds = (size_t)(OCC == 2 ? 2 : (WS * BN >= 384 ? 3 : 4)) * (256 + WS * BN) * 32 * sizeof(T);
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256_kernel<T, EPI, WS, BN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256_kernel<T, EPI, WS, BN, OCC>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm256_kernel<T, EPI, WS, BN>), dim3(nbm * nbn, a.batch > 1 ? a.batch : 1), dim3(512), lds, s, a);
+    hipLaunchKernelGGL((gemm256_kernel<T, EPI, WS, BN, OCC>), dim3(nbm * nbn, a.batch > 1 ? a.batch : 1), dim3(512), lds, s, a);
     return hipGetLastError() == hipSuccess ? 0 : 1;
 }
 
@@ -1049,11 +1051,19 @@ static int launch_epi(const GemmArgs& a, hipStream_t s, const char** err) {
                     if (best < 0 || cost < best) { best = cost; pick = bns[i]; }
                 }
             }
-            if (EPI != EPI_HEAD && use_96(a, nb)) rc = launch_96<T, EPI == EPI_HEAD ? EPI_STORE16 : EPI>(a, s);
+            // fc1 (exact-erf GELU epilogue, ~17 VALU per output) of the chip-filling batches: two 256 x 128 blocks per CU, so that one block's
+            // epilogue runs under the other's K loop.  Measured (r02, M = 15360): N = 3072, K = 768: 157 -> 143 us; N = 4096, K = 1024: 270 -> 265 us;
+            // every other epilogue is faster with one block per CU and the deeper ring (qkv 186 vs 199-209 us, fc2 210 vs 228 us).
+            static const bool gelu_occ2 = !(getenv("M3R_G256_GELU_OCC2") && atoi(getenv("M3R_G256_GELU_OCC2")) == 0);
+            if (EPI == EPI_STORE16_GELU && gelu_occ2 && mode != 0 && ok128 && t128 >= 1024) rc = launch_256<T, EPI, 2, 128, 2>(a, s);
+            else if (EPI != EPI_HEAD && use_96(a, nb)) rc = launch_96<T, EPI == EPI_HEAD ? EPI_STORE16 : EPI>(a, s);
             else if (EPI != EPI_QKV_ROPE && EPI != EPI_HEAD && use_48(a, nb)) rc = launch_48<T, EPI == EPI_QKV_ROPE || EPI == EPI_HEAD ? EPI_STORE16 : EPI, 2>(a, s);
             else if (pick == 256) rc = launch_256<T, EPI, 2, 256>(a, s);
             else if (pick == 192) rc = launch_256<T, EPI == EPI_QKV_ROPE ? EPI_STORE16 : EPI, 2, 192>(a, s);
-            else if (pick == 128) rc = launch_256<T, EPI, 2, 128>(a, s);
+            else if (pick == 128) {
+                static const bool occ2 = getenv("M3R_G256_OCC2") && atoi(getenv("M3R_G256_OCC2")) != 0;   // experiments: every 128-column launch
+                rc = occ2 ? launch_256<T, EPI, 2, 128, 2>(a, s) : launch_256<T, EPI, 2, 128>(a, s);
+            }
             else if (tiles >= min_big(true)) rc = launch_cfg<T, 128, 64, 2, 2, EPI, 2, 2>(a, s);
             else if (small8((long)((a.M + 63) / 64) * (a.N / 64) * nb)) rc = launch_cfg<T, 64, 64, SMALL_WGM, 2, EPI, SMALL8_NST_SPLIT, 2, 64, 1>(a, s);
             else rc = launch_cfg<T, 64, 64, 2, 2, EPI, 3, 2>(a, s);
