@@ -73,7 +73,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) a
     int grp, split, qb;
     if (!attn_block_coords(nqb, ngrp, nsplit, grp, split, qb)) return;
     const int view = grp / p.heads, head = grp - view * p.heads;
-    const AttnView vw = p.views[view];
+    const AttnView vw = p.view0_inline ? p.view0 : p.views[view];
     if (qb * QB >= vw.nq) return;
 
     const T* __restrict__ Q = reinterpret_cast<const T*>(p.Q);
@@ -404,7 +404,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) a
     int grp, split, qb;
     if (!attn_block_coords(nqb, ngrp, nsplit, grp, split, qb)) return;
     const int view = grp / p.heads, head = grp - view * p.heads;
-    const AttnView vw = p.views[view];
+    const AttnView vw = p.view0_inline ? p.view0 : p.views[view];
     if (qb * QB >= vw.nq) return;
 
     const E* __restrict__ Q = reinterpret_cast<const E*>(p.Q);
@@ -764,7 +764,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(QW == 
     int grp, split, qb;
     if (!attn_block_coords(nqb, ngrp, nsplit, grp, split, qb)) return;
     const int view = grp / p.heads, head = grp - view * p.heads;
-    const AttnView vw = p.views[view];
+    const AttnView vw = p.view0_inline ? p.view0 : p.views[view];
     if (qb * QB >= vw.nq) return;
 
     const T* __restrict__ Q = reinterpret_cast<const T*>(p.Q);

@@ -25,15 +25,38 @@ __device__ unsigned long long g_gemm_trace[64 * 8];   // scripts/probes/gemm_tra
 
 // One output row segment of a lane: v[j][r] = C[m][n = nw0 + j*16 + fg*4 + r] before bias; nw0 = first column of the wave tile.
 // Shared by every tile geometry so that all of them round identically (built with -ffp-contract=off).
+// The small-M kernels load the bias fragments (and, for the residual epilogue, the old x values) BEFORE their K loop: after the loop
+// they would be one or two dependent L2 round trips (~0.5-1 us) at the end of a 7-14 us launch.
+template <int NF> struct EpiPre {
+    f32x4 b[NF];   // bias columns of this lane (zero when the epilogue adds none)
+    f32x4 x[NF];   // old residual values (EPI_RESID_F32 only)
+};
+template <class T, int EPI, int NF>
+__device__ __forceinline__ void epilogue_prefetch(const GemmArgs& p, void* const outp, const float* __restrict__ bias, const int m,
+                                                  const int nw0, const int fg, EpiPre<NF>& pre) {
+    const int nb = nw0 + fg * 4;
+    const bool nobias = (EPI == EPI_F32 || EPI == EPI_HEAD) && p.accumulate;
+#pragma unroll
+    for (int j = 0; j < NF; ++j) {
+        pre.b[j] = (bias != nullptr && !nobias) ? *reinterpret_cast<const f32x4*>(bias + nb + j * 16) : f32x4{0.f, 0.f, 0.f, 0.f};
+        if constexpr (EPI == EPI_RESID_F32) {
+            const int mm = m < p.M ? m : p.M - 1;
+            pre.x[j] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(outp) + (size_t)mm * p.ldc + nb + j * 16);
+        }
+    }
+}
+
 template <class T, int EPI, int NF>
 __device__ __forceinline__ void epilogue_row(const GemmArgs& p, void* const outp, const float* __restrict__ bias, const int m,
-                                             const int nw0, const int fg, f32x4 (&v)[NF]) {
+                                             const int nw0, const int fg, f32x4 (&v)[NF], const EpiPre<NF>* pre = nullptr) {
     typedef typename Vec<T>::v4 v4;
     const int nb = nw0 + fg * 4;
 #pragma unroll
     for (int j = 0; j < NF; ++j) {
         const bool nobias = (EPI == EPI_F32 || EPI == EPI_HEAD) && p.accumulate;
-        if (bias != nullptr && !nobias) {
+        if (pre != nullptr) {
+            v[j] += pre->b[j];
+        } else if (bias != nullptr && !nobias) {
             const f32x4 b = *reinterpret_cast<const f32x4*>(bias + nb + j * 16);
             v[j] += b;
         }
@@ -81,7 +104,7 @@ __device__ __forceinline__ void epilogue_row(const GemmArgs& p, void* const outp
             *reinterpret_cast<v4*>(reinterpret_cast<T*>(outp) + (size_t)m * p.ldc + n) = cvt4_sat<T>(g);
         } else if constexpr (EPI == EPI_RESID_F32) {
             f32x4* o = reinterpret_cast<f32x4*>(reinterpret_cast<float*>(outp) + (size_t)m * p.ldc + n);
-            *o = *o + v[j];
+            *o = (pre != nullptr ? pre->x[j] : *o) + v[j];
         } else if constexpr (EPI == EPI_F32) {
             f32x4* o = reinterpret_cast<f32x4*>(reinterpret_cast<float*>(outp) + (size_t)m * p.ldc + n);
             f32x4 x = v[j];
@@ -639,6 +662,8 @@ __global__ void __launch_bounds__(576) gemm48_kernel(const GemmArgs p) {
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     const int fr = lane & 15, fg = lane >> 4;
     const int nk = p.K / BK;
+    EpiPre<1> pre;
+    epilogue_prefetch<T, EPI, 1>(p, outp, bias, m0 + wm * 16 + fr, n0 + wn * 16, fg, pre);
     int a_off[2], w_off[2][WS];
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
@@ -682,7 +707,7 @@ __global__ void __launch_bounds__(576) gemm48_kernel(const GemmArgs p) {
     const int m = m0 + wm * 16 + fr;
     if (m < p.M) {
         f32x4 v[1] = {acc};
-        epilogue_row<T, EPI, 1>(p, outp, bias, m, n0 + wn * 16, fg, v);
+        epilogue_row<T, EPI, 1>(p, outp, bias, m, n0 + wn * 16, fg, v, &pre);
     }
 }
 
@@ -774,6 +799,9 @@ __global__ void __launch_bounds__(576) gemm96_kernel(const GemmArgs p) {
 #pragma unroll
         for (int j = 0; j < NF; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int fr = lane & 15, fg = lane >> 4;
+    EpiPre<NF> pre[MF];
+#pragma unroll
+    for (int i = 0; i < MF; ++i) epilogue_prefetch<T, EPI, NF>(p, outp, bias, m0 + wm * 32 + i * 16 + fr, n0 + wn * 32, fg, pre[i]);
     int a_off[2][MF], w_off[2][WS][NF];
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
@@ -911,7 +939,7 @@ __global__ void __launch_bounds__(576) gemm96_kernel(const GemmArgs p) {
         f32x4 v[NF];
 #pragma unroll
         for (int j = 0; j < NF; ++j) v[j] = acc[i][j];
-        epilogue_row<T, EPI, NF>(p, outp, bias, m, n0 + wn * 32, fg, v);
+        epilogue_row<T, EPI, NF>(p, outp, bias, m, n0 + wn * 32, fg, v, &pre[i]);
     }
 }
 

@@ -76,6 +76,10 @@ struct AttnArgs {
     int heads;
     const AttnView* views;                                    // device pointer
     int nviews;
+    // one-view launches (every attention of a one-view memory update): the view travels in the kernel arguments, which saves each block
+    // the dependent global load of its table row in front of the Q / K / V address arithmetic (~1 us of prologue latency per launch)
+    int view0_inline;                                         // 1: use view0 instead of views[0]
+    AttnView view0;
     int max_nq;                                               // max over views of nq
     float scale;                                              // 1/sqrt(64); ignored when q_prescaled
     int q_prescaled;                                          // Q already carries scale*log2(e)

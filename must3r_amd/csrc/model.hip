@@ -886,6 +886,7 @@ extern "C" int must3r_hip_decode(must3r_hip_ctx* c, const must3r_hip_decode_args
         aa.Q = qkv; aa.K = qkv + D; aa.V = qkv + 2 * D; aa.O = a16;
         aa.ldq = aa.ldk = aa.ldv = 3 * D; aa.ldo = D; aa.heads = Hh;
         aa.views = sa_views; aa.nviews = total_views; aa.max_nq = max_n; aa.scale = 0.125f; aa.q_prescaled = 1;
+        if (total_views == 1) { aa.view0_inline = 1; aa.view0 = tab[0]; }
         if (a8) {
             M3R_OK(quant8(c, dt, qkv, 3 * D, q8, 3 * D, nullptr, 0, (size_t)R, 3 * D, s));
             aa.Q = q8; aa.K = q8 + D; aa.V = q8 + 2 * D; aa.fp8 = 1;
@@ -912,6 +913,7 @@ extern "C" int must3r_hip_decode(must3r_hip_ctx* c, const must3r_hip_decode_args
             aa.Q = q8; aa.V = reinterpret_cast<const uint8_t*>(mk) + D; aa.fp8 = 1;
         }
         aa.views = ca_views; aa.nviews = total_views; aa.max_nq = max_n; aa.scale = 0.125f; aa.q_prescaled = 1;
+        if (total_views == 1) { aa.view0_inline = 1; aa.view0 = tab[total_views]; }
         if (ca_split > 1) {
             aa.nsplit = ca_split; aa.total_q_rows = R; aa.dense_rows = 1;
             aa.part_o = reinterpret_cast<float*>(split_ws);
