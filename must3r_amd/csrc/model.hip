@@ -64,11 +64,17 @@ struct ProfEntry { hipEvent_t a, b; int cat; double flops; };
 enum ProfCat { PC_GEMM128 = 0, PC_GEMM64, PC_ATTN_SA, PC_ATTN_CA, PC_ATTN_COMBINE, PC_LN, PC_MISC, PC_COUNT };
 static const char* kProfNames[PC_COUNT] = {"gemm128", "gemm64", "attn_self", "attn_cross", "attn_combine", "layernorm", "misc"};
 
+// parameters of one transformer block, resolved to Param* once per context
+enum LayerField { LF_N1W, LF_N1B, LF_QKVW, LF_QKVB, LF_PROJW, LF_PROJB, LF_N2W, LF_N2B, LF_FC1W, LF_FC1B, LF_FC2W, LF_FC2B, LF_NYW, LF_NYB, LF_PQW, LF_PQB, LF_PKVW, LF_PKVB, LF_CPW, LF_CPB, LF_N3W, LF_N3B, LF_COUNT };
+static const char* kLayerFieldNames[LF_COUNT] = {"norm1.weight", "norm1.bias", "attn.qkv.weight", "attn.qkv.bias", "attn.proj.weight", "attn.proj.bias", "norm2.weight", "norm2.bias", "mlp.fc1.weight", "mlp.fc1.bias", "mlp.fc2.weight", "mlp.fc2.bias", "norm_y.weight", "norm_y.bias", "cross_attn.projq.weight", "cross_attn.projq.bias", "cross_attn.projkv.weight", "cross_attn.projkv.bias", "cross_attn.proj.weight", "cross_attn.proj.bias", "norm3.weight", "norm3.bias"};
+
 struct must3r_hip_ctx {
     must3r_hip_config cfg;
     int device = 0;
     std::map<std::string, Param> params;
     bool fin_enc = false, fin_dec = false;
+    // per-layer parameter tables (resolved once: no string building / map lookups per launch); entries of absent parameters are null
+    std::vector<std::vector<struct Param*>> enc_tab, dec_tab;
     int wsplit = 0;            // 2 while a forward runs in MUST3R_F16_W2 mode
     int attn8 = 0;             // 1 while a forward runs with MUST3R_ATTN_FP8 (e4m3 attention operands)
     float* rope_tab = nullptr;
@@ -311,9 +317,18 @@ static Param* param(must3r_hip_ctx* c, const std::string& name) {
 static const float* p32(must3r_hip_ctx* c, const std::string& name) { return c->params.at(name).d; }
 
 // packed 16-bit copy (and optional low part) of a parameter, created on first use for a dtype
+static int p16p(must3r_hip_ctx* c, Param& p, DType dt, bool want_lo, const void** hi, const void** lo, hipStream_t s);
+static int w16p(must3r_hip_ctx* c, Param& p, DType dt, const void** hi, hipStream_t s);
 static int p16(must3r_hip_ctx* c, const std::string& name, DType dt, bool want_lo, const void** hi, const void** lo,
                hipStream_t s) {
-    Param& p = c->params.at(name);
+    return p16p(c, c->params.at(name), dt, want_lo, hi, lo, s);
+}
+static int w16(must3r_hip_ctx* c, const std::string& name, DType dt, const void** hi, hipStream_t s) {
+    return w16p(c, c->params.at(name), dt, hi, s);
+}
+
+// Param-based forms of p16 / w16 (the per-layer loops use the tables below instead of building the parameter name per launch)
+static int p16p(must3r_hip_ctx* c, Param& p, DType dt, bool want_lo, const void** hi, const void** lo, hipStream_t s) {
     const char* err = "";
     if (!p.h16[dt] || (want_lo && !p.l16[dt])) {
         if (!p.h16[dt]) HIP_OK(hipMalloc(&p.h16[dt], p.n * 2));
@@ -324,20 +339,31 @@ static int p16(must3r_hip_ctx* c, const std::string& name, DType dt, bool want_l
     if (lo) *lo = p.l16[dt];
     return 0;
 }
-static int w16(must3r_hip_ctx* c, const std::string& name, DType dt, const void** hi, hipStream_t s) {
-    if (c->wsplit != 2) return p16(c, name, dt, false, hi, nullptr, s);
-    // split-weight mode: rows of [W_hi | W_lo] so the GEMM's K loop simply runs twice as long
-    Param& p = c->params.at(name);
+static int w16p(must3r_hip_ctx* c, Param& p, DType dt, const void** hi, hipStream_t s) {
+    if (c->wsplit != 2) return p16p(c, p, dt, false, hi, nullptr, s);
     if (!p.x2[dt]) {
         const void *h, *l;
-        M3R_OK(p16(c, name, dt, true, &h, &l, s));
+        M3R_OK(p16p(c, p, dt, true, &h, &l, s));
         const size_t rows = (size_t)p.shape[0], K = p.n / rows;
         HIP_OK(hipMalloc(&p.x2[dt], p.n * 4));
         HIP_OK(hipMemcpy2DAsync(p.x2[dt], K * 4, h, K * 2, K * 2, rows, hipMemcpyDeviceToDevice, s));
         HIP_OK(hipMemcpy2DAsync(reinterpret_cast<char*>(p.x2[dt]) + K * 2, K * 4, l, K * 2, K * 2, rows, hipMemcpyDeviceToDevice, s));
+        // the separate hi / lo copies are dead once the interleaved rows exist (they are rebuilt from the fp32 master if a later call
+        // asks for the plain 16-bit mode): 4 of the 16 bytes per parameter.  hipFree waits for the copies above (first use only).
+        (void)hipFree(p.h16[dt]); p.h16[dt] = nullptr;
+        (void)hipFree(p.l16[dt]); p.l16[dt] = nullptr;
     }
     *hi = p.x2[dt];
     return 0;
+}
+static void build_layer_tables(must3r_hip_ctx* c, bool decoder) {
+    std::vector<std::vector<Param*>>& tab = decoder ? c->dec_tab : c->enc_tab;
+    const int depth = decoder ? c->cfg.dec_depth : c->cfg.enc_depth;
+    tab.assign(depth, std::vector<Param*>(LF_COUNT, nullptr));
+    for (int l = 0; l < depth; ++l) {
+        const std::string b = (decoder ? "decoder.blocks_dec." : "encoder.blocks_enc.") + std::to_string(l) + ".";
+        for (int f = 0; f < LF_COUNT; ++f) tab[l][f] = param(c, b + kLayerFieldNames[f]);
+    }
 }
 
 // [W_hi | W_hi | W_lo] rows: with the activation laid out as [y_hi | y_lo | y_hi] the three products of the split-precision head
@@ -593,15 +619,16 @@ static int encode_chunk(must3r_hip_ctx* c, DType dt, const float* img, int V, in
     void* views_dev = nullptr;
     M3R_OK(upload_table(c, views.data(), sizeof(AttnView) * V, &views_dev, s));
 
+    if (c->enc_tab.empty()) build_layer_tables(c, false);
     const void* w;
     M3R_OK(w16(c, "encoder.patch_embed.proj.weight", dt, &w, s));
     M3R_OK(gemm(c, dt, EPI_F32, gargs(P16, w, p32(c, "encoder.patch_embed.proj.bias"), x, R, C, 768, 768, C), s));
     for (int l = 0; l < g.enc_depth; ++l) {
-        const std::string b = "encoder.blocks_enc." + std::to_string(l);
-        M3R_OK(layernorm(c, dt, x, nullptr, p32(c, b + ".norm1.weight"), p32(c, b + ".norm1.bias"), h16, nullptr, nullptr,
+        const std::vector<Param*>& LP = c->enc_tab[l];
+        M3R_OK(layernorm(c, dt, x, nullptr, LP[LF_N1W]->d, LP[LF_N1B]->d, h16, nullptr, nullptr,
                          nullptr, R, C, 1e-6f, s));
-        M3R_OK(w16(c, b + ".attn.qkv.weight", dt, &w, s));
-        GemmArgs ga = gargs(h16, w, p32(c, b + ".attn.qkv.bias"), qkv, R, 3 * C, C, C, 3 * C);
+        M3R_OK(w16p(c, *LP[LF_QKVW], dt, &w, s));
+        GemmArgs ga = gargs(h16, w, LP[LF_QKVB]->d, qkv, R, 3 * C, C, C, 3 * C);
         ga.pos = out_pos; ga.rope_tab = c->rope_tab; ga.rope_cols = 2 * C; ga.rope_npos = c->rope_npos;
         ga.out_scale = kQScale; ga.scale_cols = C;   // q *= 1/sqrt(64) * log2(e)
         M3R_OK(gemm(c, dt, EPI_QKV_ROPE, ga, s));
@@ -616,14 +643,14 @@ static int encode_chunk(must3r_hip_ctx* c, DType dt, const float* img, int V, in
             aa.Q = q8; aa.K = q8 + C; aa.V = q8 + 2 * C; aa.fp8 = 1;
         }
         M3R_OK(attention(c, dt, aa, 4.0 * V * (double)N * N * C, PC_ATTN_SA, s));
-        M3R_OK(w16(c, b + ".attn.proj.weight", dt, &w, s));
-        M3R_OK(gemm(c, dt, EPI_RESID_F32, gargs(a16, w, p32(c, b + ".attn.proj.bias"), x, R, C, C, C, C), s));
-        M3R_OK(layernorm(c, dt, x, nullptr, p32(c, b + ".norm2.weight"), p32(c, b + ".norm2.bias"), h16, nullptr, nullptr,
+        M3R_OK(w16p(c, *LP[LF_PROJW], dt, &w, s));
+        M3R_OK(gemm(c, dt, EPI_RESID_F32, gargs(a16, w, LP[LF_PROJB]->d, x, R, C, C, C, C), s));
+        M3R_OK(layernorm(c, dt, x, nullptr, LP[LF_N2W]->d, LP[LF_N2B]->d, h16, nullptr, nullptr,
                          nullptr, R, C, 1e-6f, s));
-        M3R_OK(w16(c, b + ".mlp.fc1.weight", dt, &w, s));
-        M3R_OK(gemm(c, dt, EPI_STORE16_GELU, gargs(h16, w, p32(c, b + ".mlp.fc1.bias"), g16, R, F, C, C, F), s));
-        M3R_OK(w16(c, b + ".mlp.fc2.weight", dt, &w, s));
-        M3R_OK(gemm(c, dt, EPI_RESID_F32, gargs(g16, w, p32(c, b + ".mlp.fc2.bias"), x, R, C, F, F, C), s));
+        M3R_OK(w16p(c, *LP[LF_FC1W], dt, &w, s));
+        M3R_OK(gemm(c, dt, EPI_STORE16_GELU, gargs(h16, w, LP[LF_FC1B]->d, g16, R, F, C, C, F), s));
+        M3R_OK(w16p(c, *LP[LF_FC2W], dt, &w, s));
+        M3R_OK(gemm(c, dt, EPI_RESID_F32, gargs(g16, w, LP[LF_FC2B]->d, x, R, C, F, F, C), s));
     }
     M3R_OK(layernorm(c, dt, x, nullptr, p32(c, "encoder.norm_enc.weight"), p32(c, "encoder.norm_enc.bias"), nullptr, nullptr,
                      out_tokens, nullptr, R, C, 1e-6f, s));
@@ -671,6 +698,7 @@ extern "C" int must3r_hip_decode(must3r_hip_ctx* c, const must3r_hip_decode_args
     if (A->render && (A->first_call || A->n_mem <= 0)) return fail("decode: render needs a memory (decoder.py:278)");
     if (A->first_call && A->n_mem != 0) return fail("decode: first_call with a non-empty memory");
     DeviceGuard dev_guard(c->device);
+    if (c->dec_tab.empty()) build_layer_tables(c, true);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const DType dt = adt == MUST3R_F16_W2 ? DT_F16 : (DType)adt;
     const bool a8 = c->attn8 != 0;
@@ -824,36 +852,36 @@ extern "C" int must3r_hip_decode(must3r_hip_ctx* c, const must3r_hip_decode_args
     // prepare_y (layers.py:81-88) of the R new token rows, written to memory rows [Nm, Nm+R) in the caller's mode:
     //   'kv'     LN(norm_y) -> [projk | projv]       'norm_y'  LN(norm_y)        'raw'  the tokens themselves
     auto kv_project = [&](int l, const float* src, const float* add, float* copy, hipStream_t st) -> int {
-        const std::string b = "decoder.blocks_dec." + std::to_string(l);
+        const std::vector<Param*>& LP = c->dec_tab[l];
         uint16_t* dst = reinterpret_cast<uint16_t*>(reinterpret_cast<char*>(A->mem[l]) + (size_t)Nm * memD * memES);
-        LnArgs la = lnargs(src, add, p32(c, b + ".norm_y.weight"), p32(c, b + ".norm_y.bias"), h16, nullptr, nullptr, copy, R, D, 1e-6f);
+        LnArgs la = lnargs(src, add, LP[LF_NYW]->d, LP[LF_NYB]->d, h16, nullptr, nullptr, copy, R, D, 1e-6f);
         if (mode == MUST3R_MEM_NORM_Y) la.out16 = dst;
         if (mode == MUST3R_MEM_RAW) { la.out16 = nullptr; la.raw16 = dst; }
         M3R_OK(layernorm_a(c, dt, la, st));
         if (mode != MUST3R_MEM_KV) return 0;
         const void* wk;
-        M3R_OK(w16(c, b + ".cross_attn.projkv.weight", dt, &wk, st));
-        if (!a8) return gemm(c, dt, EPI_STORE16, gargs(h16, wk, p32(c, b + ".cross_attn.projkv.bias"), dst, R, 2 * D, D, D, 2 * D), st);
+        M3R_OK(w16p(c, *LP[LF_PKVW], dt, &wk, st));
+        if (!a8) return gemm(c, dt, EPI_STORE16, gargs(h16, wk, LP[LF_PKVB]->d, dst, R, 2 * D, D, D, 2 * D), st);
         // fp8 memory: project into the 16-bit staging rows, quantise into the memory rows
-        M3R_OK(gemm(c, dt, EPI_STORE16, gargs(h16, wk, p32(c, b + ".cross_attn.projkv.bias"), kv16, R, 2 * D, D, D, 2 * D), st));
+        M3R_OK(gemm(c, dt, EPI_STORE16, gargs(h16, wk, LP[LF_PKVB]->d, kv16, R, 2 * D, D, D, 2 * D), st));
         return quant8(c, dt, kv16, 2 * D, dst, 2 * D, nullptr, 0, (size_t)R, 2 * D, st);
     };
     // K|V rows the cross attention of layer l reads: the memory itself ('kv') or a projection of it into scratch
     auto kv_source = [&](int l, const void** kptr, hipStream_t st) -> int {
         if (mode == MUST3R_MEM_KV) { *kptr = A->mem[l]; return 0; }
-        const std::string b = "decoder.blocks_dec." + std::to_string(l);
+        const std::vector<Param*>& LP = c->dec_tab[l];
         const uint16_t* src = reinterpret_cast<const uint16_t*>(A->mem[l]);
         const int rows = (int)kvs_rows;
         if (mode == MUST3R_MEM_RAW) {  // y_ = norm_y(y) on the stored tokens (layers.py:92)
-            LnArgs la = lnargs(nullptr, nullptr, p32(c, b + ".norm_y.weight"), p32(c, b + ".norm_y.bias"), ytmp, nullptr, nullptr, nullptr,
+            LnArgs la = lnargs(nullptr, nullptr, LP[LF_NYW]->d, LP[LF_NYB]->d, ytmp, nullptr, nullptr, nullptr,
                                rows, D, 1e-6f);
             la.x16 = src;
             M3R_OK(layernorm_a(c, dt, la, st));
             src = ytmp;
         }
         const void* wk;
-        M3R_OK(w16(c, b + ".cross_attn.projkv.weight", dt, &wk, st));
-        M3R_OK(gemm(c, dt, EPI_STORE16, gargs(src, wk, p32(c, b + ".cross_attn.projkv.bias"), kvs, rows, 2 * D, D, D, 2 * D), st));
+        M3R_OK(w16p(c, *LP[LF_PKVW], dt, &wk, st));
+        M3R_OK(gemm(c, dt, EPI_STORE16, gargs(src, wk, LP[LF_PKVB]->d, kvs, rows, 2 * D, D, D, 2 * D), st));
         *kptr = kvs;
         if (a8) {
             M3R_OK(quant8(c, dt, kvs, 2 * D, kvs8, 2 * D, nullptr, 0, (size_t)rows, 2 * D, st));
@@ -871,13 +899,13 @@ extern "C" int must3r_hip_decode(must3r_hip_ctx* c, const must3r_hip_decode_args
         return la;
     };
     for (int l = 0; l < L; ++l) {
-        const std::string b = "decoder.blocks_dec." + std::to_string(l);
+        const std::vector<Param*>& LP = c->dec_tab[l];
         if (need_pre_kv) M3R_OK(kv_project(l, x, nullptr, nullptr, s));
         // --- self attention (layers.py:91)
-        M3R_OK(layernorm_a(c, dt, with_slabs(lnargs(x, nullptr, p32(c, b + ".norm1.weight"), p32(c, b + ".norm1.bias"), h16, nullptr, nullptr,
+        M3R_OK(layernorm_a(c, dt, with_slabs(lnargs(x, nullptr, LP[LF_N1W]->d, LP[LF_N1B]->d, h16, nullptr, nullptr,
                                                    update ? newmem + (size_t)l * R * D : nullptr, R, D, 1e-6f)), s));
-        M3R_OK(w16(c, b + ".attn.qkv.weight", dt, &w, s));
-        GemmArgs ga = gargs(h16, w, p32(c, b + ".attn.qkv.bias"), qkv, R, 3 * D, D, D, 3 * D);
+        M3R_OK(w16p(c, *LP[LF_QKVW], dt, &w, s));
+        GemmArgs ga = gargs(h16, w, LP[LF_QKVB]->d, qkv, R, 3 * D, D, D, 3 * D);
         ga.pos = pos_all; ga.rope_tab = c->rope_tab; ga.rope_cols = 2 * D; ga.rope_npos = c->rope_npos;
         ga.out_scale = kQScale; ga.scale_cols = D;
         M3R_OK(gemm(c, dt, EPI_QKV_ROPE, ga, s));
@@ -892,14 +920,14 @@ extern "C" int must3r_hip_decode(must3r_hip_ctx* c, const must3r_hip_decode_args
             aa.Q = q8; aa.K = q8 + D; aa.V = q8 + 2 * D; aa.fp8 = 1;
         }
         M3R_OK(attention(c, dt, aa, sa_flops, PC_ATTN_SA, s));
-        M3R_OK(w16(c, b + ".attn.proj.weight", dt, &w, s));
-        M3R_OK(gemm(c, dt, EPI_RESID_F32, gargs(a16, w, p32(c, b + ".attn.proj.bias"), x, R, D, D, D, D), s));
+        M3R_OK(w16p(c, *LP[LF_PROJW], dt, &w, s));
+        M3R_OK(gemm(c, dt, EPI_RESID_F32, gargs(a16, w, LP[LF_PROJB]->d, x, R, D, D, D, D), s));
         // --- cross attention over the memory (layers.py:92-97; attention.py:139-149)
-        M3R_OK(layernorm(c, dt, x, nullptr, p32(c, b + ".norm2.weight"), p32(c, b + ".norm2.bias"), h16, nullptr, nullptr, nullptr,
+        M3R_OK(layernorm(c, dt, x, nullptr, LP[LF_N2W]->d, LP[LF_N2B]->d, h16, nullptr, nullptr, nullptr,
                          R, D, 1e-6f, s));
-        M3R_OK(w16(c, b + ".cross_attn.projq.weight", dt, &w, s));
+        M3R_OK(w16p(c, *LP[LF_PQW], dt, &w, s));
         {
-            GemmArgs gq = gargs(h16, w, p32(c, b + ".cross_attn.projq.bias"), q16, R, D, D, D, D);
+            GemmArgs gq = gargs(h16, w, LP[LF_PQB]->d, q16, R, D, D, D, D);
             gq.out_scale = kQScale; gq.scale_cols = D;
             M3R_OK(gemm(c, dt, EPI_STORE16, gq, s));
         }
@@ -920,21 +948,21 @@ extern "C" int must3r_hip_decode(must3r_hip_ctx* c, const must3r_hip_decode_args
             aa.part_ml = aa.part_o + (size_t)ca_split * R * D;
         }
         M3R_OK(attention(c, dt, aa, ca_flops, PC_ATTN_CA, s));
-        M3R_OK(w16(c, b + ".cross_attn.proj.weight", dt, &w, s));
-        M3R_OK(gemm(c, dt, EPI_RESID_F32, gargs(a16, w, p32(c, b + ".cross_attn.proj.bias"), x, R, D, D, D, D), s));
+        M3R_OK(w16p(c, *LP[LF_CPW], dt, &w, s));
+        M3R_OK(gemm(c, dt, EPI_RESID_F32, gargs(a16, w, LP[LF_CPB]->d, x, R, D, D, D, D), s));
         // --- MLP (layers.py:98)
-        M3R_OK(layernorm(c, dt, x, nullptr, p32(c, b + ".norm3.weight"), p32(c, b + ".norm3.bias"), h16, nullptr, nullptr, nullptr,
+        M3R_OK(layernorm(c, dt, x, nullptr, LP[LF_N3W]->d, LP[LF_N3B]->d, h16, nullptr, nullptr, nullptr,
                          R, D, 1e-6f, s));
-        M3R_OK(w16(c, b + ".mlp.fc1.weight", dt, &w, s));
-        M3R_OK(gemm(c, dt, EPI_STORE16_GELU, gargs(h16, w, p32(c, b + ".mlp.fc1.bias"), g16, R, F, D, D, F), s));
-        M3R_OK(w16(c, b + ".mlp.fc2.weight", dt, &w, s));
+        M3R_OK(w16p(c, *LP[LF_FC1W], dt, &w, s));
+        M3R_OK(gemm(c, dt, EPI_STORE16_GELU, gargs(h16, w, LP[LF_FC1B]->d, g16, R, F, D, D, F), s));
+        M3R_OK(w16p(c, *LP[LF_FC2W], dt, &w, s));
         if (fc2_splitk) {
             GemmArgs gs = gargs(g16, w, nullptr, slabs, R, D, F, F, D);
             gs.ksplit = KS; gs.slab_stride = (long long)R * D;
             M3R_OK(gemm(c, dt, EPI_F32, gs, s));
-            pending_bias = p32(c, b + ".mlp.fc2.bias");
+            pending_bias = LP[LF_FC2B]->d;
         } else {
-            M3R_OK(gemm(c, dt, EPI_RESID_F32, gargs(g16, w, p32(c, b + ".mlp.fc2.bias"), x, R, D, F, F, D), s));
+            M3R_OK(gemm(c, dt, EPI_RESID_F32, gargs(g16, w, LP[LF_FC2B]->d, x, R, D, F, F, D), s));
         }
         if (A->feats && l < L - 1)   // return_feats: the residual stream after block l (decoder.py:321)
             HIP_OK(hipMemcpyAsync(A->feats + (size_t)l * R * D, x, (size_t)R * D * sizeof(float), hipMemcpyDeviceToDevice, s));
