@@ -15,7 +15,7 @@ ATTN_FP8 = 0x100   # OR-able: fp8 (e4m3) attention operands, include/must3r_hip.
 MEM_KV, MEM_NORM_Y, MEM_RAW = 0, 1, 2
 PART_ENCODER, PART_DECODER = 1, 2
 EPI_STORE16, EPI_STORE16_GELU, EPI_QKV_ROPE, EPI_RESID_F32, EPI_F32, EPI_HEAD = range(6)
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 # every symbol include/must3r_hip.h declares
 EXPORTS = (
@@ -27,7 +27,7 @@ EXPORTS = (
     "must3r_hip_postprocess_cam", "must3r_hip_postprocess_cam_scratch_bytes",
     "must3r_hip_nn_query", "must3r_hip_quadrant_ids",
     "must3r_hip_affine", "must3r_hip_row_norm", "must3r_hip_topk_gather", "must3r_hip_weighted_spoc",
-    "must3r_hip_op_gemm_splitk", "must3r_hip_op_layernorm_slabs",
+    "must3r_hip_op_gemm_splitk", "must3r_hip_op_layernorm_slabs", "must3r_hip_op_gemm_lnfold",
 )
 
 
@@ -89,6 +89,7 @@ def load():
     lib.must3r_hip_attention_scratch_bytes.argtypes = [i32, i32, i32]
     lib.must3r_hip_attention_scratch_bytes.restype = C.c_size_t
     lib.must3r_hip_op_layernorm.argtypes = [i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, fp, vp]
+    lib.must3r_hip_op_gemm_lnfold.argtypes = [i32, i32, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, fp, vp, vp, i32, i32, fp, i32, vp]
     lib.must3r_hip_op_gemm_splitk.argtypes = [i32, vp, vp, vp, i32, i32, i32, i32, i32, i32, C.c_int64, vp]
     lib.must3r_hip_op_layernorm_slabs.argtypes = [i32, vp, vp, i32, C.c_int64, vp, vp, vp, vp, vp, i32, i32, fp, vp]
     lib.must3r_hip_op_im2col.argtypes = [i32, vp, vp, i32, i32, i32, vp]

@@ -138,6 +138,16 @@ __device__ __forceinline__ float wave_sum_dpp(float v) {
     return __uint_as_float(q[0]) + __uint_as_float(q[1]);
 }
 
+// sum over the 4 lanes {l, l^16, l^32, l^48} (the four column groups of one output row in the GEMM epilogues)
+__device__ __forceinline__ float quad_row_sum(float x) {
+    unsigned u = __float_as_uint(x);
+    auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    x = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    u = __float_as_uint(x);
+    auto q = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return __uint_as_float(q[0]) + __uint_as_float(q[1]);
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

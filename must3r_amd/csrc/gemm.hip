@@ -46,11 +46,79 @@ __device__ __forceinline__ void epilogue_prefetch(const GemmArgs& p, void* const
     }
 }
 
+// LN fold, producer side: the new residual values of one lane (4 columns of row m) -> 16-bit copy, optional fp32 copy, and the
+// (sum, sum of squares) of the row's 16-column fragment (the four lanes fg = 0..3 of a row hold one fragment)
+template <class T>
+__device__ __forceinline__ void ln_fold_emit(const GemmArgs& p, const int m, const int n, const int fg, const f32x4 xn) {
+    typedef typename Vec<T>::v4 v4;
+    if (p.x16_out) *reinterpret_cast<v4*>(reinterpret_cast<T*>(p.x16_out) + (size_t)m * p.ldc + n) = cvt4_sat<T>(xn);
+    if (p.copy32_out) *reinterpret_cast<f32x4*>(p.copy32_out + (size_t)m * p.ldc + n) = xn;
+    if (p.stats_out) {
+        const float s1 = quad_row_sum((xn[0] + xn[1]) + (xn[2] + xn[3]));
+        const float s2 = quad_row_sum((xn[0] * xn[0] + xn[1] * xn[1]) + (xn[2] * xn[2] + xn[3] * xn[3]));
+        if (fg == 0) {
+            float* d = p.stats_out + ((size_t)m * (p.N >> 4) + (n >> 4)) * 2;
+            d[0] = s1;
+            d[1] = s2;
+        }
+    }
+}
+
+// LN fold, consumer side: (mu, rstd) of the block's BM rows from the producer's fragment sums, left in LDS at sm[BM*TPR*2 + 2*row].
+// NT threads, TPR = NT / BM threads per row, each adds its share of the K/16 fragments in order, thread 0 of a row adds the TPR
+// partial sums in order: deterministic.  Raw barriers (LDS-DMA of the ring prologue may be in flight; __syncthreads would drain it).
+template <int BM, int NT>
+__device__ __forceinline__ void ln_fold_rows(const GemmArgs& p, const int m0, float* sm, const int tid) {
+    constexpr int TPR = NT / BM;
+    static_assert(TPR * BM == NT, "threads per row");
+    const int nslots = p.K >> 4, per = nslots / TPR;
+    const int row = tid / TPR, part = tid - row * TPR;
+    int m = m0 + row;
+    m = m < p.M ? m : p.M - 1;
+    const float* src = p.ln_stats + ((size_t)m * nslots + (size_t)part * per) * 2;
+    float s1 = 0.f, s2 = 0.f;
+    for (int i = 0; i < per; i += 2) {
+        const f32x4 q = *reinterpret_cast<const f32x4*>(src + i * 2);
+        s1 += q[0]; s2 += q[1];
+        s1 += q[2]; s2 += q[3];
+    }
+    sm[(row * TPR + part) * 2] = s1;
+    sm[(row * TPR + part) * 2 + 1] = s2;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (part == 0) {
+        float a = 0.f, b = 0.f;
+        for (int t = 0; t < TPR; ++t) {
+            a += sm[(row * TPR + t) * 2];
+            b += sm[(row * TPR + t) * 2 + 1];
+        }
+        const float inv = 1.0f / (float)p.K;
+        const float mu = a * inv;
+        float var = b * inv - mu * mu;
+        var = var > 0.f ? var : 0.f;
+        sm[BM * TPR * 2 + row * 2] = mu;
+        sm[BM * TPR * 2 + row * 2 + 1] = rsqrtf(var + p.ln_eps);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+}
+template <int BM, int NT> constexpr size_t ln_fold_lds_bytes() { return (size_t)(BM * (NT / BM) * 2 + BM * 2) * sizeof(float); }
+
 template <class T, int EPI, int NF>
 __device__ __forceinline__ void epilogue_row(const GemmArgs& p, void* const outp, const float* __restrict__ bias, const int m,
-                                             const int nw0, const int fg, f32x4 (&v)[NF], const EpiPre<NF>* pre = nullptr) {
+                                             const int nw0, const int fg, f32x4 (&v)[NF], const EpiPre<NF>* pre = nullptr,
+                                             const float ln_mu = 0.f, const float ln_rstd = 0.f) {
     typedef typename Vec<T>::v4 v4;
     const int nb = nw0 + fg * 4;
+    if constexpr (EPI == EPI_STORE16 || EPI == EPI_STORE16_GELU || EPI == EPI_QKV_ROPE) {
+        if (p.ln_stats != nullptr) {   // LN fold: acc = sum_k x_k W'_nk  ->  rstd (acc - mu s_n); c_n comes in as the bias
+#pragma unroll
+            for (int j = 0; j < NF; ++j) {
+                const f32x4 s4 = *reinterpret_cast<const f32x4*>(p.ln_s + nb + j * 16);
+                v[j] = (v[j] - s4 * ln_mu) * ln_rstd;
+            }
+        }
+    }
 #pragma unroll
     for (int j = 0; j < NF; ++j) {
         const bool nobias = (EPI == EPI_F32 || EPI == EPI_HEAD) && p.accumulate;
@@ -104,7 +172,9 @@ __device__ __forceinline__ void epilogue_row(const GemmArgs& p, void* const outp
             *reinterpret_cast<v4*>(reinterpret_cast<T*>(outp) + (size_t)m * p.ldc + n) = cvt4_sat<T>(g);
         } else if constexpr (EPI == EPI_RESID_F32) {
             f32x4* o = reinterpret_cast<f32x4*>(reinterpret_cast<float*>(outp) + (size_t)m * p.ldc + n);
-            *o = (pre != nullptr ? pre->x[j] : *o) + v[j];
+            const f32x4 xn = (pre != nullptr ? pre->x[j] : *o) + v[j];
+            *o = xn;
+            ln_fold_emit<T>(p, m, n, fg, xn);
         } else if constexpr (EPI == EPI_F32) {
             f32x4* o = reinterpret_cast<f32x4*>(reinterpret_cast<float*>(outp) + (size_t)m * p.ldc + n);
             f32x4 x = v[j];
@@ -114,6 +184,7 @@ __device__ __forceinline__ void epilogue_row(const GemmArgs& p, void* const outp
                 x += *reinterpret_cast<const f32x4*>(p.bias2 + n);
             }
             *o = x;
+            ln_fold_emit<T>(p, m, n, fg, x);
         } else if constexpr (EPI == EPI_HEAD) {
             // permuted feature n = (i*16 + jj)*7 + c ; token t of view vv at grid (gy, gx)
             const int vv = m / p.ntok, t = m - vv * p.ntok;
@@ -219,6 +290,12 @@ __global__ void __launch_bounds__(64 * WGM * WGN) gemm_kernel(const GemmArgs p) 
     const int fr = lane & 15;   // fragment row supplied by this lane
     const int fg = lane >> 4;   // k-group (16-byte chunk) supplied by this lane
     const int nk = nka;
+    // LN fold (consumer): row statistics of this block's BM rows, kept behind the ring
+    constexpr bool LNF = EPI == EPI_STORE16 || EPI == EPI_STORE16_GELU || EPI == EPI_QKV_ROPE;
+    float* const sm_ln = reinterpret_cast<float*>(smem + (size_t)NST * (BM + WS * BN) * BK * sizeof(T));
+    if constexpr (LNF) {
+        if (p.ln_stats != nullptr) ln_fold_rows<BM, 64 * NW>(p, m0, sm_ln, tid);
+    }
 
     auto compute = [&](int buf) {
         const T* a = sA + buf * BM * BK;
@@ -391,14 +468,22 @@ __global__ void __launch_bounds__(64 * WGM * WGN) gemm_kernel(const GemmArgs p) 
         f32x4 v[NF];
 #pragma unroll
         for (int j = 0; j < NF; ++j) v[j] = acc[i][j];
-        epilogue_row<T, EPI, NF>(p, outp, bias, m, n0 + wn * WN, fg, v);
+        float mu = 0.f, rstd = 0.f;
+        if constexpr (LNF) {
+            if (p.ln_stats != nullptr) {
+                constexpr int TPR = 64 * NW / BM;
+                mu = sm_ln[BM * TPR * 2 + (wm * WM + i * 16 + fr) * 2];
+                rstd = sm_ln[BM * TPR * 2 + (wm * WM + i * 16 + fr) * 2 + 1];
+            }
+        }
+        epilogue_row<T, EPI, NF>(p, outp, bias, m, n0 + wn * WN, fg, v, nullptr, mu, rstd);
     }
 }
 
 template <class T, int BM, int BN, int WGM, int WGN, int EPI, int NST, int WS, int BK = 64, int PIPE = 0>
 static int launch_cfg(const GemmArgs& a, hipStream_t s) {
     const int nbn = a.N / BN, nbm = (a.M + BM - 1) / BM;
-    const size_t lds = (size_t)NST * (BM + WS * BN) * BK * sizeof(T);
+    const size_t lds = (size_t)NST * (BM + WS * BN) * BK * sizeof(T) + ln_fold_lds_bytes<BM, 64 * WGM * WGN>();
     static bool attr_set = false;
     if (!attr_set) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<T, BM, BN, WGM, WGN, EPI, NST, WS, BK, PIPE>),
@@ -664,6 +749,8 @@ __global__ void __launch_bounds__(576) gemm48_kernel(const GemmArgs p) {
     const int nk = p.K / BK;
     EpiPre<1> pre;
     epilogue_prefetch<T, EPI, 1>(p, outp, bias, m0 + wm * 16 + fr, n0 + wn * 16, fg, pre);
+    constexpr bool LNF = EPI == EPI_STORE16 || EPI == EPI_STORE16_GELU;
+    float* const sm_ln = reinterpret_cast<float*>(smem + (size_t)NST * STAGE * sizeof(T));
     int a_off[2], w_off[2][WS];
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
@@ -678,6 +765,9 @@ __global__ void __launch_bounds__(576) gemm48_kernel(const GemmArgs p) {
 #pragma unroll
     for (int t = 0; t < NST - 1; ++t)
         if (t < nk) stage(t, t);
+    if constexpr (LNF) {   // LN fold: the row statistics are gathered while the ring prologue is in flight
+        if (p.ln_stats != nullptr) ln_fold_rows<BM, 64 * NW>(p, m0, sm_ln, tid);
+    }
     int buf = 0;
     for (int kt = 0; kt < nk; ++kt) {
         // tile kt landed: at most NST-2 younger tiles x TMAX loads may still be in flight (tail: drain)
@@ -707,7 +797,14 @@ __global__ void __launch_bounds__(576) gemm48_kernel(const GemmArgs p) {
     const int m = m0 + wm * 16 + fr;
     if (m < p.M) {
         f32x4 v[1] = {acc};
-        epilogue_row<T, EPI, 1>(p, outp, bias, m, n0 + wn * 16, fg, v, &pre);
+        float mu = 0.f, rstd = 0.f;
+        if constexpr (LNF) {
+            if (p.ln_stats != nullptr) {
+                mu = sm_ln[BM * 12 * 2 + (wm * 16 + fr) * 2];
+                rstd = sm_ln[BM * 12 * 2 + (wm * 16 + fr) * 2 + 1];
+            }
+        }
+        epilogue_row<T, EPI, 1>(p, outp, bias, m, n0 + wn * 16, fg, v, &pre, mu, rstd);
     }
 }
 
@@ -715,7 +812,7 @@ template <class T, int EPI, int WS>
 static int launch_48(const GemmArgs& a, hipStream_t s) {
     constexpr int NST = 6;
     const int nbn = a.N / 48, nbm = (a.M + 47) / 48;
-    const size_t lds = (size_t)NST * (48 + WS * 48) * 64 * sizeof(T);
+    const size_t lds = (size_t)NST * (48 + WS * 48) * 64 * sizeof(T) + ln_fold_lds_bytes<48, 576>();
     static bool attr_set = false;
     if (!attr_set) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm48_kernel<T, EPI, WS, NST>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -802,6 +899,8 @@ __global__ void __launch_bounds__(576) gemm96_kernel(const GemmArgs p) {
     EpiPre<NF> pre[MF];
 #pragma unroll
     for (int i = 0; i < MF; ++i) epilogue_prefetch<T, EPI, NF>(p, outp, bias, m0 + wm * 32 + i * 16 + fr, n0 + wn * 32, fg, pre[i]);
+    constexpr bool LNF = EPI == EPI_STORE16 || EPI == EPI_STORE16_GELU || EPI == EPI_QKV_ROPE;
+    float* const sm_ln = reinterpret_cast<float*>(smem + (size_t)NST * STAGE * sizeof(T));
     int a_off[2][MF], w_off[2][WS][NF];
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
@@ -845,6 +944,9 @@ __global__ void __launch_bounds__(576) gemm96_kernel(const GemmArgs p) {
 #pragma unroll
         for (int t = 0; t < NST; ++t)
             if (t < nk) stage(t, t);
+        if constexpr (LNF) {   // LN fold: the row statistics are gathered while the ring prologue is in flight
+            if (p.ln_stats != nullptr) ln_fold_rows<BM, 64 * NW>(p, m0, sm_ln, tid);
+        }
         // tile 0 landed: up to NST-1 younger tiles in flight
         if (nk >= NST) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 1) * TP) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -898,6 +1000,9 @@ __global__ void __launch_bounds__(576) gemm96_kernel(const GemmArgs p) {
 #pragma unroll
     for (int t = 0; t < NST - 1; ++t)
         if (t < nk) stage(t, t);
+    if constexpr (LNF) {
+        if (p.ln_stats != nullptr) ln_fold_rows<BM, 64 * NW>(p, m0, sm_ln, tid);
+    }
     int buf = 0;
     for (int kt = 0; kt < nk; ++kt) {
         // tile kt landed: at most NST-2 younger tiles x TP loads may still be in flight (tail: drain)
@@ -939,7 +1044,14 @@ __global__ void __launch_bounds__(576) gemm96_kernel(const GemmArgs p) {
         f32x4 v[NF];
 #pragma unroll
         for (int j = 0; j < NF; ++j) v[j] = acc[i][j];
-        epilogue_row<T, EPI, NF>(p, outp, bias, m, n0 + wn * 32, fg, v, &pre[i]);
+        float mu = 0.f, rstd = 0.f;
+        if constexpr (LNF) {
+            if (p.ln_stats != nullptr) {
+                mu = sm_ln[BM * 6 * 2 + (wm * 32 + i * 16 + fr) * 2];
+                rstd = sm_ln[BM * 6 * 2 + (wm * 32 + i * 16 + fr) * 2 + 1];
+            }
+        }
+        epilogue_row<T, EPI, NF>(p, outp, bias, m, n0 + wn * 32, fg, v, &pre[i], mu, rstd);
     }
 }
 
@@ -947,7 +1059,7 @@ template <class T, int EPI, int PF>
 static int launch_96pf(const GemmArgs& a, hipStream_t s) {
     constexpr int NST = 4;
     const int nbn = a.N / 96, nbm = (a.M + 95) / 96;
-    const size_t lds = (size_t)NST * (96 + 2 * 96) * 64 * sizeof(T);
+    const size_t lds = (size_t)NST * (96 + 2 * 96) * 64 * sizeof(T) + ln_fold_lds_bytes<96, 576>();
     static bool attr_set = false;
     if (!attr_set) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm96_kernel<T, EPI, NST, PF>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1083,7 +1195,13 @@ static int launch_epi(const GemmArgs& a, hipStream_t s, const char** err) {
             // epilogue runs under the other's K loop.  Measured (r02, M = 15360): N = 3072, K = 768: 157 -> 143 us; N = 4096, K = 1024: 270 -> 265 us;
             // every other epilogue is faster with one block per CU and the deeper ring (qkv 186 vs 199-209 us, fc2 210 vs 228 us).
             static const bool gelu_occ2 = !(getenv("M3R_G256_GELU_OCC2") && atoi(getenv("M3R_G256_GELU_OCC2")) == 0);
-            if (EPI == EPI_STORE16_GELU && gelu_occ2 && mode != 0 && ok128 && t128 >= 1024) rc = launch_256<T, EPI, 2, 128, 2>(a, s);
+            if (a.ln_stats != nullptr) {
+                // LN-fold consumers: the kernels that carry the row-statistics prologue, whatever the tile count
+                if constexpr (EPI == EPI_STORE16_GELU) rc = a.N % 96 == 0 ? launch_96<T, EPI>(a, s) : 1;
+                else if constexpr (EPI == EPI_STORE16) rc = a.N % 48 == 0 ? launch_48<T, EPI, 2>(a, s) : 1;
+                else if constexpr (EPI == EPI_QKV_ROPE) rc = launch_cfg<T, 64, 64, 2, 2, EPI, 3, 2>(a, s);
+                else rc = 1;
+            } else if (EPI == EPI_STORE16_GELU && gelu_occ2 && mode != 0 && ok128 && t128 >= 1024) rc = launch_256<T, EPI, 2, 128, 2>(a, s);
             else if (EPI != EPI_HEAD && use_96(a, nb)) rc = launch_96<T, EPI == EPI_HEAD ? EPI_STORE16 : EPI>(a, s);
             else if (EPI != EPI_QKV_ROPE && EPI != EPI_HEAD && use_48(a, nb)) rc = launch_48<T, EPI == EPI_QKV_ROPE || EPI == EPI_HEAD ? EPI_STORE16 : EPI, 2>(a, s);
             else if (pick == 256) rc = launch_256<T, EPI, 2, 256>(a, s);
@@ -1134,6 +1252,18 @@ int launch_gemm(DType dt, Epi epi, const GemmArgs& a, hipStream_t s, const char*
         *err = "gemm: rope epilogue needs pos, table and 64-aligned rope_cols"; return 1;
     }
     if (epi == EPI_HEAD && (a.N % 112 != 0 || a.ntok <= 0 || a.gw <= 0)) { *err = "gemm: head epilogue geometry"; return 1; }
+    if (a.ln_stats != nullptr) {
+        const bool epi_ok = epi == EPI_STORE16 || epi == EPI_STORE16_GELU || epi == EPI_QKV_ROPE;
+        if (!epi_ok || a.ln_s == nullptr || a.wsplit != 2 || dt != DT_F16 || (a.K / 16) % 24 != 0 || (a.batch > 1)) {
+            *err = "gemm: LN fold needs a 16-bit-store epilogue, ln_s, split fp16 weights, K/16 divisible by 24, no batch";
+            return 1;
+        }
+    }
+    if ((a.x16_out || a.copy32_out || a.stats_out) && !(epi == EPI_RESID_F32 || epi == EPI_F32)) {
+        *err = "gemm: LN-fold outputs need the RESID_F32 / F32 epilogue";
+        return 1;
+    }
+    if (a.stats_out && a.N % 16 != 0) { *err = "gemm: stats_out needs N % 16 == 0"; return 1; }
     if (a.ksplit > 1) {   // split-K: fp32 partial slabs, no bias, 96 x 96 tiles with split weights only
         if (epi != EPI_F32 || a.bias != nullptr || a.bias2 != nullptr || a.accumulate || a.wsplit != 2 || dt != DT_F16 || a.N % 96 ||
             (a.K / 64) % a.ksplit || a.slab_stride < (long long)a.M * a.ldc) {

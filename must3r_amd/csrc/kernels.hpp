@@ -49,6 +49,18 @@ struct GemmArgs {
     int accumulate;          // EPI_F32 / EPI_HEAD: add into out, skip bias
     // EPI_HEAD: rows are `ntok`-token views of one aspect ratio
     int ntok, gw, H, Wimg;
+    // LayerNorm folded into the GEMMs around it (one-view memory update; DESIGN.md section 3, "LN fold"):
+    //   producer (EPI_RESID_F32 / EPI_F32): besides `out` it writes the new fp32 rows rounded to the 16-bit type (x16_out, row stride ldc),
+    //     an optional second fp32 copy (copy32_out) and, per row and 16-column fragment, (sum x, sum x^2) into stats_out [M][N/16][2];
+    //   consumer (STORE16 / STORE16_GELU / QKV_ROPE): A = those raw 16-bit rows, W = gamma (.) W, `bias` = c = W beta + b, and
+    //     out = epi( rstd_m (acc - mu_m s_n) + c_n ), (mu_m, rstd_m) from ln_stats [M][K/16][2], s_n = sum_k W'[n][k] (ln_s) -- which is
+    //     LN(x) W^T + b with the normalisation applied after the product instead of before it.
+    void* x16_out;
+    float* copy32_out;
+    float* stats_out;
+    const float* ln_stats;
+    const float* ln_s;
+    float ln_eps;
     // split-K (EPI_F32, bias == nullptr): ksplit > 1 cuts K into ksplit equal ranges, range z stores its fp32 partial product into
     // out + z * slab_stride (elements).  The consumer adds the slabs in a fixed order (LnArgs::slabs): deterministic, no atomics.
     int ksplit;

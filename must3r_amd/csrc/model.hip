@@ -65,8 +65,8 @@ enum ProfCat { PC_GEMM128 = 0, PC_GEMM64, PC_ATTN_SA, PC_ATTN_CA, PC_ATTN_COMBIN
 static const char* kProfNames[PC_COUNT] = {"gemm128", "gemm64", "attn_self", "attn_cross", "attn_combine", "layernorm", "misc"};
 
 // parameters of one transformer block, resolved to Param* once per context
-enum LayerField { LF_N1W, LF_N1B, LF_QKVW, LF_QKVB, LF_PROJW, LF_PROJB, LF_N2W, LF_N2B, LF_FC1W, LF_FC1B, LF_FC2W, LF_FC2B, LF_NYW, LF_NYB, LF_PQW, LF_PQB, LF_PKVW, LF_PKVB, LF_CPW, LF_CPB, LF_N3W, LF_N3B, LF_COUNT };
-static const char* kLayerFieldNames[LF_COUNT] = {"norm1.weight", "norm1.bias", "attn.qkv.weight", "attn.qkv.bias", "attn.proj.weight", "attn.proj.bias", "norm2.weight", "norm2.bias", "mlp.fc1.weight", "mlp.fc1.bias", "mlp.fc2.weight", "mlp.fc2.bias", "norm_y.weight", "norm_y.bias", "cross_attn.projq.weight", "cross_attn.projq.bias", "cross_attn.projkv.weight", "cross_attn.projkv.bias", "cross_attn.proj.weight", "cross_attn.proj.bias", "norm3.weight", "norm3.bias"};
+enum LayerField { LF_N1W, LF_N1B, LF_QKVW, LF_QKVB, LF_PROJW, LF_PROJB, LF_N2W, LF_N2B, LF_FC1W, LF_FC1B, LF_FC2W, LF_FC2B, LF_NYW, LF_NYB, LF_PQW, LF_PQB, LF_PKVW, LF_PKVB, LF_CPW, LF_CPB, LF_N3W, LF_N3B, LF_QKVLN_W, LF_QKVLN_S, LF_QKVLN_C, LF_PQLN_W, LF_PQLN_S, LF_PQLN_C, LF_FC1LN_W, LF_FC1LN_S, LF_FC1LN_C, LF_COUNT };
+static const char* kLayerFieldNames[LF_COUNT] = {"norm1.weight", "norm1.bias", "attn.qkv.weight", "attn.qkv.bias", "attn.proj.weight", "attn.proj.bias", "norm2.weight", "norm2.bias", "mlp.fc1.weight", "mlp.fc1.bias", "mlp.fc2.weight", "mlp.fc2.bias", "norm_y.weight", "norm_y.bias", "cross_attn.projq.weight", "cross_attn.projq.bias", "cross_attn.projkv.weight", "cross_attn.projkv.bias", "cross_attn.proj.weight", "cross_attn.proj.bias", "norm3.weight", "norm3.bias", "attn.qkv_ln.weight", "attn.qkv_ln.s", "attn.qkv_ln.c", "cross_attn.projq_ln.weight", "cross_attn.projq_ln.s", "cross_attn.projq_ln.c", "mlp.fc1_ln.weight", "mlp.fc1_ln.s", "mlp.fc1_ln.c"};
 
 struct must3r_hip_ctx {
     must3r_hip_config cfg;
@@ -579,6 +579,39 @@ extern "C" int must3r_hip_finalize_weights(must3r_hip_ctx* c, int parts) {
         M3R_OK(derive(c, "decoder.head_dec.proj_ps.weight", {7 * P, D}, w2));
         M3R_OK(derive(c, "decoder.head_dec.proj_ps.bias", {7 * P}, b2));
     }
+    // "LN fold" operands of the one-view memory update: for the three Linears that follow a LayerNorm,
+    // W' = gamma (.) W, s_n = sum_k W'[n][k], c_n = (W beta + b)_n, so that LN(x) W^T + b = rstd (x W'^T - mu s) + c.
+    {
+        const char* pairs[3][2] = {{"norm1", "attn.qkv"}, {"norm2", "cross_attn.projq"}, {"norm3", "mlp.fc1"}};
+        std::vector<float> w, bb, gam, bet;
+        for (int l = 0; l < g.dec_depth; ++l) {
+            const std::string pb = "decoder.blocks_dec." + std::to_string(l) + ".";
+            for (auto& pr : pairs) {
+                M3R_OK(fetch(c, pb + pr[1] + ".weight", w));
+                M3R_OK(fetch(c, pb + pr[1] + ".bias", bb));
+                M3R_OK(fetch(c, pb + pr[0] + ".weight", gam));
+                M3R_OK(fetch(c, pb + pr[0] + ".bias", bet));
+                const size_t K = gam.size(), N = bb.size();
+                if (w.size() != N * K || bet.size() != K) return fail("finalize: LN-fold shapes of %s%s", pb.c_str(), pr[1]);
+                std::vector<float> sn(N), cn(N);
+                for (size_t n = 0; n < N; ++n) {
+                    double ss = 0.0, cc = bb[n];
+                    float* row = &w[n * K];
+                    for (size_t k = 0; k < K; ++k) {
+                        cc += (double)bet[k] * row[k];
+                        row[k] *= gam[k];
+                        ss += row[k];
+                    }
+                    sn[n] = (float)ss;
+                    cn[n] = (float)cc;
+                }
+                M3R_OK(derive(c, pb + pr[1] + "_ln.weight", {(int64_t)N, (int64_t)K}, w));
+                M3R_OK(derive(c, pb + pr[1] + "_ln.s", {(int64_t)N}, sn));
+                M3R_OK(derive(c, pb + pr[1] + "_ln.c", {(int64_t)N}, cn));
+            }
+        }
+    }
+    c->dec_tab.clear();   // rebuilt on the next decode (the derived entries above may be new)
     c->fin_dec = true;
     return 0;
 }
@@ -743,6 +776,13 @@ extern "C" int must3r_hip_decode(must3r_hip_ctx* c, const must3r_hip_decode_args
         need = ws_need(need, (size_t)R * D, 4);       // feedback offset
         need = ws_need(need, (size_t)L * R * D, 2);   // norm_y of all layers (grouped K|V projection)
     }
+    // LN fold (one-view update calls, fp16 + split weights): none of the 36 LayerNorm launches of the blocks is issued; the residual GEMMs
+    // leave 16-bit rows + per-fragment sums, the Linears that follow normalise after their product (kernels.hpp GemmArgs "LN fold").
+    static const bool lnf_on = !(getenv("M3R_LNFOLD") && atoi(getenv("M3R_LNFOLD")) == 0);
+    const bool lnf = lnf_on && update && !need_pre_kv && c->wsplit == 2 && dt == DT_F16 && !a8 && !A->feats && A->n_groups == 1 &&
+                     D % 96 == 0 && (D / 16) % 24 == 0 && F % 96 == 0 && true;
+    need = ws_need(need, lnf ? (size_t)R * D : 0, 2);                 // x16: the residual stream rounded to fp16
+    need = ws_need(need, lnf ? (size_t)R * (D / 16) * 2 : 0, 4);      // per row and 16-column fragment (sum, sum of squares)
     // One-view update calls: the K = 4 D fc2 of every block runs as a split-K GEMM on 96 x 96 tiles (64 tiles x 4 K-ranges = one
     // block per CU instead of 256 blocks of 48 x 48 over the whole K) that leaves fp32 partial slabs; the residual update
     // x += b + slabs is done by the LayerNorm that reads x next (norm1 of the next block / norm_dec), in a fixed order.
@@ -750,7 +790,7 @@ extern "C" int must3r_hip_decode(must3r_hip_ctx* c, const must3r_hip_decode_args
     // Measured in the scene (r02, same box, interleaved): the GEMM class loses 0.9 ms and the LayerNorm class gains 0.9 ms (the four
     // 2.4 MB slabs per launch) -- a wash, so the route is OFF by default (M3R_FC2_SPLITK=1 enables it; operator-level tests cover it).
     static const bool fc2_splitk_on = getenv("M3R_FC2_SPLITK") && atoi(getenv("M3R_FC2_SPLITK")) != 0;
-    const bool fc2_splitk = fc2_splitk_on && c->wsplit == 2 && dt == DT_F16 && !need_pre_kv && !A->feats && D % 96 == 0 &&
+    const bool fc2_splitk = !lnf && fc2_splitk_on && c->wsplit == 2 && dt == DT_F16 && !need_pre_kv && !A->feats && D % 96 == 0 &&
                             (F / 64) % KS == 0 && (long)((R + 95) / 96) * (D / 96) * KS <= 256;
     need = ws_need(need, fc2_splitk ? (size_t)KS * R * D : 0, 4);   // slabs
     // split-KV cross attention when the launch cannot fill the chip (sequential memory update: one view per call)
@@ -784,6 +824,8 @@ extern "C" int must3r_hip_decode(must3r_hip_ctx* c, const must3r_hip_decode_args
     float* newmem = update ? ws_take<float>(c, (size_t)L * R * D) : nullptr;
     float* off32 = update ? ws_take<float>(c, (size_t)R * D) : nullptr;
     uint16_t* yall = update ? ws_take<uint16_t>(c, (size_t)L * R * D) : nullptr;
+    uint16_t* x16 = lnf ? ws_take<uint16_t>(c, (size_t)R * D) : nullptr;
+    float* lnstats = lnf ? ws_take<float>(c, (size_t)R * (D / 16) * 2) : nullptr;
     float* slabs = fc2_splitk ? ws_take<float>(c, (size_t)KS * R * D) : nullptr;
     char* split_ws = split_bytes ? ws_take<char>(c, split_bytes) : nullptr;
     uint16_t* kvs = kvs_rows ? ws_take<uint16_t>(c, kvs_rows * 2 * D) : nullptr;
@@ -835,6 +877,7 @@ extern "C" int must3r_hip_decode(must3r_hip_ctx* c, const must3r_hip_decode_args
         GemmArgs ga = gargs(t16, w, p32(c, "decoder.feat_embed_enc_to_dec.bias"), x, R, D, C, C, D);
         ga.bias2 = p32(c, "decoder.image2_embed");
         ga.row_start2 = A->first_call ? A->groups[0].n_tokens : 0;  // reference view (group 0, view 0) gets no embed
+        if (lnf) { ga.x16_out = x16; ga.stats_out = lnstats; ga.copy32_out = newmem; }   // block 0's norm1 input (+ its memorised copy)
         M3R_OK(gemm(c, dt, EPI_F32, ga, s));
     }
     // several aspect ratios: gather the positions of all rows into one [R,2] array.  t16 is dead after the
@@ -902,10 +945,18 @@ extern "C" int must3r_hip_decode(must3r_hip_ctx* c, const must3r_hip_decode_args
         const std::vector<Param*>& LP = c->dec_tab[l];
         if (need_pre_kv) M3R_OK(kv_project(l, x, nullptr, nullptr, s));
         // --- self attention (layers.py:91)
-        M3R_OK(layernorm_a(c, dt, with_slabs(lnargs(x, nullptr, LP[LF_N1W]->d, LP[LF_N1B]->d, h16, nullptr, nullptr,
-                                                   update ? newmem + (size_t)l * R * D : nullptr, R, D, 1e-6f)), s));
-        M3R_OK(w16p(c, *LP[LF_QKVW], dt, &w, s));
+        // LN fold: a consumer reads the raw 16-bit rows + fragment sums its producer left, with the gamma-scaled weight
+        auto fold_in = [&](GemmArgs& g_, int fs) {
+            g_.A = x16; g_.ln_stats = lnstats; g_.ln_s = LP[fs]->d; g_.bias = LP[fs + 1]->d; g_.ln_eps = 1e-6f;
+        };
+        // ... and a residual GEMM leaves them for the next consumer (copy: the memorised input of the next block, decoder.py:304-305)
+        auto fold_out = [&](GemmArgs& g_, float* copy) { g_.x16_out = x16; g_.stats_out = lnstats; g_.copy32_out = copy; };
+        if (!lnf)
+            M3R_OK(layernorm_a(c, dt, with_slabs(lnargs(x, nullptr, LP[LF_N1W]->d, LP[LF_N1B]->d, h16, nullptr, nullptr,
+                                                       update ? newmem + (size_t)l * R * D : nullptr, R, D, 1e-6f)), s));
+        M3R_OK(w16p(c, *LP[lnf ? LF_QKVLN_W : LF_QKVW], dt, &w, s));
         GemmArgs ga = gargs(h16, w, LP[LF_QKVB]->d, qkv, R, 3 * D, D, D, 3 * D);
+        if (lnf) fold_in(ga, LF_QKVLN_S);
         ga.pos = pos_all; ga.rope_tab = c->rope_tab; ga.rope_cols = 2 * D; ga.rope_npos = c->rope_npos;
         ga.out_scale = kQScale; ga.scale_cols = D;
         M3R_OK(gemm(c, dt, EPI_QKV_ROPE, ga, s));
@@ -921,13 +972,19 @@ extern "C" int must3r_hip_decode(must3r_hip_ctx* c, const must3r_hip_decode_args
         }
         M3R_OK(attention(c, dt, aa, sa_flops, PC_ATTN_SA, s));
         M3R_OK(w16p(c, *LP[LF_PROJW], dt, &w, s));
-        M3R_OK(gemm(c, dt, EPI_RESID_F32, gargs(a16, w, LP[LF_PROJB]->d, x, R, D, D, D, D), s));
+        {
+            GemmArgs gp = gargs(a16, w, LP[LF_PROJB]->d, x, R, D, D, D, D);
+            if (lnf) fold_out(gp, nullptr);
+            M3R_OK(gemm(c, dt, EPI_RESID_F32, gp, s));
+        }
         // --- cross attention over the memory (layers.py:92-97; attention.py:139-149)
-        M3R_OK(layernorm(c, dt, x, nullptr, LP[LF_N2W]->d, LP[LF_N2B]->d, h16, nullptr, nullptr, nullptr,
-                         R, D, 1e-6f, s));
-        M3R_OK(w16p(c, *LP[LF_PQW], dt, &w, s));
+        if (!lnf)
+            M3R_OK(layernorm(c, dt, x, nullptr, LP[LF_N2W]->d, LP[LF_N2B]->d, h16, nullptr, nullptr, nullptr,
+                             R, D, 1e-6f, s));
+        M3R_OK(w16p(c, *LP[lnf ? LF_PQLN_W : LF_PQW], dt, &w, s));
         {
             GemmArgs gq = gargs(h16, w, LP[LF_PQB]->d, q16, R, D, D, D, D);
+            if (lnf) fold_in(gq, LF_PQLN_S);
             gq.out_scale = kQScale; gq.scale_cols = D;
             M3R_OK(gemm(c, dt, EPI_STORE16, gq, s));
         }
@@ -949,12 +1006,21 @@ extern "C" int must3r_hip_decode(must3r_hip_ctx* c, const must3r_hip_decode_args
         }
         M3R_OK(attention(c, dt, aa, ca_flops, PC_ATTN_CA, s));
         M3R_OK(w16p(c, *LP[LF_CPW], dt, &w, s));
-        M3R_OK(gemm(c, dt, EPI_RESID_F32, gargs(a16, w, LP[LF_CPB]->d, x, R, D, D, D, D), s));
+        {
+            GemmArgs gp = gargs(a16, w, LP[LF_CPB]->d, x, R, D, D, D, D);
+            if (lnf) fold_out(gp, nullptr);
+            M3R_OK(gemm(c, dt, EPI_RESID_F32, gp, s));
+        }
         // --- MLP (layers.py:98)
-        M3R_OK(layernorm(c, dt, x, nullptr, LP[LF_N3W]->d, LP[LF_N3B]->d, h16, nullptr, nullptr, nullptr,
-                         R, D, 1e-6f, s));
-        M3R_OK(w16p(c, *LP[LF_FC1W], dt, &w, s));
-        M3R_OK(gemm(c, dt, EPI_STORE16_GELU, gargs(h16, w, LP[LF_FC1B]->d, g16, R, F, D, D, F), s));
+        if (!lnf)
+            M3R_OK(layernorm(c, dt, x, nullptr, LP[LF_N3W]->d, LP[LF_N3B]->d, h16, nullptr, nullptr, nullptr,
+                             R, D, 1e-6f, s));
+        M3R_OK(w16p(c, *LP[lnf ? LF_FC1LN_W : LF_FC1W], dt, &w, s));
+        {
+            GemmArgs g1 = gargs(h16, w, LP[LF_FC1B]->d, g16, R, F, D, D, F);
+            if (lnf) fold_in(g1, LF_FC1LN_S);
+            M3R_OK(gemm(c, dt, EPI_STORE16_GELU, g1, s));
+        }
         M3R_OK(w16p(c, *LP[LF_FC2W], dt, &w, s));
         if (fc2_splitk) {
             GemmArgs gs = gargs(g16, w, nullptr, slabs, R, D, F, F, D);
@@ -962,7 +1028,9 @@ extern "C" int must3r_hip_decode(must3r_hip_ctx* c, const must3r_hip_decode_args
             M3R_OK(gemm(c, dt, EPI_F32, gs, s));
             pending_bias = LP[LF_FC2B]->d;
         } else {
-            M3R_OK(gemm(c, dt, EPI_RESID_F32, gargs(g16, w, LP[LF_FC2B]->d, x, R, D, F, F, D), s));
+            GemmArgs g2 = gargs(g16, w, LP[LF_FC2B]->d, x, R, D, F, F, D);
+            if (lnf && l + 1 < L) fold_out(g2, newmem + (size_t)(l + 1) * R * D);   // the next block's norm1 input
+            M3R_OK(gemm(c, dt, EPI_RESID_F32, g2, s));
         }
         if (A->feats && l < L - 1)   // return_feats: the residual stream after block l (decoder.py:321)
             HIP_OK(hipMemcpyAsync(A->feats + (size_t)l * R * D, x, (size_t)R * D * sizeof(float), hipMemcpyDeviceToDevice, s));
@@ -1140,6 +1208,23 @@ extern "C" int must3r_hip_op_gemm(int dtype, int epi, const void* A, const void*
     a.ntok = ntok; a.gw = gw; a.H = H; a.Wimg = W_img; a.wsplit = wsplit;
     const char* err = "";
     if (launch_gemm((DType)dtype, (Epi)epi, a, reinterpret_cast<hipStream_t>(stream), &err)) return fail("%s", err);
+    return 0;
+}
+
+extern "C" int must3r_hip_op_gemm_lnfold(int dtype, int epi, const void* A, const void* W2, const float* bias, void* out, int M, int N, int K,
+                                         int lda, int ldc, void* x16_out, float* copy32_out, float* stats_out, const float* ln_stats,
+                                         const float* ln_s, float ln_eps, const int64_t* pos, const float* rope_tab, int rope_cols,
+                                         int rope_npos, float out_scale, int scale_cols, void* stream) {
+    if (dtype != MUST3R_F16) return fail("op_gemm_lnfold: fp16 operands with split weights only");
+    if (epi < 0 || epi >= EPI_COUNT) return fail("op_gemm_lnfold: bad epilogue");
+    GemmArgs a = gargs(A, W2, bias, out, M, N, K, lda, ldc);
+    a.wsplit = 2;
+    a.x16_out = x16_out; a.copy32_out = copy32_out; a.stats_out = stats_out;
+    a.ln_stats = ln_stats; a.ln_s = ln_s; a.ln_eps = ln_eps;
+    a.pos = pos; a.rope_tab = rope_tab; a.rope_cols = rope_cols; a.rope_npos = rope_npos;
+    a.out_scale = out_scale; a.scale_cols = scale_cols;
+    const char* err = "";
+    if (launch_gemm(DT_F16, (Epi)epi, a, reinterpret_cast<hipStream_t>(stream), &err)) return fail("%s", err);
     return 0;
 }
 

@@ -439,3 +439,78 @@ def test_im2col_cast_postprocess(lib, dt):
     r = R.postprocess(pm.cpu())
     for k in r:
         assert torch.allclose(o[k].cpu(), r[k], rtol=1e-5, atol=1e-6), k
+
+
+@pytest.mark.parametrize("M", [768, 196])
+def test_gemm_ln_fold(lib, M):
+    """LN fold of the one-view memory update (must3r_hip_op_gemm_lnfold): a residual GEMM leaves the new rows rounded to fp16 plus per
+    row and 16-column fragment (sum, sum of squares); the Linear that follows multiplies the RAW rows by gamma (.) W and normalises after
+    the product: epi(rstd (x W'^T - mu s) + c) = epi(LN(x) W^T + b).  Checked against fp64 for the three consumers of a decoder block
+    (projq: store + scale, fc1: GELU, qkv: RoPE) and against the unfolded HIP route (LayerNorm kernel + GEMM)."""
+    from oracle import must3r_ref as R
+    D = 768
+    g = torch.Generator(device="cuda").manual_seed(11 + M)
+    L = lib.load()
+    # ---- producer: x += a Wp^T + bp
+    x0 = torch.randn((M, D), device="cuda", generator=g) * (1.0 + 3.0 * torch.rand((M, 1), device="cuda", generator=g)) + \
+        0.7 * torch.randn((M, 1), device="cuda", generator=g)
+    a = torch.randn((M, D), device="cuda", generator=g).half()
+    Wp = torch.randn((D, D), device="cuda", generator=g) / math.sqrt(D)
+    bp = torch.randn((D,), device="cuda", generator=g)
+    x = x0.clone()
+    x16 = torch.empty((M, D), device="cuda", dtype=torch.float16)
+    cp = torch.empty((M, D), device="cuda")
+    st = torch.full((M, D // 16, 2), float("nan"), device="cuda")
+    lib.check(L.must3r_hip_op_gemm_lnfold(1, lib.EPI_RESID_F32, P(a), P(_split_w(Wp)), P(bp), P(x), M, D, D, D, D, P(x16), P(cp), P(st),
+                                          None, None, 0.0, None, None, 0, 0, 0.0, 0, stream()))
+    torch.cuda.synchronize()
+    want = x0.double() + a.double() @ Wp.double().t() + bp.double()
+    assert torch.allclose(x.double(), want, rtol=1e-5, atol=1e-4) and torch.equal(cp, x) and torch.equal(x16, x.half())
+    fr = x.double().view(M, D // 16, 16)
+    assert torch.allclose(st[..., 0].double(), fr.sum(-1), rtol=1e-5, atol=1e-4)
+    assert torch.allclose(st[..., 1].double(), (fr * fr).sum(-1), rtol=1e-5, atol=1e-3)
+    # ---- consumers
+    gam = 1.0 + 0.3 * torch.randn((D,), device="cuda", generator=g)
+    bet = 0.2 * torch.randn((D,), device="cuda", generator=g)
+    ln = torch.nn.functional.layer_norm(x.double(), (D,), gam.double(), bet.double(), 1e-6)
+    h16 = torch.empty((M, D), device="cuda", dtype=torch.float16)
+    lib.check(L.must3r_hip_op_layernorm(1, P(x), None, P(gam), P(bet), P(h16), None, None, None, M, D, 1e-6, stream()))
+    gh, gw = (24, 32) if M == 768 else (14, 14)
+    ys, xs = torch.meshgrid(torch.arange(gh), torch.arange(gw), indexing="ij")
+    pos = torch.stack((ys.reshape(-1), xs.reshape(-1)), -1).contiguous().cuda()
+    buf = (C.c_float * (64 * 32))()
+    L.must3r_hip_rope_table(100.0, 1.0, 64, buf)
+    tab = torch.tensor(list(buf), device="cuda")
+    errs = {}
+    for name, epi, N, scale in (("projq", lib.EPI_STORE16, 768, 0.18), ("fc1", lib.EPI_STORE16_GELU, 3072, 0.0), ("qkv", lib.EPI_QKV_ROPE, 2304, 0.18)):
+        W = torch.randn((N, D), device="cuda", generator=g) / math.sqrt(D)
+        b = torch.randn((N,), device="cuda", generator=g)
+        Wg = W * gam
+        s_n = Wg.double().sum(1).float()
+        c_n = (W.double() @ bet.double() + b.double()).float()
+        out = torch.empty((M, N), device="cuda", dtype=torch.float16)
+        rope = epi == lib.EPI_QKV_ROPE
+        lib.check(L.must3r_hip_op_gemm_lnfold(1, epi, P(x16), P(_split_w(Wg)), P(c_n), P(out), M, N, D, D, N, None, None, None, P(st), P(s_n),
+                                              1e-6, P(pos) if rope else None, P(tab) if rope else None, 2 * D if rope else 0,
+                                              64 if rope else 0, scale, D if scale else 0, stream()))
+        plain = torch.empty((M, N), device="cuda", dtype=torch.float16)
+        lib.check(L.must3r_hip_op_gemm(1, epi, P(h16), P(_split_w(W)), P(b), P(plain), M, N, D, D, N, P(pos) if rope else None,
+                                       P(tab) if rope else None, 2 * D if rope else 0, 64 if rope else 0, None, 0, 0, 0, 0, 0, 0, 2, stream()))
+        torch.cuda.synchronize()
+        y = ln @ W.double().t() + b.double()
+        if epi == lib.EPI_STORE16_GELU:
+            y = torch.nn.functional.gelu(y)
+        if rope:
+            yy = y.cpu().view(1, M, 3, 12, 64)
+            q, k, v = (yy[:, :, i].permute(0, 2, 1, 3).float() for i in range(3))
+            pp = pos.cpu().view(1, M, 2)
+            y = torch.stack((R.rope2d(q, pp), R.rope2d(k, pp), v), dim=2).permute(0, 3, 2, 1, 4).reshape(M, N).double().cuda()
+        if scale:
+            y = y.clone()
+            y[:, :D] *= 0.125 * 1.44269504088896340736 if rope else 0.125 * 1.44269504088896340736
+        # the library folds kQScale = 1/8 * log2(e) only when asked through out_scale: use the same factor here
+        if scale:
+            y[:, :D] *= scale / (0.125 * 1.44269504088896340736)
+        errs[name] = (rel_inf(out, y), rel_inf(plain if not scale else plain, y if not scale else y))
+        assert errs[name][0] < 2.5e-3, (name, errs[name])
+    record("gemm_ln_fold", M=M, errs=errs)
