@@ -67,20 +67,24 @@ __device__ __forceinline__ void ln_fold_emit(const GemmArgs& p, const int m, con
 // LN fold, consumer side: (mu, rstd) of the block's BM rows from the producer's fragment sums, left in LDS at sm[BM*TPR*2 + 2*row].
 // NT threads, TPR = NT / BM threads per row, each adds its share of the K/16 fragments in order, thread 0 of a row adds the TPR
 // partial sums in order: deterministic.  Raw barriers (LDS-DMA of the ring prologue may be in flight; __syncthreads would drain it).
+constexpr int LNF_SLOTS = 48;   // K = 768 (the decoder width): 48 fragments per row; launch_gemm refuses anything else
 template <int BM, int NT>
 __device__ __forceinline__ void ln_fold_rows(const GemmArgs& p, const int m0, float* sm, const int tid) {
     constexpr int TPR = NT / BM;
-    static_assert(TPR * BM == NT, "threads per row");
-    const int nslots = p.K >> 4, per = nslots / TPR;
+    constexpr int PER = LNF_SLOTS / TPR;   // fragments per thread: 12 / 8 / 6 / 4 (all loads issued before the first add)
+    static_assert(TPR * BM == NT && PER * TPR == LNF_SLOTS && PER % 2 == 0, "threads per row");
     const int row = tid / TPR, part = tid - row * TPR;
     int m = m0 + row;
     m = m < p.M ? m : p.M - 1;
-    const float* src = p.ln_stats + ((size_t)m * nslots + (size_t)part * per) * 2;
+    const float* src = p.ln_stats + ((size_t)m * LNF_SLOTS + (size_t)part * PER) * 2;
+    f32x4 q[PER / 2];
+#pragma unroll
+    for (int i = 0; i < PER / 2; ++i) q[i] = *reinterpret_cast<const f32x4*>(src + i * 4);
     float s1 = 0.f, s2 = 0.f;
-    for (int i = 0; i < per; i += 2) {
-        const f32x4 q = *reinterpret_cast<const f32x4*>(src + i * 2);
-        s1 += q[0]; s2 += q[1];
-        s1 += q[2]; s2 += q[3];
+#pragma unroll
+    for (int i = 0; i < PER / 2; ++i) {
+        s1 += q[i][0]; s2 += q[i][1];
+        s1 += q[i][2]; s2 += q[i][3];
     }
     sm[(row * TPR + part) * 2] = s1;
     sm[(row * TPR + part) * 2 + 1] = s2;
@@ -1254,8 +1258,8 @@ int launch_gemm(DType dt, Epi epi, const GemmArgs& a, hipStream_t s, const char*
     if (epi == EPI_HEAD && (a.N % 112 != 0 || a.ntok <= 0 || a.gw <= 0)) { *err = "gemm: head epilogue geometry"; return 1; }
     if (a.ln_stats != nullptr) {
         const bool epi_ok = epi == EPI_STORE16 || epi == EPI_STORE16_GELU || epi == EPI_QKV_ROPE;
-        if (!epi_ok || a.ln_s == nullptr || a.wsplit != 2 || dt != DT_F16 || (a.K / 16) % 24 != 0 || (a.batch > 1)) {
-            *err = "gemm: LN fold needs a 16-bit-store epilogue, ln_s, split fp16 weights, K/16 divisible by 24, no batch";
+        if (!epi_ok || a.ln_s == nullptr || a.wsplit != 2 || dt != DT_F16 || a.K != 16 * LNF_SLOTS || (a.batch > 1)) {
+            *err = "gemm: LN fold needs a 16-bit-store epilogue, ln_s, split fp16 weights, K = 768, no batch";
             return 1;
         }
     }

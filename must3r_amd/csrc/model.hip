@@ -780,7 +780,7 @@ extern "C" int must3r_hip_decode(must3r_hip_ctx* c, const must3r_hip_decode_args
     // leave 16-bit rows + per-fragment sums, the Linears that follow normalise after their product (kernels.hpp GemmArgs "LN fold").
     static const bool lnf_on = !(getenv("M3R_LNFOLD") && atoi(getenv("M3R_LNFOLD")) == 0);
     const bool lnf = lnf_on && update && !need_pre_kv && c->wsplit == 2 && dt == DT_F16 && !a8 && !A->feats && A->n_groups == 1 &&
-                     D % 96 == 0 && (D / 16) % 24 == 0 && F % 96 == 0 && true;
+                     D == 768 && F % 96 == 0;
     need = ws_need(need, lnf ? (size_t)R * D : 0, 2);                 // x16: the residual stream rounded to fp16
     need = ws_need(need, lnf ? (size_t)R * (D / 16) * 2 : 0, 4);      // per row and 16-column fragment (sum, sum of squares)
     // One-view update calls: the K = 4 D fc2 of every block runs as a split-K GEMM on 96 x 96 tiles (64 tiles x 4 K-ranges = one
