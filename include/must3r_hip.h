@@ -170,11 +170,13 @@ int must3r_hip_op_gemm(int dtype, int epi, const void* A, const void* W, const f
  * ldc), an optional fp32 copy (copy32_out) and per row and 16-column fragment (sum x, sum x^2) into stats_out [M][N/16][2].
  * Consumer role (epi = STORE16 / STORE16_GELU / QKV_ROPE; ln_stats != NULL): A = those raw fp16 rows, W2 = split fp16 copy of gamma (.) W,
  * bias = W beta + b, ln_s[n] = sum_k (gamma (.) W)[n][k]; out = epi(rstd_m (A W2^T - mu_m ln_s) + bias) = epi(LN(x) W^T + b).
+ * ln_shift [M] (optional): the producer rounds and sums x - ln_shift[m] (an estimate of the row mean: the mean the previous consumer
+ * measured), the consumer adds the mean it measures to it (ln_shift_init: the buffer holds nothing yet).
  * must3r/model/blocks/layers.py:91-99 (norm1 -> attn.qkv, norm2 -> cross_attn.projq, norm3 -> mlp.fc1). */
 int must3r_hip_op_gemm_lnfold(int dtype, int epi, const void* A, const void* W2, const float* bias, void* out, int M, int N, int K,
                               int lda, int ldc, void* x16_out, float* copy32_out, float* stats_out, const float* ln_stats,
-                              const float* ln_s, float ln_eps, const int64_t* pos, const float* rope_tab, int rope_cols, int rope_npos,
-                              float out_scale, int scale_cols, void* stream);
+                              const float* ln_s, float ln_eps, float* ln_shift, int ln_shift_init, const int64_t* pos,
+                              const float* rope_tab, int rope_cols, int rope_npos, float out_scale, int scale_cols, void* stream);
 /* split-K form of the Linear above (fp16 activations, split fp16 weights W2 = [W_hi | W_lo], no bias): K is cut into `ksplit`
  * equal ranges and range z stores its fp32 partial product into slabs + z * slab_stride (elements, >= M * ldc).  The consumer adds
  * the slabs in a fixed order (must3r_hip_op_layernorm_slabs): deterministic, no atomics.  N % 96 == 0, (K / 64) % ksplit == 0.

@@ -89,7 +89,7 @@ def load():
     lib.must3r_hip_attention_scratch_bytes.argtypes = [i32, i32, i32]
     lib.must3r_hip_attention_scratch_bytes.restype = C.c_size_t
     lib.must3r_hip_op_layernorm.argtypes = [i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, fp, vp]
-    lib.must3r_hip_op_gemm_lnfold.argtypes = [i32, i32, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, fp, vp, vp, i32, i32, fp, i32, vp]
+    lib.must3r_hip_op_gemm_lnfold.argtypes = [i32, i32, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, fp, vp, i32, vp, vp, i32, i32, fp, i32, vp]
     lib.must3r_hip_op_gemm_splitk.argtypes = [i32, vp, vp, vp, i32, i32, i32, i32, i32, i32, C.c_int64, vp]
     lib.must3r_hip_op_layernorm_slabs.argtypes = [i32, vp, vp, i32, C.c_int64, vp, vp, vp, vp, vp, i32, i32, fp, vp]
     lib.must3r_hip_op_im2col.argtypes = [i32, vp, vp, i32, i32, i32, vp]

@@ -49,13 +49,14 @@ __device__ __forceinline__ void epilogue_prefetch(const GemmArgs& p, void* const
 // LN fold, producer side: the new residual values of one lane (4 columns of row m) -> 16-bit copy, optional fp32 copy, and the
 // (sum, sum of squares) of the row's 16-column fragment (the four lanes fg = 0..3 of a row hold one fragment)
 template <class T>
-__device__ __forceinline__ void ln_fold_emit(const GemmArgs& p, const int m, const int n, const int fg, const f32x4 xn) {
+__device__ __forceinline__ void ln_fold_emit(const GemmArgs& p, const int m, const int n, const int fg, const f32x4 xn, const float shift) {
     typedef typename Vec<T>::v4 v4;
-    if (p.x16_out) *reinterpret_cast<v4*>(reinterpret_cast<T*>(p.x16_out) + (size_t)m * p.ldc + n) = cvt4_sat<T>(xn);
     if (p.copy32_out) *reinterpret_cast<f32x4*>(p.copy32_out + (size_t)m * p.ldc + n) = xn;
+    const f32x4 y = xn - shift;   // shift = the row mean the previous consumer measured (0 without one)
+    if (p.x16_out) *reinterpret_cast<v4*>(reinterpret_cast<T*>(p.x16_out) + (size_t)m * p.ldc + n) = cvt4_sat<T>(y);
     if (p.stats_out) {
-        const float s1 = quad_row_sum((xn[0] + xn[1]) + (xn[2] + xn[3]));
-        const float s2 = quad_row_sum((xn[0] * xn[0] + xn[1] * xn[1]) + (xn[2] * xn[2] + xn[3] * xn[3]));
+        const float s1 = quad_row_sum((y[0] + y[1]) + (y[2] + y[3]));
+        const float s2 = quad_row_sum((y[0] * y[0] + y[1] * y[1]) + (y[2] * y[2] + y[3] * y[3]));
         if (fg == 0) {
             float* d = p.stats_out + ((size_t)m * (p.N >> 4) + (n >> 4)) * 2;
             d[0] = s1;
@@ -69,7 +70,7 @@ __device__ __forceinline__ void ln_fold_emit(const GemmArgs& p, const int m, con
 // partial sums in order: deterministic.  Raw barriers (LDS-DMA of the ring prologue may be in flight; __syncthreads would drain it).
 constexpr int LNF_SLOTS = 48;   // K = 768 (the decoder width): 48 fragments per row; launch_gemm refuses anything else
 template <int BM, int NT>
-__device__ __forceinline__ void ln_fold_rows(const GemmArgs& p, const int m0, float* sm, const int tid) {
+__device__ __forceinline__ void ln_fold_rows(const GemmArgs& p, const int m0, float* sm, const int tid, const bool first_col) {
     constexpr int TPR = NT / BM;
     constexpr int PER = LNF_SLOTS / TPR;   // fragments per thread: 12 / 8 / 6 / 4 (all loads issued before the first add)
     static_assert(TPR * BM == NT && PER * TPR == LNF_SLOTS && PER % 2 == 0, "threads per row");
@@ -102,6 +103,9 @@ __device__ __forceinline__ void ln_fold_rows(const GemmArgs& p, const int m0, fl
         var = var > 0.f ? var : 0.f;
         sm[BM * TPR * 2 + row * 2] = mu;
         sm[BM * TPR * 2 + row * 2 + 1] = rsqrtf(var + p.ln_eps);
+        // the blocks of column 0 leave the current row mean for the next producer (the rows were shifted by the previous estimate)
+        if (first_col && p.ln_shift != nullptr && m0 + row < p.M)
+            p.ln_shift[m0 + row] = (p.ln_shift_init ? 0.f : p.ln_shift[m0 + row]) + mu;
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -114,6 +118,10 @@ __device__ __forceinline__ void epilogue_row(const GemmArgs& p, void* const outp
                                              const float ln_mu = 0.f, const float ln_rstd = 0.f) {
     typedef typename Vec<T>::v4 v4;
     const int nb = nw0 + fg * 4;
+    float ln_shift = 0.f;
+    if constexpr (EPI == EPI_RESID_F32 || EPI == EPI_F32) {
+        if (p.ln_shift != nullptr && (p.x16_out != nullptr || p.stats_out != nullptr)) ln_shift = p.ln_shift[m];
+    }
     if constexpr (EPI == EPI_STORE16 || EPI == EPI_STORE16_GELU || EPI == EPI_QKV_ROPE) {
         if (p.ln_stats != nullptr) {   // LN fold: acc = sum_k x_k W'_nk  ->  rstd (acc - mu s_n); c_n comes in as the bias
 #pragma unroll
@@ -178,7 +186,7 @@ __device__ __forceinline__ void epilogue_row(const GemmArgs& p, void* const outp
             f32x4* o = reinterpret_cast<f32x4*>(reinterpret_cast<float*>(outp) + (size_t)m * p.ldc + n);
             const f32x4 xn = (pre != nullptr ? pre->x[j] : *o) + v[j];
             *o = xn;
-            ln_fold_emit<T>(p, m, n, fg, xn);
+            ln_fold_emit<T>(p, m, n, fg, xn, ln_shift);
         } else if constexpr (EPI == EPI_F32) {
             f32x4* o = reinterpret_cast<f32x4*>(reinterpret_cast<float*>(outp) + (size_t)m * p.ldc + n);
             f32x4 x = v[j];
@@ -188,7 +196,7 @@ __device__ __forceinline__ void epilogue_row(const GemmArgs& p, void* const outp
                 x += *reinterpret_cast<const f32x4*>(p.bias2 + n);
             }
             *o = x;
-            ln_fold_emit<T>(p, m, n, fg, x);
+            ln_fold_emit<T>(p, m, n, fg, x, ln_shift);
         } else if constexpr (EPI == EPI_HEAD) {
             // permuted feature n = (i*16 + jj)*7 + c ; token t of view vv at grid (gy, gx)
             const int vv = m / p.ntok, t = m - vv * p.ntok;
@@ -298,7 +306,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN) gemm_kernel(const GemmArgs p) 
     constexpr bool LNF = EPI == EPI_STORE16 || EPI == EPI_STORE16_GELU || EPI == EPI_QKV_ROPE;
     float* const sm_ln = reinterpret_cast<float*>(smem + (size_t)NST * (BM + WS * BN) * BK * sizeof(T));
     if constexpr (LNF) {
-        if (p.ln_stats != nullptr) ln_fold_rows<BM, 64 * NW>(p, m0, sm_ln, tid);
+        if (p.ln_stats != nullptr) ln_fold_rows<BM, 64 * NW>(p, m0, sm_ln, tid, n0 == 0);
     }
 
     auto compute = [&](int buf) {
@@ -770,7 +778,7 @@ __global__ void __launch_bounds__(576) gemm48_kernel(const GemmArgs p) {
     for (int t = 0; t < NST - 1; ++t)
         if (t < nk) stage(t, t);
     if constexpr (LNF) {   // LN fold: the row statistics are gathered while the ring prologue is in flight
-        if (p.ln_stats != nullptr) ln_fold_rows<BM, 64 * NW>(p, m0, sm_ln, tid);
+        if (p.ln_stats != nullptr) ln_fold_rows<BM, 64 * NW>(p, m0, sm_ln, tid, n0 == 0);
     }
     int buf = 0;
     for (int kt = 0; kt < nk; ++kt) {
@@ -949,7 +957,7 @@ __global__ void __launch_bounds__(576) gemm96_kernel(const GemmArgs p) {
         for (int t = 0; t < NST; ++t)
             if (t < nk) stage(t, t);
         if constexpr (LNF) {   // LN fold: the row statistics are gathered while the ring prologue is in flight
-            if (p.ln_stats != nullptr) ln_fold_rows<BM, 64 * NW>(p, m0, sm_ln, tid);
+            if (p.ln_stats != nullptr) ln_fold_rows<BM, 64 * NW>(p, m0, sm_ln, tid, n0 == 0);
         }
         // tile 0 landed: up to NST-1 younger tiles in flight
         if (nk >= NST) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 1) * TP) : "memory");
@@ -1005,7 +1013,7 @@ __global__ void __launch_bounds__(576) gemm96_kernel(const GemmArgs p) {
     for (int t = 0; t < NST - 1; ++t)
         if (t < nk) stage(t, t);
     if constexpr (LNF) {
-        if (p.ln_stats != nullptr) ln_fold_rows<BM, 64 * NW>(p, m0, sm_ln, tid);
+        if (p.ln_stats != nullptr) ln_fold_rows<BM, 64 * NW>(p, m0, sm_ln, tid, n0 == 0);
     }
     int buf = 0;
     for (int kt = 0; kt < nk; ++kt) {

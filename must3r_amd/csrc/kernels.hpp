@@ -61,6 +61,12 @@ struct GemmArgs {
     const float* ln_stats;
     const float* ln_s;
     float ln_eps;
+    //   ln_shift [M]: a per-row estimate of the row mean (the mean the PREVIOUS consumer measured).  The producer rounds and sums
+    //     y = x - shift instead of x, so a common offset of a row does not eat the fp16 mantissa of its small deviations and the one-pass
+    //     variance works on shifted data; nothing changes for the consumer ((y - mean(y)) rstd = (x - mean(x)) rstd), except that its
+    //     column-0 blocks leave shift += mean(y) (= the current row mean) for the next producer.  ln_shift_init: the buffer holds nothing yet.
+    float* ln_shift;
+    int ln_shift_init;
     // split-K (EPI_F32, bias == nullptr): ksplit > 1 cuts K into ksplit equal ranges, range z stores its fp32 partial product into
     // out + z * slab_stride (elements).  The consumer adds the slabs in a fixed order (LnArgs::slabs): deterministic, no atomics.
     int ksplit;

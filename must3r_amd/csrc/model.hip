@@ -783,6 +783,7 @@ extern "C" int must3r_hip_decode(must3r_hip_ctx* c, const must3r_hip_decode_args
                      D == 768 && F % 96 == 0;
     need = ws_need(need, lnf ? (size_t)R * D : 0, 2);                 // x16: the residual stream rounded to fp16
     need = ws_need(need, lnf ? (size_t)R * (D / 16) * 2 : 0, 4);      // per row and 16-column fragment (sum, sum of squares)
+    need = ws_need(need, lnf ? (size_t)R : 0, 4);                     // per row: the mean the last consumer measured (shift of the next rows)
     // One-view update calls: the K = 4 D fc2 of every block runs as a split-K GEMM on 96 x 96 tiles (64 tiles x 4 K-ranges = one
     // block per CU instead of 256 blocks of 48 x 48 over the whole K) that leaves fp32 partial slabs; the residual update
     // x += b + slabs is done by the LayerNorm that reads x next (norm1 of the next block / norm_dec), in a fixed order.
@@ -826,6 +827,8 @@ extern "C" int must3r_hip_decode(must3r_hip_ctx* c, const must3r_hip_decode_args
     uint16_t* yall = update ? ws_take<uint16_t>(c, (size_t)L * R * D) : nullptr;
     uint16_t* x16 = lnf ? ws_take<uint16_t>(c, (size_t)R * D) : nullptr;
     float* lnstats = lnf ? ws_take<float>(c, (size_t)R * (D / 16) * 2) : nullptr;
+    float* lnshift = lnf ? ws_take<float>(c, (size_t)R) : nullptr;
+    bool lnshift_fresh = true;   // nothing measured yet in this call: the first consumer starts the estimate
     float* slabs = fc2_splitk ? ws_take<float>(c, (size_t)KS * R * D) : nullptr;
     char* split_ws = split_bytes ? ws_take<char>(c, split_bytes) : nullptr;
     uint16_t* kvs = kvs_rows ? ws_take<uint16_t>(c, kvs_rows * 2 * D) : nullptr;
@@ -948,9 +951,11 @@ extern "C" int must3r_hip_decode(must3r_hip_ctx* c, const must3r_hip_decode_args
         // LN fold: a consumer reads the raw 16-bit rows + fragment sums its producer left, with the gamma-scaled weight
         auto fold_in = [&](GemmArgs& g_, int fs) {
             g_.A = x16; g_.ln_stats = lnstats; g_.ln_s = LP[fs]->d; g_.bias = LP[fs + 1]->d; g_.ln_eps = 1e-6f;
+            g_.ln_shift = lnshift; g_.ln_shift_init = lnshift_fresh ? 1 : 0;
+            lnshift_fresh = false;
         };
         // ... and a residual GEMM leaves them for the next consumer (copy: the memorised input of the next block, decoder.py:304-305)
-        auto fold_out = [&](GemmArgs& g_, float* copy) { g_.x16_out = x16; g_.stats_out = lnstats; g_.copy32_out = copy; };
+        auto fold_out = [&](GemmArgs& g_, float* copy) { g_.x16_out = x16; g_.stats_out = lnstats; g_.copy32_out = copy; g_.ln_shift = lnshift; };
         if (!lnf)
             M3R_OK(layernorm_a(c, dt, with_slabs(lnargs(x, nullptr, LP[LF_N1W]->d, LP[LF_N1B]->d, h16, nullptr, nullptr,
                                                        update ? newmem + (size_t)l * R * D : nullptr, R, D, 1e-6f)), s));
@@ -1213,14 +1218,14 @@ extern "C" int must3r_hip_op_gemm(int dtype, int epi, const void* A, const void*
 
 extern "C" int must3r_hip_op_gemm_lnfold(int dtype, int epi, const void* A, const void* W2, const float* bias, void* out, int M, int N, int K,
                                          int lda, int ldc, void* x16_out, float* copy32_out, float* stats_out, const float* ln_stats,
-                                         const float* ln_s, float ln_eps, const int64_t* pos, const float* rope_tab, int rope_cols,
-                                         int rope_npos, float out_scale, int scale_cols, void* stream) {
+                                         const float* ln_s, float ln_eps, float* ln_shift, int ln_shift_init, const int64_t* pos,
+                                         const float* rope_tab, int rope_cols, int rope_npos, float out_scale, int scale_cols, void* stream) {
     if (dtype != MUST3R_F16) return fail("op_gemm_lnfold: fp16 operands with split weights only");
     if (epi < 0 || epi >= EPI_COUNT) return fail("op_gemm_lnfold: bad epilogue");
     GemmArgs a = gargs(A, W2, bias, out, M, N, K, lda, ldc);
     a.wsplit = 2;
     a.x16_out = x16_out; a.copy32_out = copy32_out; a.stats_out = stats_out;
-    a.ln_stats = ln_stats; a.ln_s = ln_s; a.ln_eps = ln_eps;
+    a.ln_stats = ln_stats; a.ln_s = ln_s; a.ln_eps = ln_eps; a.ln_shift = ln_shift; a.ln_shift_init = ln_shift_init;
     a.pos = pos; a.rope_tab = rope_tab; a.rope_cols = rope_cols; a.rope_npos = rope_npos;
     a.out_scale = out_scale; a.scale_cols = scale_cols;
     const char* err = "";

@@ -454,6 +454,8 @@ def test_gemm_ln_fold(lib, M):
     # ---- producer: x += a Wp^T + bp
     x0 = torch.randn((M, D), device="cuda", generator=g) * (1.0 + 3.0 * torch.rand((M, 1), device="cuda", generator=g)) + \
         0.7 * torch.randn((M, 1), device="cuda", generator=g)
+    x0[:8] += 40.0          # rows whose mean is ~20 standard deviations: what the per-row shift (the previous mean) is for
+    x0[8:16, :3] *= 300.0   # rows with a few massive channels
     a = torch.randn((M, D), device="cuda", generator=g).half()
     Wp = torch.randn((D, D), device="cuda", generator=g) / math.sqrt(D)
     bp = torch.randn((D,), device="cuda", generator=g)
@@ -461,12 +463,22 @@ def test_gemm_ln_fold(lib, M):
     x16 = torch.empty((M, D), device="cuda", dtype=torch.float16)
     cp = torch.empty((M, D), device="cuda")
     st = torch.full((M, D // 16, 2), float("nan"), device="cuda")
+    # without a shift (the first producer of a call): raw rows
     lib.check(L.must3r_hip_op_gemm_lnfold(1, lib.EPI_RESID_F32, P(a), P(_split_w(Wp)), P(bp), P(x), M, D, D, D, D, P(x16), P(cp), P(st),
-                                          None, None, 0.0, None, None, 0, 0, 0.0, 0, stream()))
+                                          None, None, 0.0, None, 0, None, None, 0, 0, 0.0, 0, stream()))
     torch.cuda.synchronize()
     want = x0.double() + a.double() @ Wp.double().t() + bp.double()
     assert torch.allclose(x.double(), want, rtol=1e-5, atol=1e-4) and torch.equal(cp, x) and torch.equal(x16, x.half())
-    fr = x.double().view(M, D // 16, 16)
+    # with the shift a previous consumer left (here: the row means of the old x): rows and sums are those of y = x - shift
+    shift = x0.mean(1).contiguous()
+    x = x0.clone()
+    lib.check(L.must3r_hip_op_gemm_lnfold(1, lib.EPI_RESID_F32, P(a), P(_split_w(Wp)), P(bp), P(x), M, D, D, D, D, P(x16), P(cp), P(st),
+                                          None, None, 0.0, P(shift), 0, None, None, 0, 0, 0.0, 0, stream()))
+    torch.cuda.synchronize()
+    assert torch.allclose(x.double(), want, rtol=1e-5, atol=1e-4) and torch.equal(cp, x)
+    ysh = x - shift[:, None]
+    assert torch.equal(x16, ysh.half())
+    fr = ysh.double().view(M, D // 16, 16)
     assert torch.allclose(st[..., 0].double(), fr.sum(-1), rtol=1e-5, atol=1e-4)
     assert torch.allclose(st[..., 1].double(), (fr * fr).sum(-1), rtol=1e-5, atol=1e-3)
     # ---- consumers
@@ -490,9 +502,10 @@ def test_gemm_ln_fold(lib, M):
         c_n = (W.double() @ bet.double() + b.double()).float()
         out = torch.empty((M, N), device="cuda", dtype=torch.float16)
         rope = epi == lib.EPI_QKV_ROPE
+        sh = shift.clone() if name != "fc1" else torch.full_like(shift, float("nan"))
         lib.check(L.must3r_hip_op_gemm_lnfold(1, epi, P(x16), P(_split_w(Wg)), P(c_n), P(out), M, N, D, D, N, None, None, None, P(st), P(s_n),
-                                              1e-6, P(pos) if rope else None, P(tab) if rope else None, 2 * D if rope else 0,
-                                              64 if rope else 0, scale, D if scale else 0, stream()))
+                                              1e-6, P(sh), 1 if name == "fc1" else 0, P(pos) if rope else None, P(tab) if rope else None,
+                                              2 * D if rope else 0, 64 if rope else 0, scale, D if scale else 0, stream()))
         plain = torch.empty((M, N), device="cuda", dtype=torch.float16)
         lib.check(L.must3r_hip_op_gemm(1, epi, P(h16), P(_split_w(W)), P(b), P(plain), M, N, D, D, N, P(pos) if rope else None,
                                        P(tab) if rope else None, 2 * D if rope else 0, 64 if rope else 0, None, 0, 0, 0, 0, 0, 0, 2, stream()))
@@ -505,12 +518,13 @@ def test_gemm_ln_fold(lib, M):
             q, k, v = (yy[:, :, i].permute(0, 2, 1, 3).float() for i in range(3))
             pp = pos.cpu().view(1, M, 2)
             y = torch.stack((R.rope2d(q, pp), R.rope2d(k, pp), v), dim=2).permute(0, 3, 2, 1, 4).reshape(M, N).double().cuda()
+        y_plain = y   # the unfolded route is called without the scale on the first D columns
         if scale:
             y = y.clone()
-            y[:, :D] *= 0.125 * 1.44269504088896340736 if rope else 0.125 * 1.44269504088896340736
-        # the library folds kQScale = 1/8 * log2(e) only when asked through out_scale: use the same factor here
-        if scale:
-            y[:, :D] *= scale / (0.125 * 1.44269504088896340736)
-        errs[name] = (rel_inf(out, y), rel_inf(plain if not scale else plain, y if not scale else y))
-        assert errs[name][0] < 2.5e-3, (name, errs[name])
+            y[:, :D] *= scale
+        errs[name] = (rel_inf(out, y), rel_inf(plain, y_plain))
+        # the consumer leaves the mean of the rows it normalised for the next producer (init: the buffer held nothing -> mean of y)
+        want_sh = x.double().mean(1) if name != "fc1" else ysh.double().mean(1)
+        assert torch.allclose(sh.double(), want_sh, rtol=1e-5, atol=1e-4), name
+        assert errs[name][0] < max(1e-3, 2 * errs[name][1]), (name, errs[name])
     record("gemm_ln_fold", M=M, errs=errs)
