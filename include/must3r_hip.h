@@ -132,12 +132,19 @@ int must3r_hip_postprocess_cam(const float* pointmaps, int n_views, int H, int W
  *   b_transposed B is an nn.Linear weight [N,K] (the projector, :139-151,169).  sub / bias / resid may be NULL; sub, B and
  *   bias are float64 arrays when is_double, fp32 otherwise.
  * must3r_hip_row_norm: attention = x.norm(dim=-1) (:130-131).
+ * must3r_hip_l2_normalize: F.normalize(x, dim) of a contiguous fp32 tensor seen as [outer, L, inner] (eps 1e-12):
+ *   Whitener(l2norm=dim) (:77-78).  out may alias x.
+ * must3r_hip_layernorm_act_f32: nn.LayerNorm(C, eps) (+ nn.GELU, erf form, when gelu) on fp32 rows: the hidden layers of a
+ *   multi-layer projector (build_projector :139-151, Linear - LayerNorm - GELU stacks); gamma / beta may be NULL.
  * must3r_hip_topk_gather: how_select_local (:91-101): per image the k tokens of largest attention, sorted descending
  *   (ties: lower index first), their features, attentions and int64 indices.  N <= 4096.
  * must3r_hip_weighted_spoc: weighted_spoc (:82-88): normalize(sum_n attn[n] * feat[n,:]). */
 int must3r_hip_affine(int is_double, const float* A, const void* sub, const void* B, int b_transposed, const void* bias,
                       const float* resid, float* out, int M, int N, int K, void* stream);
 int must3r_hip_row_norm(const float* x, int M, int C, float* out, void* stream);
+int must3r_hip_l2_normalize(const float* x, int64_t outer, int L, int64_t inner, float* out, void* stream);
+int must3r_hip_layernorm_act_f32(const float* x, const float* gamma, const float* beta, float eps, int M, int C, int gelu,
+                                 float* out, void* stream);
 int must3r_hip_topk_gather(const float* feat, const float* attn, int n_images, int N, int C, int k, float* out_feat,
                            float* out_attn, int64_t* out_idx, void* stream);
 int must3r_hip_weighted_spoc(const float* feat, const float* attn, int n_images, int N, int C, float* out, void* stream);

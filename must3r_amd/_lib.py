@@ -26,7 +26,7 @@ EXPORTS = (
     "must3r_hip_get_profile", "must3r_hip_debug_tr_probe", "must3r_hip_attention_scratch_bytes",
     "must3r_hip_postprocess_cam", "must3r_hip_postprocess_cam_scratch_bytes",
     "must3r_hip_nn_query", "must3r_hip_quadrant_ids",
-    "must3r_hip_affine", "must3r_hip_row_norm", "must3r_hip_topk_gather", "must3r_hip_weighted_spoc",
+    "must3r_hip_affine", "must3r_hip_row_norm", "must3r_hip_l2_normalize", "must3r_hip_layernorm_act_f32", "must3r_hip_topk_gather", "must3r_hip_weighted_spoc",
     "must3r_hip_op_gemm_splitk", "must3r_hip_op_layernorm_slabs", "must3r_hip_op_gemm_lnfold",
 )
 
@@ -99,6 +99,8 @@ def load():
     lib.must3r_hip_postprocess_cam.argtypes = [vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, C.c_size_t, vp]
     lib.must3r_hip_affine.argtypes = [i32, vp, vp, vp, i32, vp, vp, vp, i32, i32, i32, vp]
     lib.must3r_hip_row_norm.argtypes = [vp, i32, i32, vp, vp]
+    lib.must3r_hip_l2_normalize.argtypes = [vp, C.c_int64, i32, C.c_int64, vp, vp]
+    lib.must3r_hip_layernorm_act_f32.argtypes = [vp, vp, vp, fp, i32, i32, i32, vp, vp]
     lib.must3r_hip_topk_gather.argtypes = [vp, vp, i32, i32, i32, i32, vp, vp, vp, vp]
     lib.must3r_hip_weighted_spoc.argtypes = [vp, vp, i32, i32, i32, vp, vp]
     lib.must3r_hip_nn_query.argtypes = [vp, C.c_int64, vp, C.c_int64, vp, vp]

@@ -166,6 +166,9 @@ int launch_postprocess(const float* pm, float* pts3d, float* pts3d_local, float*
 int launch_gemmx(int is_double, const float* A, const void* sub, const void* B, int b_transposed, const void* bias, const float* resid,
                  float* out, int M, int N, int K, hipStream_t s, const char** err);
 int launch_row_norm(const float* x, int M, int C, float* out, hipStream_t s, const char** err);
+int launch_l2_normalize(const float* x, long long outer, int L, long long inner, float* out, hipStream_t s, const char** err);
+int launch_ln_act_f32(const float* x, const float* gamma, const float* beta, float eps, int M, int C, int gelu, float* out, hipStream_t s,
+                      const char** err);
 int launch_topk_gather(const float* feat, const float* attn, int Bn, int N, int C, int k, float* out_feat, float* out_attn,
                        long long* out_idx, hipStream_t s, const char** err);
 int launch_weighted_spoc(const float* feat, const float* attn, int Bn, int N, int C, float* out, hipStream_t s, const char** err);

@@ -1147,6 +1147,26 @@ extern "C" int must3r_hip_row_norm(const float* x, int M, int C, float* out, voi
     return 0;
 }
 
+extern "C" int must3r_hip_l2_normalize(const float* x, int64_t outer, int L, int64_t inner, float* out, void* stream) {
+    if (outer < 0 || inner < 0 || L < 0) return fail("l2_normalize: negative size");
+    if (outer == 0 || inner == 0 || L == 0) return 0;
+    if (!x || !out) return fail("l2_normalize: null argument");
+    if (outer * inner > (int64_t)0x7fffffff * 4) return fail("l2_normalize: too many vectors");
+    const char* err = nullptr;
+    if (launch_l2_normalize(x, outer, L, inner, out, reinterpret_cast<hipStream_t>(stream), &err)) return fail("%s", err);
+    return 0;
+}
+
+extern "C" int must3r_hip_layernorm_act_f32(const float* x, const float* gamma, const float* beta, float eps, int M, int C, int gelu,
+                                            float* out, void* stream) {
+    if (M < 0 || C <= 0) return fail("layernorm_act_f32: bad shape");
+    if (M == 0) return 0;
+    if (!x || !out) return fail("layernorm_act_f32: null argument");
+    const char* err = nullptr;
+    if (launch_ln_act_f32(x, gamma, beta, eps, M, C, gelu, out, reinterpret_cast<hipStream_t>(stream), &err)) return fail("%s", err);
+    return 0;
+}
+
 extern "C" int must3r_hip_topk_gather(const float* feat, const float* attn, int n_images, int N, int C, int k, float* out_feat,
                                       float* out_attn, int64_t* out_idx, void* stream) {
     if (n_images < 0 || N < 0 || C <= 0 || k < 0) return fail("topk_gather: bad shape");

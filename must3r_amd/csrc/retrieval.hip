@@ -9,6 +9,8 @@
 //   row_norm_kernel      attn[r] = |x[r,:]|_2, wave per row
 //   topk_kernel          per image: bitonic sort of (attn, index) pairs in LDS (N <= 4096), descending, ties by lower
 //                        index; gathers the first k rows of the features
+//   l2_normalize_*       F.normalize along any dimension of a contiguous tensor (Whitener(l2norm=dim))
+//   ln_act_f32_kernel    fp32 LayerNorm + erf GELU: the hidden layers of a multi-layer projector
 //   spoc_kernel          per image: out = normalize(sum_n attn[n] feat[n,:])  (fp32 sums in token order, F.normalize eps 1e-12)
 // Small problems (768 tokens x 1024 features per image): latency matters more than rate; fp64 MFMA peak is 78.6 TFLOP/s.
 #include "common.hpp"
@@ -182,6 +184,77 @@ __global__ void __launch_bounds__(256) l2_normalize_rows_kernel(float* __restric
     }
     const float inv = 1.0f / fmaxf(sqrtf(wave_sum(s)), 1e-12f);      // F.normalize eps
     for (int c = lane; c < C; c += 64) x[(size_t)row * C + c] *= inv;
+}
+
+// F.normalize(x, dim) of a contiguous tensor seen as [outer, L, inner] (Whitener(l2norm=dim), retrieval/model.py:77-78): one thread per
+// (outer, inner) column, fp32 sum of squares in index order, x / max(|x|_2, 1e-12).  inner == 1 takes the wave-per-row kernel above.
+__global__ void __launch_bounds__(256) l2_normalize_strided_kernel(const float* __restrict__ x, long long outer, int L, long long inner,
+                                                                   float* __restrict__ out) {
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= outer * inner) return;
+    const long long o = t / inner, i = t - o * inner;
+    const float* src = x + o * L * inner + i;
+    float* dst = out + o * L * inner + i;
+    float s = 0.f;
+    for (int l = 0; l < L; ++l) {
+        const float v = src[(long long)l * inner];
+        s += v * v;
+    }
+    const float inv = 1.0f / fmaxf(sqrtf(s), 1e-12f);
+    for (int l = 0; l < L; ++l) dst[(long long)l * inner] = src[(long long)l * inner] * inv;
+}
+__global__ void __launch_bounds__(256) l2_normalize_rows_copy_kernel(const float* __restrict__ x, long long M, int C, float* __restrict__ out) {
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= M) return;
+    float s = 0.f;
+    for (int c = lane; c < C; c += 64) {
+        const float v = x[row * C + c];
+        s += v * v;
+    }
+    const float inv = 1.0f / fmaxf(sqrtf(wave_sum(s)), 1e-12f);
+    for (int c = lane; c < C; c += 64) out[row * C + c] = x[row * C + c] * inv;
+}
+
+// nn.LayerNorm (two passes over the row held by one wave: mean, then centred variance) followed by nn.GELU (erf form, libm erff):
+// the hidden layers of a multi-layer projector (retrieval/model.py:139-151: Linear - LayerNorm - GELU stacks), all fp32.
+__global__ void __launch_bounds__(256) ln_act_f32_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, float eps, int M, int C, int gelu,
+                                                          float* __restrict__ out) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= M) return;
+    const float* xr = x + (size_t)row * C;
+    float s = 0.f;
+    for (int c = lane; c < C; c += 64) s += xr[c];
+    const float mu = wave_sum(s) / (float)C;
+    float q = 0.f;
+    for (int c = lane; c < C; c += 64) {
+        const float d = xr[c] - mu;
+        q += d * d;
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)C + eps);
+    for (int c = lane; c < C; c += 64) {
+        float v = (xr[c] - mu) * rstd;
+        v = v * (gamma ? gamma[c] : 1.0f) + (beta ? beta[c] : 0.0f);
+        if (gelu) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+        out[(size_t)row * C + c] = v;
+    }
+}
+
+int launch_l2_normalize(const float* x, long long outer, int L, long long inner, float* out, hipStream_t s, const char** err) {
+    if (outer <= 0 || inner <= 0 || L <= 0) return 0;
+    if (inner == 1) hipLaunchKernelGGL(l2_normalize_rows_copy_kernel, dim3((unsigned)((outer + 3) / 4)), dim3(256), 0, s, x, outer, L, out);
+    else hipLaunchKernelGGL(l2_normalize_strided_kernel, dim3((unsigned)((outer * inner + 255) / 256)), dim3(256), 0, s, x, outer, L, inner, out);
+    if (hipGetLastError() != hipSuccess) { *err = "l2_normalize: launch failed"; return 1; }
+    return 0;
+}
+
+int launch_ln_act_f32(const float* x, const float* gamma, const float* beta, float eps, int M, int C, int gelu, float* out, hipStream_t s,
+                      const char** err) {
+    if (M <= 0) return 0;
+    hipLaunchKernelGGL(ln_act_f32_kernel, dim3((M + 3) / 4), dim3(256), 0, s, x, gamma, beta, eps, M, C, gelu, out);
+    if (hipGetLastError() != hipSuccess) { *err = "ln_act: launch failed"; return 1; }
+    return 0;
 }
 
 int launch_gemmx(int is_double, const float* A, const void* sub, const void* B, int b_transposed, const void* bias, const float* resid,

@@ -4,7 +4,8 @@
 (``prewhiten.m/p`` and ``postwhiten.m/p`` in float64, ``projector.{i}.weight/bias``), so ``load_state_dict`` of a
 reference retrieval checkpoint works unchanged; ``forward_local`` / ``forward_global`` take the encoder tokens
 ``x [B,N,C]`` (cuda fp32) like the reference's (demo/inference.py:40).  Every stage is a native call: float64 centre +
-PCA projection (``must3r_hip_affine``, fp64 MFMA), the projector Linear (fp32 MFMA, exact products), token attention
+PCA projection (``must3r_hip_affine``, fp64 MFMA; ``Whitener(l2norm=dim)`` -> ``must3r_hip_l2_normalize``), the projector Linears (fp32
+MFMA, exact products; hidden layers of a multi-layer projector: ``must3r_hip_layernorm_act_f32``), token attention
 (``must3r_hip_row_norm``), top-k selection + gather (``must3r_hip_topk_gather``) or weighted sum pooling
 (``must3r_hip_weighted_spoc``).  No CPU fallback.  Learning the whitening (``pcawhitenlearn_shrinkage``) and the ASMK
 codebook stay on the host as in the reference (out of scope: SURVEY.md section 8f rank 4 is the front-end only).
@@ -58,8 +59,39 @@ class Whitener(nn.Module):
     def forward(self, x):
         out = affine(x, self.m, self.p, b_transposed=False, double=True).view(x.shape)
         if self.l2norm is not None:
-            raise NotImplementedError("Whitener(l2norm=...) is never constructed by RetrievalModel (retrieval/model.py:115,123)")
+            out = l2_normalize(out, self.l2norm)   # the reference normalises the float64 product (:77-78); here its fp32 rounding
         return out.to(x.dtype)
+
+
+def l2_normalize(x, dim):
+    """F.normalize(x, dim=dim) (eps 1e-12), in place on a contiguous fp32 tensor."""
+    x = _tokens(x, "x")
+    dim = dim % x.dim()
+    outer = 1
+    for d in x.shape[:dim]:
+        outer *= d
+    inner = 1
+    for d in x.shape[dim + 1:]:
+        inner *= d
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.load().must3r_hip_l2_normalize(x.data_ptr(), outer, x.shape[dim], inner, x.data_ptr(), _stream(x)))
+    return x
+
+
+def layernorm_act(x, ln, gelu):
+    """nn.LayerNorm ``ln`` (+ erf GELU) on fp32 rows."""
+    x = _tokens(x, "x")
+    Cd = x.shape[-1]
+    if tuple(ln.normalized_shape) != (Cd,):
+        raise ValueError(f"LayerNorm over {tuple(ln.normalized_shape)} on rows of {Cd}")
+    dev = x.device
+    w = None if ln.weight is None else ln.weight.detach().to(device=dev, dtype=torch.float32).contiguous()
+    b = None if ln.bias is None else ln.bias.detach().to(device=dev, dtype=torch.float32).contiguous()
+    out = torch.empty_like(x)
+    with torch.cuda.device(dev):
+        _lib.check(_lib.load().must3r_hip_layernorm_act_f32(x.data_ptr(), None if w is None else w.data_ptr(), None if b is None else b.data_ptr(),
+                                                            float(ln.eps), x.numel() // Cd, Cd, 1 if gelu else 0, out.data_ptr(), _stream(x)))
+    return out
 
 
 def weighted_spoc(feat, attn):
@@ -108,10 +140,7 @@ class RetrievalModel(nn.Module):
         self.residual = residual
         if residual:
             assert hdims[-1] == self.backbone_dim
-        if len(hdims) > 1:
-            raise NotImplementedError("multi-layer projectors (Linear-LayerNorm-GELU stacks) are not built; the released retrieval "
-                                      "models use hdims=[1024] (retrieval/processor.py:71-75)")
-        self.projector = nn.Identity() if len(hdims) == 0 else nn.Sequential(nn.Linear(self.backbone_dim, hdims[-1]))
+        self.projector = self.build_projector(hdims, residual)
         self.dim = hdims[-1] if len(hdims) > 0 else self.backbone_dim
         self.postwhiten_freq = postwhiten
         self.postwhiten = nn.Identity() if postwhiten is None else Whitener(self.dim)
@@ -126,6 +155,28 @@ class RetrievalModel(nn.Module):
             msg = self.load_state_dict(ckpt["model"], strict=False)
             assert len(msg.unexpected_keys) == 0 and all(k.startswith("backbone") or k.startswith("postwhiten") for k in msg.missing_keys)
 
+    def build_projector(self, hdims, residual):   # retrieval/model.py:139-151: same modules, same state-dict keys
+        d = self.backbone_dim
+        if len(hdims) == 0:
+            return nn.Identity()
+        layers = []
+        for h in hdims[:-1]:
+            layers += [nn.Linear(d, h), nn.LayerNorm(h), nn.GELU()]
+            d = h
+        layers.append(nn.Linear(d, hdims[-1]))
+        return nn.Sequential(*layers)
+
+    def _project(self, pre):
+        """projector(pre) (+ pre): every Linear one fp32 GEMM, LayerNorm + GELU of a hidden layer one kernel."""
+        mods = list(self.projector)
+        h = pre
+        for i in range(0, len(mods) - 1, 3):
+            lin, ln, act = mods[i], mods[i + 1], mods[i + 2]
+            assert isinstance(lin, nn.Linear) and isinstance(ln, nn.LayerNorm) and isinstance(act, nn.GELU)
+            h = layernorm_act(affine(h, None, lin.weight, b_transposed=True, bias=lin.bias), ln, gelu=True)
+        lin = mods[-1]
+        return affine(h, None, lin.weight, b_transposed=True, bias=lin.bias, resid=pre if self.residual else None)
+
     @torch.no_grad()
     def extract_features_and_attention(self, x):   # retrieval/model.py:165-172
         x = _tokens(x, "x")
@@ -133,8 +184,7 @@ class RetrievalModel(nn.Module):
         if isinstance(self.projector, nn.Identity):
             proj = pre if not self.residual else pre + pre
         else:
-            lin = self.projector[0]
-            proj = affine(pre, None, lin.weight, b_transposed=True, bias=lin.bias, resid=pre if self.residual else None)
+            proj = self._project(pre)
         Bn, N, Cd = proj.shape
         attention = torch.empty((Bn, N), dtype=torch.float32, device=proj.device)
         with torch.cuda.device(proj.device):

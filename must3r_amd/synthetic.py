@@ -142,17 +142,26 @@ def make_overlap_frames(seed, n_kf=3, H=24, W=32):
     return frames
 
 
-def make_retrieval_state_dict(dim, seed=0, prewhiten=True, postwhiten=True):
+def make_retrieval_state_dict(dim, seed=0, prewhiten=True, postwhiten=True, hdims=None):
     """Seeded RetrievalModel state dict (reference keys, retrieval/model.py:104-151): whiteners with a non-trivial mean and a
-    well-conditioned random projection (float64), xavier Linear projector with a non-zero bias."""
+    well-conditioned random projection (float64), xavier Linear projector with a non-zero bias.  ``hdims`` (default ``[dim]``):
+    a multi-layer projector gets LayerNorms with non-trivial affine parameters between its Linears (build_projector :139-151)."""
     g = torch.Generator().manual_seed(1000 + seed)
+    hdims = [dim] if hdims is None else list(hdims)
+    out_dim = hdims[-1] if hdims else dim
     sd = {}
-    for name, on in (("prewhiten", prewhiten), ("postwhiten", postwhiten)):
+    for name, on, d in (("prewhiten", prewhiten, dim), ("postwhiten", postwhiten, out_dim)):
         if on:
-            sd[name + ".m"] = (torch.randn((1, dim), generator=g, dtype=torch.float64) * 0.1)
-            q, _ = torch.linalg.qr(torch.randn((dim, dim), generator=g, dtype=torch.float64))
-            sd[name + ".p"] = q * (0.5 + torch.rand((dim,), generator=g, dtype=torch.float64))[None, :]
-    bound = (6.0 / (2 * dim)) ** 0.5
-    sd["projector.0.weight"] = (torch.rand((dim, dim), generator=g) * 2 - 1) * bound
-    sd["projector.0.bias"] = torch.randn((dim,), generator=g) * 0.02
+            sd[name + ".m"] = (torch.randn((1, d), generator=g, dtype=torch.float64) * 0.1)
+            q, _ = torch.linalg.qr(torch.randn((d, d), generator=g, dtype=torch.float64))
+            sd[name + ".p"] = q * (0.5 + torch.rand((d,), generator=g, dtype=torch.float64))[None, :]
+    d = dim
+    for j, h in enumerate(hdims):
+        bound = (6.0 / (d + h)) ** 0.5
+        sd[f"projector.{3 * j}.weight"] = (torch.rand((h, d), generator=g) * 2 - 1) * bound
+        sd[f"projector.{3 * j}.bias"] = torch.randn((h,), generator=g) * 0.02
+        if j + 1 < len(hdims):
+            sd[f"projector.{3 * j + 1}.weight"] = 1.0 + 0.2 * torch.randn((h,), generator=g)
+            sd[f"projector.{3 * j + 1}.bias"] = 0.1 * torch.randn((h,), generator=g)
+        d = h
     return sd

@@ -157,6 +157,21 @@ def make_retrieval():
             feat, attn, idx = model.forward_local(x)
             glob = model.forward_global(x)
         out.update({tag + "/feat": feat.numpy(), tag + "/attn": attn.numpy(), tag + "/idx": idx.numpy(), tag + "/glob": glob.numpy()})
+    # multi-layer projector (build_projector: Linear - LayerNorm - GELU - Linear) and Whitener(l2norm=dim)
+    model = RM.RetrievalModel(_Backbone(), prewhiten=-1, postwhiten=-1, hdims=[320, 192], nfeat=20).eval()
+    sd = S.make_retrieval_state_dict(256, seed=4, hdims=[320, 192])
+    msg = model.load_state_dict(sd, strict=False)
+    assert not msg.unexpected_keys and not [k for k in msg.missing_keys if not k.startswith("backbone")], msg
+    x = torch.randn((3, 48, 256), generator=torch.Generator().manual_seed(6))
+    with torch.no_grad():
+        feat, attn, idx = model.forward_local(x)
+        glob = model.forward_global(x)
+    out.update({"deep/feat": feat.numpy(), "deep/attn": attn.numpy(), "deep/idx": idx.numpy(), "deep/glob": glob.numpy()})
+    for dim in (-1, 1):
+        wh = RM.Whitener(256, l2norm=dim)
+        wh.load_state_dict({"m": sd["prewhiten.m"], "p": sd["prewhiten.p"]})
+        with torch.no_grad():
+            out[f"l2norm{dim}/out"] = wh(x).numpy()
     np.savez_compressed(os.path.join(OUT, "retrieval_small.npz"), **out)
     print("retrieval_small", {k: v.shape for k, v in out.items()})
 

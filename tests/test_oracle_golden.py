@@ -179,3 +179,11 @@ def test_retrieval_oracle_matches_reference_fixture():
         assert np.array_equal(i.numpy(), g[tag + "/idx"]) and np.array_equal(a.numpy(), g[tag + "/attn"])
         assert np.array_equal(f.numpy(), g[tag + "/feat"])
         assert np.array_equal(RR.forward_global(sd, x, resid).numpy(), g[tag + "/glob"])
+    # multi-layer projector and Whitener(l2norm=dim)
+    sd = S.make_retrieval_state_dict(256, seed=4, hdims=[320, 192])
+    x = torch.randn((3, 48, 256), generator=torch.Generator().manual_seed(6))
+    f, a, i = RR.forward_local(sd, x, 20)
+    assert np.array_equal(i.numpy(), g["deep/idx"]) and np.array_equal(a.numpy(), g["deep/attn"]) and np.array_equal(f.numpy(), g["deep/feat"])
+    assert np.array_equal(RR.forward_global(sd, x).numpy(), g["deep/glob"])
+    for dim in (-1, 1):
+        assert np.array_equal(RR.whiten(x, sd["prewhiten.m"], sd["prewhiten.p"], l2norm=dim).numpy(), g[f"l2norm{dim}/out"])

@@ -199,7 +199,7 @@ def test_get_overlap_score_equals_reference_source(mode, subsamp):
 
 
 @pytest.mark.parametrize("cfg", [dict(prewhiten=-1, postwhiten=-1), dict(prewhiten=None, postwhiten=-1, residual=True),
-                                 dict(prewhiten=None, postwhiten=None)])
+                                 dict(prewhiten=None, postwhiten=None), dict(prewhiten=-1, postwhiten=-1, hdims=[96, 160, 64])])
 def test_retrieval_equals_reference(cfg):
     """must3r/retrieval/model.py RetrievalModel (verbatim import) vs oracle/retrieval_ref.py: local and global paths."""
     from oracle import ref_shims, retrieval_ref as RR
@@ -208,9 +208,11 @@ def test_retrieval_equals_reference(cfg):
 
     class _Backbone(torch.nn.Module):
         embed_dim = 128
-    model = RM.RetrievalModel(_Backbone(), prewhiten=cfg.get("prewhiten"), postwhiten=cfg.get("postwhiten"), hdims=[128],
+    hdims = cfg.get("hdims", [128])
+    model = RM.RetrievalModel(_Backbone(), prewhiten=cfg.get("prewhiten"), postwhiten=cfg.get("postwhiten"), hdims=hdims,
                               residual=cfg.get("residual", False), nfeat=17).eval()
-    sd = S.make_retrieval_state_dict(128, seed=1, prewhiten=cfg.get("prewhiten") is not None, postwhiten=cfg.get("postwhiten") is not None)
+    sd = S.make_retrieval_state_dict(128, seed=1, prewhiten=cfg.get("prewhiten") is not None, postwhiten=cfg.get("postwhiten") is not None,
+                                     hdims=hdims)
     msg = model.load_state_dict(sd, strict=False)
     assert not msg.unexpected_keys and not [k for k in msg.missing_keys if not k.startswith("backbone")]
     x = torch.randn((2, 40, 128), generator=torch.Generator().manual_seed(0))
@@ -220,6 +222,12 @@ def test_retrieval_equals_reference(cfg):
     fo, ao, io = RR.forward_local(sd, x, 17, cfg.get("residual", False))
     go = RR.forward_global(sd, x, cfg.get("residual", False))
     assert torch.equal(i, io) and torch.equal(a, ao) and torch.equal(f, fo) and torch.equal(g, go)
+    if cfg.get("prewhiten") is not None:      # Whitener(l2norm=dim) (:77-78), any dimension
+        for dim in (-1, 1, 0):
+            wh = RM.Whitener(128, l2norm=dim)
+            wh.load_state_dict({"m": sd["prewhiten.m"], "p": sd["prewhiten.p"]})
+            with torch.no_grad():
+                assert torch.equal(wh(x), RR.whiten(x, sd["prewhiten.m"], sd["prewhiten.p"], l2norm=dim))
 
 
 @pytest.mark.parametrize("fb", ["single_linear", None])
@@ -532,3 +540,48 @@ def test_forward_must3r_equals_reference_source():
             out_m, mem_m = forward_must3r((enc, dec), batch, mem_m, render=render, device="cpu", postprocess=RI.postprocess)
             _same(out_m, out_r)
             _same(list(mem_m), list(mem_r))
+
+
+def test_backend_switch_inside_the_reference(tmp_path, monkeypatch):
+    """must3r_amd.backend.install(): the reference's own `must3r.model.load_model` (model/__init__.py:30-50) dispatches to the HIP-backed
+    loader when the module-global switch is on (the attention.py:18-27 pattern), also for modules that imported the name earlier
+    (slam/model.py:10 style), and is the untouched reference function when it is off / after uninstall()."""
+    import types
+    from oracle import ref_shims
+    ref_shims.install()
+    import must3r.model as RM
+    import must3r_amd.backend as hb
+    import must3r_amd.model as HM
+    from must3r_amd.config import TINY
+    orig = RM.load_model
+    early = types.ModuleType("must3r._early_importer")       # a module that did `from must3r.model import load_model` before install()
+    early.load_model = orig
+    monkeypatch.setitem(__import__("sys").modules, "must3r._early_importer", early)
+    # a checkpoint in the reference's format (constructor strings + state dicts)
+    cfg = TINY
+    enc_s = (f"Dust3rEncoder(img_size=({cfg.img_size},{cfg.img_size}), patch_size=16, embed_dim={cfg.enc_dim}, depth={cfg.enc_depth}, "
+             f"num_heads={cfg.enc_heads})")
+    dec_s = (f"MUSt3R(img_size=({cfg.img_size},{cfg.img_size}), patch_size=16, enc_embed_dim={cfg.enc_dim}, embed_dim={cfg.dec_dim}, "
+             f"depth={cfg.dec_depth}, num_heads={cfg.dec_heads}, feedback_type='single_mlp', memory_mode='kv')")
+    ck = tmp_path / "tiny.pth"
+    torch.save({"args": types.SimpleNamespace(encoder=enc_s, decoder=dec_s), "encoder": S.make_encoder_state_dict(cfg, 0),
+                "decoder": S.make_decoder_state_dict(cfg, 0)}, ck)
+    try:
+        hb.install()
+        assert RM.load_model is not orig and early.load_model is RM.load_model and RM.load_model.__wrapped__ is orig
+        assert RM.is_hip_backend_enabled() is False
+        e0, d0 = RM.load_model(str(ck), device="cpu", verbose=False)                 # switch off: the reference's modules
+        assert type(e0).__module__.startswith("must3r.model") and type(d0).__module__.startswith("must3r.model")
+        RM.toggle_hip_backend(True)
+        e1, d1 = early.load_model(str(ck), device="cpu", verbose=False)              # switch on: the HIP-backed mirrors, same state dict
+        assert isinstance(e1, HM.Dust3rEncoder) and isinstance(d1, HM.MUSt3R)
+        assert set(e1.state_dict()) == set(e0.state_dict()) and set(d1.state_dict()) == set(d0.state_dict())
+        for k, v in d0.state_dict().items():
+            assert torch.equal(v, d1.state_dict()[k]), k
+        with pytest.raises(RuntimeError, match="no CPU"):                           # and they have no CPU route: the native path or nothing
+            e1(torch.zeros((1, 3, cfg.img_size, cfg.img_size)), torch.tensor([[cfg.img_size, cfg.img_size]]))
+        RM.toggle_hip_backend(False)
+        assert type(RM.load_model(str(ck), device="cpu", verbose=False)[0]).__module__.startswith("must3r.model")
+    finally:
+        hb.uninstall()
+    assert RM.load_model is orig and early.load_model is orig and not hasattr(RM, "toggle_hip_backend")

@@ -21,9 +21,9 @@ class _Backbone(torch.nn.Module):
         self.embed_dim = d
 
 
-def _model(dim, nfeat, sd, **kw):
+def _model(dim, nfeat, sd, hdims=None, **kw):
     from must3r_amd.retrieval import RetrievalModel
-    m = RetrievalModel(_Backbone(dim), hdims=[dim], nfeat=nfeat, **kw).cuda().eval()
+    m = RetrievalModel(_Backbone(dim), hdims=[dim] if hdims is None else hdims, nfeat=nfeat, **kw).cuda().eval()
     msg = m.load_state_dict(sd, strict=True)
     assert not msg.missing_keys and not msg.unexpected_keys
     return m
@@ -63,6 +63,40 @@ def test_retrieval_vs_oracle(shape):
     assert same == 1.0, same
     assert errs["attn"] < 2e-6 and errs["feat"] < 2e-6 and errs["glob"] < 5e-6, errs
     assert bool((a[:, :-1] >= a[:, 1:]).all())      # sorted descending like torch.topk
+
+
+def test_multilayer_projector_and_l2norm_whitener():
+    """build_projector with hidden layers (retrieval/model.py:139-151: Linear - LayerNorm - GELU stacks) and Whitener(l2norm=dim) (:77-78)
+    against the reference-generated fixture and, at the encoder geometry, against the oracle.  fp32 LayerNorm / erf GELU: 3e-6."""
+    from must3r_amd.retrieval import Whitener
+    g = load_golden("retrieval_small")
+    sd = S.make_retrieval_state_dict(256, seed=4, hdims=[320, 192])
+    x = torch.randn((3, 48, 256), generator=torch.Generator().manual_seed(6))
+    m = _model(256, 20, sd, hdims=[320, 192], prewhiten=-1, postwhiten=-1)
+    assert [k for k in m.state_dict()] == list(sd.keys()) or set(m.state_dict()) == set(sd)
+    f, a, i = m.forward_local(x.cuda())
+    gl = m.forward_global(x.cuda())
+    assert np.array_equal(i.cpu().numpy(), g["deep/idx"])
+    errs = dict(attn=rel_inf(a.cpu(), g["deep/attn"]), feat=rel_inf(f.cpu(), g["deep/feat"]), glob=rel_inf(gl.cpu(), g["deep/glob"]))
+    for dim in (-1, 1):
+        wh = Whitener(256, l2norm=dim).cuda()
+        wh.load_state_dict({"m": sd["prewhiten.m"], "p": sd["prewhiten.p"]})
+        errs[f"l2norm{dim}"] = rel_inf(wh(x.cuda()).cpu(), g[f"l2norm{dim}/out"])
+    # the encoder geometry: 1024 -> 2048 -> 512 -> 1024 with a residual
+    sd2 = S.make_retrieval_state_dict(1024, seed=9, hdims=[2048, 512, 1024])
+    x2 = torch.randn((2, 768, 1024), generator=torch.Generator().manual_seed(8)) * (1.0 + torch.arange(768).view(1, 768, 1) / 768)
+    m2 = _model(1024, 300, sd2, hdims=[2048, 512, 1024], prewhiten=-1, postwhiten=-1, residual=True)
+    f2, a2, i2 = m2.forward_local(x2.cuda())
+    fo, ao, io = RR.forward_local(sd2, x2, 300, True)
+    same = float((i2.cpu() == io).float().mean())
+    errs.update(attn_1024=rel_inf(a2.cpu(), ao), glob_1024=rel_inf(m2.forward_global(x2.cuda()).cpu(), RR.forward_global(sd2, x2, True)), idx_same=same)
+    if same == 1.0:
+        errs["feat_1024"] = rel_inf(f2.cpu(), fo)
+    wh0 = Whitener(1024, l2norm=0).cuda()        # a leading dimension: the strided kernel with inner = N * C
+    wh0.load_state_dict({"m": sd2["prewhiten.m"], "p": sd2["prewhiten.p"]})
+    errs["l2norm0"] = rel_inf(wh0(x2.cuda()).cpu(), RR.whiten(x2, sd2["prewhiten.m"], sd2["prewhiten.p"], l2norm=0))
+    record("retrieval_multilayer", **errs)
+    assert same == 1.0 and all(v < 3e-6 for k, v in errs.items() if k != "idx_same"), errs
 
 
 def test_whitener_is_float64_inside_and_affine_options():
