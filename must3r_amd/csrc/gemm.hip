@@ -21,6 +21,10 @@ namespace m3r {
 
 #ifdef GEMM_TRACE
 __device__ unsigned long long g_gemm_trace[64 * 8];   // scripts/probes/gemm_trace.hip: cycle stamps of block 0 / thread 0
+__device__ unsigned long long g_gemm256_trace[2][64 * 8];   // scripts/probes/gemm256_trace.hip: block 0, lane 0 of wave 0 (group 0) / wave 4 (group 1)
+#define M3R_STAMP256(slot) do { if (blockIdx.x == 0 && lane == 0 && wc == 0 && t < 64) g_gemm256_trace[wr][t * 8 + (slot)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define M3R_STAMP256(slot) do { } while (0)
 #endif
 
 // One output row segment of a lane: v[j][r] = C[m][n = nw0 + j*16 + fg*4 + r] before bias; nw0 = first column of the wave tile.
@@ -634,8 +638,11 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(OCC ==
     }
     int buf = 0;
     for (int t = 0; t < nk; ++t) {
+        M3R_STAMP256(0);
         if (wr == 0) wait_tile(t);
+        M3R_STAMP256(1);
         __builtin_amdgcn_s_barrier();
+        M3R_STAMP256(2);
         // ---- read interval
         const T* base = lds + buf * STAGE;
         v8 af[MF], wf[WS][NF];
@@ -650,9 +657,13 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(OCC ==
             nb = nb >= NST ? nb - NST : nb;
             stage(t + NST - 1, nb);
         }
+        M3R_STAMP256(3);
         if (wr == 1 && t + 1 < nk) wait_tile(t + 1);
+        M3R_STAMP256(4);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        M3R_STAMP256(5);
         __builtin_amdgcn_s_barrier();
+        M3R_STAMP256(6);
         // ---- multiply interval
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -662,6 +673,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(OCC ==
 #pragma unroll
                 for (int j = 0; j < NF; ++j) acc[i][j] = mfma16(wf[part][j], af[i], acc[i][j]);
         __builtin_amdgcn_s_setprio(0);
+        M3R_STAMP256(7);
         buf = buf + 1 == NST ? 0 : buf + 1;
     }
     if (wr == 0) __builtin_amdgcn_s_barrier();
