@@ -1133,11 +1133,18 @@ int launch_attention_phase(DType dt, const AttnArgs& a_in, int phase, hipStream_
     const int ngrp = a.nviews * a.heads;
     // (measured: for the split-KV cross attention the 16-row variant is slower, 24.0 vs 22.7 ms per scene)
     const bool small = nsplit == 1 && (long)ngrp * ((a.max_nq + ATT_QB - 1) / ATT_QB) < 192;
-    static int qw_big = -1;   // experiments: M3R_ATTN_QW = 48 / 64 query rows per wave for the launches that are not `small`
+    // Experiment builds only (make EXTRA=-DM3R_ATTN_EXPERIMENTS): M3R_ATTN_QW = 48 / 64 query rows per wave for the launches that are not
+    // `small` (equal / spilling, profiles/r02_attn3_ablation.txt) and the M3R_ATTN_ABL timing ablations of attn3_kernel, which compute
+    // WRONG results on purpose -- neither is compiled into the product library.
+#ifdef M3R_ATTN_EXPERIMENTS
+    static int qw_big = -1;
     if (qw_big < 0) {
         const char* e = getenv("M3R_ATTN_QW");
         qw_big = e ? atoi(e) : 32;
     }
+#else
+    constexpr int qw_big = 32;
+#endif
     const int qb_rows = small ? 64 : 4 * qw_big;
     const int nqb_abs = (a.max_nq + qb_rows - 1) / qb_rows;
     const int npairs = ngrp * nsplit;
@@ -1165,6 +1172,7 @@ int launch_attention_phase(DType dt, const AttnArgs& a_in, int phase, hipStream_
             if (small) { if (dt == DT_BF16) M3R_LAUNCH_ATTN((attn2_kernel<bf16_t, 16, true>)); else M3R_LAUNCH_ATTN((attn2_kernel<f16_t, 16, true>)); }
             else { if (dt == DT_BF16) M3R_LAUNCH_ATTN((attn2_kernel<bf16_t, 32, true>)); else M3R_LAUNCH_ATTN((attn2_kernel<f16_t, 32, true>)); }
         } else if (variant == 2) {
+#ifdef M3R_ATTN_EXPERIMENTS
             static const int abl = getenv("M3R_ATTN_ABL") ? atoi(getenv("M3R_ATTN_ABL")) : 0;   // timing ablations (wrong results)
             if (!small && dt == DT_F16 && abl == 1) M3R_LAUNCH_ATTN((attn3_kernel<f16_t, 32, 1>));
             else if (!small && dt == DT_F16 && abl == 2) M3R_LAUNCH_ATTN((attn3_kernel<f16_t, 32, 2>));
@@ -1173,12 +1181,15 @@ int launch_attention_phase(DType dt, const AttnArgs& a_in, int phase, hipStream_
             else if (!small && dt == DT_F16 && qw_big == 48) M3R_LAUNCH_ATTN((attn3_kernel<f16_t, 48>));
             else if (!small && dt == DT_F16 && qw_big == 64) M3R_LAUNCH_ATTN((attn3_kernel<f16_t, 64>));
             else
+#endif
             if (small) { if (dt == DT_BF16) M3R_LAUNCH_ATTN((attn3_kernel<bf16_t, 16>)); else M3R_LAUNCH_ATTN((attn3_kernel<f16_t, 16>)); }
             else { if (dt == DT_BF16) M3R_LAUNCH_ATTN((attn3_kernel<bf16_t, 32>)); else M3R_LAUNCH_ATTN((attn3_kernel<f16_t, 32>)); }
         } else if (variant == 0) {
+#ifdef M3R_ATTN_EXPERIMENTS
             if (!small && qw_big == 48 && dt == DT_F16) M3R_LAUNCH_ATTN((attn_kernel<f16_t, 48>));
             else if (!small && qw_big == 64 && dt == DT_F16) M3R_LAUNCH_ATTN((attn_kernel<f16_t, 64>));
             else
+#endif
             if (small) { if (dt == DT_BF16) M3R_LAUNCH_ATTN((attn_kernel<bf16_t, 16>)); else M3R_LAUNCH_ATTN((attn_kernel<f16_t, 16>)); }
             else { if (dt == DT_BF16) M3R_LAUNCH_ATTN((attn_kernel<bf16_t, 32>)); else M3R_LAUNCH_ATTN((attn_kernel<f16_t, 32>)); }
         } else {
