@@ -202,3 +202,38 @@ def test_header_is_plain_c_and_links_from_c(tmp_path):
     err, t16 = r.stdout.strip().split("|")
     import math
     assert "null" in err and abs(float(t16) - math.cos(1.0)) < 1e-6   # angle(p=1, i=0) = f0 = 1
+
+
+def test_backend_switch_dispatch_without_the_reference(monkeypatch):
+    """must3r_amd.backend on a stand-in `must3r.model` (no reference tree needed): install() wraps load_model and re-points early importers,
+    the switch selects the loader, arguments travel unchanged, uninstall() restores everything."""
+    import sys
+    import types
+    import must3r_amd.backend as hb
+    import must3r_amd.model as HM
+    calls = []
+
+    def ref_load_model(chkpt_path, encoder=None, decoder=None, device="cuda", img_size=None, memory_mode=None, verbose=True):
+        calls.append(("ref", chkpt_path, encoder, decoder, device, img_size, memory_mode, verbose))
+        return "ref-enc", "ref-dec"
+
+    pkg, mod, early = types.ModuleType("must3r"), types.ModuleType("must3r.model"), types.ModuleType("must3r.slam_like")
+    mod.load_model = early.load_model = ref_load_model
+    pkg.model = mod
+    for name, m in (("must3r", pkg), ("must3r.model", mod), ("must3r.slam_like", early)):
+        monkeypatch.setitem(sys.modules, name, m)
+    monkeypatch.setattr(HM, "load_model", lambda *a: (calls.append(("hip",) + a), ("hip-enc", "hip-dec"))[1])
+    try:
+        assert hb.install() is mod and hb.install() is mod                    # idempotent
+        assert mod.load_model is early.load_model and mod.load_model.__wrapped__ is ref_load_model
+        assert mod.load_model("a.pth", device="cpu", img_size=224) == ("ref-enc", "ref-dec")
+        mod.toggle_hip_backend(True)
+        assert mod.is_hip_backend_enabled()
+        assert early.load_model("b.pth", None, None, "cuda:1", 512, "kv", False) == ("hip-enc", "hip-dec")
+        mod.toggle_hip_backend(False)
+        assert mod.load_model("c.pth") == ("ref-enc", "ref-dec")
+    finally:
+        hb.uninstall()
+    assert mod.load_model is ref_load_model and early.load_model is ref_load_model and not hasattr(mod, "toggle_hip_backend")
+    assert calls == [("ref", "a.pth", None, None, "cpu", 224, None, True), ("hip", "b.pth", None, None, "cuda:1", 512, "kv", False),
+                     ("ref", "c.pth", None, None, "cuda", None, None, True)]
