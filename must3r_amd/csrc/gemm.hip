@@ -639,7 +639,11 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(OCC ==
     int buf = 0;
     for (int t = 0; t < nk; ++t) {
         M3R_STAMP256(0);
+#if defined(G256_EXP_NOLADDER)   // probe builds only (timing of the hand-over; the last K-tiles would race): one unconditional counted wait
+        if (wr == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NST >= 4 ? 2 * IPT : IPT) : "memory");
+#else
         if (wr == 0) wait_tile(t);
+#endif
         M3R_STAMP256(1);
         __builtin_amdgcn_s_barrier();
         M3R_STAMP256(2);
