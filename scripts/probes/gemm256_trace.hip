@@ -51,5 +51,9 @@ int main() {
     run<256>(15360, 3072, 1024);
     run<256>(15360, 1024, 4096);
     run<128>(15360, 3072, 1024);
+    // fewer busy CUs: is the K-loop step the same when the chip draws less power / shares less L2 and fabric?
+    run<256>(2048, 3072, 4096);    //  96 tiles
+    run<256>(512, 3072, 4096);     //  24 tiles
+    run<256>(256, 256, 4096);      //   1 tile
     return 0;
 }
