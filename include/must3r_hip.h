@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MUST3R_HIP_ABI_VERSION 4
+#define MUST3R_HIP_ABI_VERSION 5
 
 typedef struct must3r_hip_ctx must3r_hip_ctx;
 
@@ -81,7 +81,9 @@ int must3r_hip_finalize_weights(must3r_hip_ctx* ctx, int parts);
 int must3r_hip_encode(must3r_hip_ctx* ctx, int dtype, const float* img, int n_views, int H, int W,
                       float* out_tokens, int64_t* out_pos, void* stream);
 
-/* one aspect-ratio group of a decoder call (one list entry of MUSt3R.forward_list, decoder.py:158) */
+/* one aspect-ratio group of a decoder call (one list entry of MUSt3R.forward_list, decoder.py:158).
+ * With n_scenes = B > 1 every array carries the batch dimension in front, like the reference's tensors (decoder.py:170-186):
+ * tokens [B, n_views, n_tokens, enc_dim], pos [B, n_views, n_tokens, 2], pointmaps [B, n_views, H, W, 7], all contiguous. */
 typedef struct must3r_hip_group {
     const float* tokens;  /* fp32 [n_views, n_tokens, enc_dim] encoder output */
     const int64_t* pos;   /* int64 [n_views, n_tokens, 2] */
@@ -97,18 +99,28 @@ typedef struct must3r_hip_decode_args {
     int32_t first_call;   /* current_mem is None: view 0 of group 0 gets no image2_embed (decoder.py:280-282) */
     int32_t n_groups;
     const must3r_hip_group* groups;
-    int32_t n_mem;        /* Nm: valid memory tokens before this call */
-    /* per decoder layer: 16-bit (e4m3 with MUST3R_ATTN_FP8 + MUST3R_MEM_KV) [capacity, mem_dim] row-major, mem_dim = 2*dec_dim (KV) or dec_dim.
-     * Rows [0,n_mem) are read; unless render, rows [n_mem, n_mem + sum(n_views*n_tokens)) are WRITTEN
-     * (the caller guarantees capacity) -- the in-place form of torch.concatenate at decoder.py:239/330. */
+    int32_t n_mem;        /* Nm: valid memory tokens (per scene) before this call */
+    /* per decoder layer: 16-bit (e4m3 with MUST3R_ATTN_FP8 + MUST3R_MEM_KV) [mem_capacity, mem_dim] row-major, mem_dim = 2*dec_dim (KV)
+     * or dec_dim.  Rows [0,n_mem) are read; unless render, rows [n_mem, n_mem + sum(n_views*n_tokens)) are WRITTEN -- the in-place
+     * form of torch.concatenate at decoder.py:239/330.  The call is refused when they would not fit mem_capacity. */
     void* const* mem;
-    /* optional (`return_feats=True`, decoder.py:344-347 / :258-262): fp32 [dec_depth][R][dec_dim], R = sum(n_views*n_tokens)
-     * in group order; entry l = the residual stream after decoder block l, the last one after norm_dec (decoder.py:150).
-     * NULL = not wanted.  (feats[0] of the reference, the encoder tokens, is the caller's own input.) */
+    /* optional (`return_feats=True`, decoder.py:344-347 / :258-262): fp32 [dec_depth][R][dec_dim], R = n_scenes * sum(n_views*n_tokens),
+     * rows scene-major, then group order; entry l = the residual stream after decoder block l, the last one after norm_dec
+     * (decoder.py:150).  NULL = not wanted.  (feats[0] of the reference, the encoder tokens, is the caller's own input.) */
     float* feats;
+    /* ---- ABI 5 ---- */
+    int32_t mem_capacity; /* rows every scene's buffer can hold (> 0): bounds-checked against n_mem + the rows this call appends */
+    /* B of the reference's tensors (decoder.py:170: x[i] is [B, nimg, Ni, Denc]): n_scenes independent scenes of identical shapes
+     * (same groups, same n_mem) decoded by ONE launch sequence -- M = B x rows in every GEMM, B x views in the attention tables.
+     * Scene b's memory of layer l is mem[l] + b * mem_scene_stride rows (mem_scene_stride >= mem_capacity); the scenes never
+     * interact, results are bit-identical to B calls with n_scenes = 1 wherever the kernels' tile shapes coincide and within the
+     * mode's tolerance otherwise.  0 / 1 = one scene. */
+    int32_t n_scenes;
+    int64_t mem_scene_stride;
 } must3r_hip_decode_args;
 
-/* MUSt3R.forward / forward_list (decoder.py:158-350), batch B = 1. */
+/* MUSt3R.forward / forward_list (decoder.py:158-350).  Render calls whose view tables exceed the library's staging slot
+ * (1365 views) are cut into ranges of scenes / views inside the library: rendered views are independent. */
 int must3r_hip_decode(must3r_hip_ctx* ctx, const must3r_hip_decode_args* args, void* stream);
 
 /* postprocess activation (engine/inference.py:19-27; tools/geometry.py:14-18): pointmaps fp32 [npix,7]

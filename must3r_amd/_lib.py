@@ -15,7 +15,7 @@ ATTN_FP8 = 0x100   # OR-able: fp8 (e4m3) attention operands, include/must3r_hip.
 MEM_KV, MEM_NORM_Y, MEM_RAW = 0, 1, 2
 PART_ENCODER, PART_DECODER = 1, 2
 EPI_STORE16, EPI_STORE16_GELU, EPI_QKV_ROPE, EPI_RESID_F32, EPI_F32, EPI_HEAD = range(6)
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 # every symbol include/must3r_hip.h declares
 EXPORTS = (
@@ -47,7 +47,8 @@ class Group(C.Structure):
 class DecodeArgs(C.Structure):
     _fields_ = [("dtype", C.c_int32), ("mem_mode", C.c_int32), ("render", C.c_int32), ("first_call", C.c_int32),
                 ("n_groups", C.c_int32), ("groups", C.POINTER(Group)), ("n_mem", C.c_int32),
-                ("mem", C.POINTER(C.c_void_p)), ("feats", C.c_void_p)]
+                ("mem", C.POINTER(C.c_void_p)), ("feats", C.c_void_p),
+                ("mem_capacity", C.c_int32), ("n_scenes", C.c_int32), ("mem_scene_stride", C.c_int64)]
 
 
 class ProfRecord(C.Structure):

@@ -196,7 +196,7 @@ __device__ __forceinline__ void epilogue_row(const GemmArgs& p, void* const outp
             f32x4 x = v[j];
             if (p.accumulate) {
                 x += *o;
-            } else if (p.bias2 != nullptr && m >= p.row_start2) {
+            } else if (p.bias2 != nullptr && (p.row_period2 > 0 ? m % p.row_period2 : m) >= p.row_start2) {
                 x += *reinterpret_cast<const f32x4*>(p.bias2 + n);
             }
             *o = x;
@@ -262,8 +262,9 @@ __global__ void __launch_bounds__(64 * WGM * WGN) gemm_kernel(const GemmArgs p) 
 
     const int grp = blockIdx.y;   // grouped launch: independent problems of equal shape
     const T* __restrict__ A = reinterpret_cast<const T*>(p.A) + (size_t)grp * p.strideA;
-    const T* __restrict__ W = reinterpret_cast<const T*>(p.W) + (size_t)grp * p.strideW;
-    const float* __restrict__ bias = p.bias ? p.bias + (size_t)grp * p.strideB : nullptr;
+    const int wgrp = p.wdiv > 1 ? grp / p.wdiv : grp;
+    const T* __restrict__ W = reinterpret_cast<const T*>(p.W) + (size_t)wgrp * p.strideW;
+    const float* __restrict__ bias = p.bias ? p.bias + (size_t)wgrp * p.strideB : nullptr;
     void* const outp = p.out_table ? p.out_table[grp] : p.out;
 
     // ---- staging: one wave instruction moves RPP rows x (BK*2) bytes = 1 KiB
@@ -568,8 +569,9 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(OCC ==
 
     const int grp = blockIdx.y;
     const T* __restrict__ A = reinterpret_cast<const T*>(p.A) + (size_t)grp * p.strideA;
-    const T* __restrict__ W = reinterpret_cast<const T*>(p.W) + (size_t)grp * p.strideW;
-    const float* __restrict__ bias = p.bias ? p.bias + (size_t)grp * p.strideB : nullptr;
+    const int wgrp = p.wdiv > 1 ? grp / p.wdiv : grp;
+    const T* __restrict__ W = reinterpret_cast<const T*>(p.W) + (size_t)wgrp * p.strideW;
+    const float* __restrict__ bias = p.bias ? p.bias + (size_t)wgrp * p.strideB : nullptr;
     void* const outp = p.out_table ? p.out_table[grp] : p.out;
 
     // ---- staging: one wave instruction moves 16 rows x 64 B; per K-tile a wave issues 2 (A) + 2 (W) instructions
@@ -743,8 +745,9 @@ __global__ void __launch_bounds__(576) gemm48_kernel(const GemmArgs p) {
     const int n0 = (bid / nbm) * BN;
     const int grp = blockIdx.y;
     const T* __restrict__ A = reinterpret_cast<const T*>(p.A) + (size_t)grp * p.strideA;
-    const T* __restrict__ W = reinterpret_cast<const T*>(p.W) + (size_t)grp * p.strideW;
-    const float* __restrict__ bias = p.bias ? p.bias + (size_t)grp * p.strideB : nullptr;
+    const int wgrp = p.wdiv > 1 ? grp / p.wdiv : grp;
+    const T* __restrict__ W = reinterpret_cast<const T*>(p.W) + (size_t)wgrp * p.strideW;
+    const float* __restrict__ bias = p.bias ? p.bias + (size_t)wgrp * p.strideB : nullptr;
     void* const outp = p.out_table ? p.out_table[grp] : p.out;
 
     // pieces dealt round-robin: piece = t * NW + wave (split weights: 18 pieces, 2 per wave)
@@ -893,8 +896,9 @@ __global__ void __launch_bounds__(576) gemm96_kernel(const GemmArgs p) {
     const int nk = p.K / BK / (int)gridDim.z;           // K-tiles of this block
     const int kt0 = blockIdx.z * nk;
     const T* __restrict__ A = reinterpret_cast<const T*>(p.A) + (size_t)grp * p.strideA + (size_t)kt0 * BK;
-    const T* __restrict__ W = reinterpret_cast<const T*>(p.W) + (size_t)grp * p.strideW + (size_t)kt0 * BK;
-    const float* __restrict__ bias = p.bias ? p.bias + (size_t)grp * p.strideB : nullptr;
+    const int wgrp = p.wdiv > 1 ? grp / p.wdiv : grp;
+    const T* __restrict__ W = reinterpret_cast<const T*>(p.W) + (size_t)wgrp * p.strideW + (size_t)kt0 * BK;
+    const float* __restrict__ bias = p.bias ? p.bias + (size_t)wgrp * p.strideB : nullptr;
     void* outp = p.out_table ? p.out_table[grp] : p.out;
     if (gridDim.z > 1) outp = reinterpret_cast<float*>(outp) + (size_t)blockIdx.z * p.slab_stride;
 

@@ -38,6 +38,9 @@ struct GemmArgs {
     int batch;               // 0/1 = single problem
     long long strideA, strideW, strideB;   // in elements
     void* const* out_table;  // device array of `batch` output base pointers
+    // wdiv > 1: problems g and g' with g / wdiv == g' / wdiv share weights and bias (W + (g / wdiv) * strideW): the S scenes of a
+    // batched decoder call write their K|V rows of layer l into S different memory buffers with layer l's one projection
+    int wdiv;
     // EPI_QKV_ROPE
     const int64_t* pos;      // [M,2] (y,x)
     const float* rope_tab;   // [npos][16][2] (cos,sin)
@@ -46,6 +49,7 @@ struct GemmArgs {
     // EPI_F32
     const float* bias2;
     int row_start2;
+    int row_period2;         // > 0: bias2 on rows with (m % row_period2) >= row_start2 (batched scenes: the reference view of EVERY scene)
     int accumulate;          // EPI_F32 / EPI_HEAD: add into out, skip bias
     // EPI_HEAD: rows are `ntok`-token views of one aspect ratio
     int ntok, gw, H, Wimg;

@@ -718,9 +718,8 @@ extern "C" int must3r_hip_encode(must3r_hip_ctx* c, int dtype, const float* img,
 // ------------------------------------------------------------------------------------------------
 // decoder  (MUSt3R.forward_list decoder.py:158-265; forward :267-350 is the single-group case)
 // ------------------------------------------------------------------------------------------------
-extern "C" int must3r_hip_decode(must3r_hip_ctx* c, const must3r_hip_decode_args* A, void* stream) {
-    if (!c || !A || !A->groups || !A->mem) return fail("decode: null argument");
-    if (!c->fin_dec) return fail("decode: decoder weights not finalized");
+// one native call = one launch sequence; must3r_hip_decode (below) validates the arguments and cuts oversize render calls
+static int decode_impl(must3r_hip_ctx* c, const must3r_hip_decode_args* A, void* stream) {
     const int adt = A->dtype & ~MUST3R_ATTN_FP8;
     c->attn8 = (A->dtype & MUST3R_ATTN_FP8) ? 1 : 0;
     if (adt != MUST3R_BF16 && adt != MUST3R_F16 && adt != MUST3R_F16_W2) return fail("decode: bad dtype %d", A->dtype);
@@ -740,25 +739,25 @@ extern "C" int must3r_hip_decode(must3r_hip_ctx* c, const must3r_hip_decode_args
     const int OUT = g.patch_size * g.patch_size * 7;
     const char* err = "";
 
-    // ---- row layout: groups, then views, then tokens (x_cat order, decoder.py:211-214)
-    int R = 0, total_views = 0, max_n = 0;
+    // ---- row layout: scenes (batch elements, decoder.py:170-186: B), then groups, then views, then tokens (x_cat order of a scene,
+    //      decoder.py:211-214).  The S scenes of a call never interact (memory, labels and attention are per batch element): they
+    //      share every launch -- M = S x rows-per-scene in the GEMMs, S x views in the attention tables -- and nothing else.
+    const int S = A->n_scenes > 1 ? A->n_scenes : 1;
+    const long long mem_stride = S > 1 ? A->mem_scene_stride : 0;      // memory rows between two scenes' buffers
+    int Rs = 0, views_s = 0, max_n = 0;
     std::vector<int> grow0(A->n_groups);
     for (int gi = 0; gi < A->n_groups; ++gi) {
         const must3r_hip_group& G = A->groups[gi];
-        if (!G.tokens || !G.pos || !G.pointmaps) return fail("decode: null buffer in group %d", gi);
-        if (G.n_views <= 0 || G.n_tokens <= 0) return fail("decode: empty group %d", gi);
-        if (G.H % 16 || G.W % 16 || (G.H / 16) * (G.W / 16) != G.n_tokens)
-            return fail("decode: group %d: %dx%d does not give %d tokens", gi, G.H, G.W, G.n_tokens);
-        grow0[gi] = R;
-        R += G.n_views * G.n_tokens;
-        total_views += G.n_views;
+        grow0[gi] = Rs;
+        Rs += G.n_views * G.n_tokens;
+        views_s += G.n_views;
         if (G.n_tokens > max_n) max_n = G.n_tokens;
     }
-    for (int l = 0; l < L; ++l)
-        if (!A->mem[l]) return fail("decode: null memory buffer for layer %d", l);
+    const int R = S * Rs, total_views = S * views_s;
+    const bool one_block = A->n_groups == 1;                           // a group's [S, n_views, n_tokens] rows ARE the call's row order
     const bool update = !A->render;
-    const bool use_mask = update && (Nm > 0 || total_views > 1);       // decoder.py:199 / :293
-    const bool lone_view = update && total_views == 1 && Nm > 0;       // own tokens excluded -> keys = old memory only
+    const bool use_mask = update && (Nm > 0 || views_s > 1);           // decoder.py:199 / :293
+    const bool lone_view = update && views_s == 1 && Nm > 0;           // own tokens excluded -> keys = old memory only
     const bool need_pre_kv = update && !lone_view;                     // pre-feedback K|V of the new tokens are attended
 
     // ---- workspace
@@ -779,8 +778,9 @@ extern "C" int must3r_hip_decode(must3r_hip_ctx* c, const must3r_hip_decode_args
     // LN fold (one-view update calls, fp16 + split weights): none of the 36 LayerNorm launches of the blocks is issued; the residual GEMMs
     // leave 16-bit rows + per-fragment sums, the Linears that follow normalise after their product (kernels.hpp GemmArgs "LN fold").
     static const bool lnf_on = !(getenv("M3R_LNFOLD") && atoi(getenv("M3R_LNFOLD")) == 0);
+    // (S > 1: the consumers of the fold only exist on the small-M tile shapes; a batched call is past the launch floor the fold removes)
     const bool lnf = lnf_on && update && !need_pre_kv && c->wsplit == 2 && dt == DT_F16 && !a8 && !A->feats && A->n_groups == 1 &&
-                     D == 768 && F % 96 == 0;
+                     S == 1 && D == 768 && F % 96 == 0;
     need = ws_need(need, lnf ? (size_t)R * D : 0, 2);                 // x16: the residual stream rounded to fp16
     need = ws_need(need, lnf ? (size_t)R * (D / 16) * 2 : 0, 4);      // per row and 16-column fragment (sum, sum of squares)
     need = ws_need(need, lnf ? (size_t)R : 0, 4);                     // per row: the mean the last consumer measured (shift of the next rows)
@@ -795,7 +795,7 @@ extern "C" int must3r_hip_decode(must3r_hip_ctx* c, const must3r_hip_decode_args
                             (F / 64) % KS == 0 && (long)((R + 95) / 96) * (D / 96) * KS <= 256;
     need = ws_need(need, fc2_splitk ? (size_t)KS * R * D : 0, 4);   // slabs
     // split-KV cross attention when the launch cannot fill the chip (sequential memory update: one view per call)
-    const int max_nk_ca = A->render ? Nm : Nm + (lone_view ? 0 : R);
+    const int max_nk_ca = A->render ? Nm : Nm + (lone_view ? 0 : Rs);
     const int ca_split = attention_pick_split(total_views, Hh, max_n, max_nk_ca);
     const size_t split_bytes = attention_split_scratch_bytes(ca_split, R, Hh);
     need = ws_need(need, split_bytes, 1);
@@ -804,7 +804,8 @@ extern "C" int must3r_hip_decode(must3r_hip_ctx* c, const must3r_hip_decode_args
     const int mode = A->mem_mode;
     const int memD = mode == MUST3R_MEM_KV ? 2 * D : D;
     const int memES = (a8 && mode == MUST3R_MEM_KV) ? 1 : 2;   // bytes per memory element: e4m3 K|V rows in fp8-attention mode
-    const size_t kvs_rows = mode == MUST3R_MEM_KV ? 0 : (size_t)max_nk_ca;
+    const size_t kvs_rows1 = mode == MUST3R_MEM_KV ? 0 : (size_t)max_nk_ca;   // per scene
+    const size_t kvs_rows = kvs_rows1 * S;
     need = ws_need(need, kvs_rows * 2 * D, 2);
     need = ws_need(need, mode == MUST3R_MEM_RAW ? kvs_rows * D : 0, 2);
     // fp8 attention: e4m3 copies of q|k|v (self) / q (cross), 16-bit staging of freshly projected K|V rows before they are
@@ -843,23 +844,28 @@ extern "C" int must3r_hip_decode(must3r_hip_ctx* c, const must3r_hip_decode_args
     std::vector<AttnView> tab(2 * (size_t)total_views);
     double sa_flops = 0, ca_flops = 0;
     {
+        // K|V rows a scene's cross attention reads: its own memory buffer ('kv': rows b * mem_stride of the layer's buffer) or its slice
+        // of the per-call projection scratch ('norm_y' / 'raw')
+        const long long kv_stride = mode == MUST3R_MEM_KV ? mem_stride : (long long)kvs_rows1;
         int vi = 0;
-        for (int gi = 0; gi < A->n_groups; ++gi) {
-            const must3r_hip_group& G = A->groups[gi];
-            for (int j = 0; j < G.n_views; ++j, ++vi) {
-                const int r0 = grow0[gi] + j * G.n_tokens, n = G.n_tokens;
-                tab[vi] = AttnView{r0, n, r0, n, 0, 0};
-                AttnView cv{r0, n, 0, Nm, 0, 0};
-                if (update) {
-                    if (lone_view) { cv.nk = Nm; }
-                    else if (use_mask) { cv.nk = Nm + R; cv.skip_lo = Nm + r0; cv.skip_hi = Nm + r0 + n; }
-                    else { cv.nk = Nm + R; }  // first view alone: attends its own (pre-feedback) tokens
+        for (int b = 0; b < S; ++b)
+            for (int gi = 0; gi < A->n_groups; ++gi) {
+                const must3r_hip_group& G = A->groups[gi];
+                for (int j = 0; j < G.n_views; ++j, ++vi) {
+                    const int rl = grow0[gi] + j * G.n_tokens, n = G.n_tokens;   // row inside the scene
+                    const int r0 = b * Rs + rl;
+                    tab[vi] = AttnView{r0, n, r0, n, 0, 0};
+                    AttnView cv{r0, n, (int)(b * kv_stride), Nm, 0, 0};
+                    if (update) {
+                        if (lone_view) { cv.nk = Nm; }
+                        else if (use_mask) { cv.nk = Nm + Rs; cv.skip_lo = Nm + rl; cv.skip_hi = Nm + rl + n; }
+                        else { cv.nk = Nm + Rs; }  // first view alone: attends its own (pre-feedback) tokens
+                    }
+                    tab[total_views + vi] = cv;
+                    sa_flops += 4.0 * n * (double)n * D;
+                    ca_flops += 4.0 * n * (double)(cv.nk - (cv.skip_hi - cv.skip_lo)) * D;
                 }
-                tab[total_views + vi] = cv;
-                sa_flops += 4.0 * n * (double)n * D;
-                ca_flops += 4.0 * n * (double)(cv.nk - (cv.skip_hi - cv.skip_lo)) * D;
             }
-        }
     }
     void* tab_dev = nullptr;
     M3R_OK(upload_table(c, tab.data(), sizeof(AttnView) * tab.size(), &tab_dev, s));
@@ -867,31 +873,50 @@ extern "C" int must3r_hip_decode(must3r_hip_ctx* c, const must3r_hip_decode_args
     const AttnView* ca_views = sa_views + total_views;
     const int64_t* pos_all = A->groups[0].pos;  // single group: the caller's array is already [R,2]
 
-    // ---- tokens -> 16 bit, enc->dec projection + image2_embed  (decoder.py:172-181 / :275-287)
-    for (int gi = 0; gi < A->n_groups; ++gi) {
-        const must3r_hip_group& G = A->groups[gi];
-        ProfScope ps(c, s, PC_MISC, 0.0);
-        if (launch_cast(dt, G.tokens, t16 + (size_t)grow0[gi] * C, nullptr, (size_t)G.n_views * G.n_tokens * C, s, &err))
-            return fail("%s", err);
+    // per-(layer, scene) destinations of freshly projected K|V rows: memory rows [Nm, Nm + Rs) of scene b in layer l's buffer;
+    // second half: the 16-bit staging rows the fp8 memory is quantised from
+    void* kvout_dev = nullptr;
+    if (update && mode == MUST3R_MEM_KV) {
+        std::vector<void*> outs(2 * (size_t)L * S);
+        for (int l = 0; l < L; ++l)
+            for (int b = 0; b < S; ++b) {
+                void* memrow = reinterpret_cast<char*>(A->mem[l]) + ((size_t)b * mem_stride + Nm) * 2 * D * memES;
+                outs[(size_t)l * S + b] = a8 ? static_cast<void*>(kv16 + ((size_t)l * S + b) * Rs * 2 * D) : memrow;
+                outs[(size_t)L * S + (size_t)l * S + b] = memrow;
+            }
+        M3R_OK(upload_table(c, outs.data(), sizeof(void*) * outs.size(), &kvout_dev, s));
     }
+    void* const* kvout = reinterpret_cast<void* const*>(kvout_dev);
+
+    // ---- tokens -> 16 bit, enc->dec projection + image2_embed  (decoder.py:172-181 / :275-287)
+    for (int b = 0; b < (one_block ? 1 : S); ++b)
+        for (int gi = 0; gi < A->n_groups; ++gi) {
+            const must3r_hip_group& G = A->groups[gi];
+            const size_t rg = (size_t)G.n_views * G.n_tokens;   // rows of this group per scene
+            ProfScope ps(c, s, PC_MISC, 0.0);
+            if (launch_cast(dt, G.tokens + (size_t)b * rg * C, t16 + ((size_t)b * Rs + grow0[gi]) * C, nullptr, (one_block ? S : 1) * rg * C, s, &err))
+                return fail("%s", err);
+        }
     const void* w;
     {
         M3R_OK(w16(c, "decoder.feat_embed_enc_to_dec.weight", dt, &w, s));
         GemmArgs ga = gargs(t16, w, p32(c, "decoder.feat_embed_enc_to_dec.bias"), x, R, D, C, C, D);
         ga.bias2 = p32(c, "decoder.image2_embed");
-        ga.row_start2 = A->first_call ? A->groups[0].n_tokens : 0;  // reference view (group 0, view 0) gets no embed
+        ga.row_start2 = A->first_call ? A->groups[0].n_tokens : 0;  // reference view (group 0, view 0) of every scene gets no embed
+        ga.row_period2 = S > 1 ? Rs : 0;
         if (lnf) { ga.x16_out = x16; ga.stats_out = lnstats; ga.copy32_out = newmem; }   // block 0's norm1 input (+ its memorised copy)
         M3R_OK(gemm(c, dt, EPI_F32, ga, s));
     }
     // several aspect ratios: gather the positions of all rows into one [R,2] array.  t16 is dead after the
     // projection above (stream order) and is large enough (R*C*2 >= R*16 bytes).
-    if (A->n_groups > 1) {
+    if (!one_block) {
         int64_t* pos_ws = reinterpret_cast<int64_t*>(t16);
-        for (int gi = 0; gi < A->n_groups; ++gi) {
-            const must3r_hip_group& G = A->groups[gi];
-            HIP_OK(hipMemcpyAsync(pos_ws + (size_t)grow0[gi] * 2, G.pos, (size_t)G.n_views * G.n_tokens * 16,
-                                  hipMemcpyDeviceToDevice, s));
-        }
+        for (int b = 0; b < S; ++b)
+            for (int gi = 0; gi < A->n_groups; ++gi) {
+                const must3r_hip_group& G = A->groups[gi];
+                const size_t rg = (size_t)G.n_views * G.n_tokens;
+                HIP_OK(hipMemcpyAsync(pos_ws + ((size_t)b * Rs + grow0[gi]) * 2, G.pos + (size_t)b * rg * 2, rg * 16, hipMemcpyDeviceToDevice, s));
+            }
         pos_all = pos_ws;
     }
 
@@ -899,38 +924,50 @@ extern "C" int must3r_hip_decode(must3r_hip_ctx* c, const must3r_hip_decode_args
     //   'kv'     LN(norm_y) -> [projk | projv]       'norm_y'  LN(norm_y)        'raw'  the tokens themselves
     auto kv_project = [&](int l, const float* src, const float* add, float* copy, hipStream_t st) -> int {
         const std::vector<Param*>& LP = c->dec_tab[l];
-        uint16_t* dst = reinterpret_cast<uint16_t*>(reinterpret_cast<char*>(A->mem[l]) + (size_t)Nm * memD * memES);
-        LnArgs la = lnargs(src, add, LP[LF_NYW]->d, LP[LF_NYB]->d, h16, nullptr, nullptr, copy, R, D, 1e-6f);
-        if (mode == MUST3R_MEM_NORM_Y) la.out16 = dst;
-        if (mode == MUST3R_MEM_RAW) { la.out16 = nullptr; la.raw16 = dst; }
-        M3R_OK(layernorm_a(c, dt, la, st));
-        if (mode != MUST3R_MEM_KV) return 0;
+        if (mode != MUST3R_MEM_KV) {   // the LayerNorm itself writes the scene's memory rows (one launch per scene)
+            for (int b = 0; b < S; ++b) {
+                uint16_t* dst = reinterpret_cast<uint16_t*>(A->mem[l]) + ((size_t)b * mem_stride + Nm) * memD;
+                const size_t o = (size_t)b * Rs * D;
+                LnArgs la = lnargs(src + o, add ? add + o : nullptr, LP[LF_NYW]->d, LP[LF_NYB]->d, nullptr, nullptr, nullptr, copy ? copy + o : nullptr,
+                                   Rs, D, 1e-6f);
+                if (mode == MUST3R_MEM_NORM_Y) la.out16 = dst; else la.raw16 = dst;
+                M3R_OK(layernorm_a(c, dt, la, st));
+            }
+            return 0;
+        }
+        M3R_OK(layernorm_a(c, dt, lnargs(src, add, LP[LF_NYW]->d, LP[LF_NYB]->d, h16, nullptr, nullptr, copy, R, D, 1e-6f), st));
         const void* wk;
         M3R_OK(w16p(c, *LP[LF_PKVW], dt, &wk, st));
-        if (!a8) return gemm(c, dt, EPI_STORE16, gargs(h16, wk, LP[LF_PKVB]->d, dst, R, 2 * D, D, D, 2 * D), st);
-        // fp8 memory: project into the 16-bit staging rows, quantise into the memory rows
-        M3R_OK(gemm(c, dt, EPI_STORE16, gargs(h16, wk, LP[LF_PKVB]->d, kv16, R, 2 * D, D, D, 2 * D), st));
-        return quant8(c, dt, kv16, 2 * D, dst, 2 * D, nullptr, 0, (size_t)R, 2 * D, st);
+        // one problem per scene (same weights): rows [b Rs, (b+1) Rs) -> memory rows of scene b (fp8 memory: 16-bit staging rows first)
+        GemmArgs gk = gargs(h16, wk, LP[LF_PKVB]->d, nullptr, Rs, 2 * D, D, D, 2 * D);
+        gk.batch = S; gk.strideA = (long long)Rs * D; gk.out_table = kvout + (size_t)l * S;
+        if (S == 1) { gk.batch = 0; gk.out_table = nullptr; gk.out = a8 ? static_cast<void*>(kv16) : reinterpret_cast<char*>(A->mem[l]) + (size_t)Nm * memD * memES; }
+        M3R_OK(gemm(c, dt, EPI_STORE16, gk, st));
+        if (!a8) return 0;
+        return quant8(c, dt, kv16 + (size_t)l * S * Rs * 2 * D * (S > 1 ? 1 : 0), 2 * D, S == 1 ? reinterpret_cast<char*>(A->mem[l]) + (size_t)Nm * memD * memES : nullptr,
+                      2 * D, S > 1 ? kvout + (size_t)L * S + (size_t)l * S : nullptr, Rs, (size_t)R, 2 * D, st);
     };
     // K|V rows the cross attention of layer l reads: the memory itself ('kv') or a projection of it into scratch
     auto kv_source = [&](int l, const void** kptr, hipStream_t st) -> int {
         if (mode == MUST3R_MEM_KV) { *kptr = A->mem[l]; return 0; }
         const std::vector<Param*>& LP = c->dec_tab[l];
-        const uint16_t* src = reinterpret_cast<const uint16_t*>(A->mem[l]);
-        const int rows = (int)kvs_rows;
-        if (mode == MUST3R_MEM_RAW) {  // y_ = norm_y(y) on the stored tokens (layers.py:92)
-            LnArgs la = lnargs(nullptr, nullptr, LP[LF_NYW]->d, LP[LF_NYB]->d, ytmp, nullptr, nullptr, nullptr,
-                               rows, D, 1e-6f);
-            la.x16 = src;
-            M3R_OK(layernorm_a(c, dt, la, st));
-            src = ytmp;
-        }
+        const int rows = (int)kvs_rows1;
         const void* wk;
         M3R_OK(w16p(c, *LP[LF_PKVW], dt, &wk, st));
-        M3R_OK(gemm(c, dt, EPI_STORE16, gargs(src, wk, LP[LF_PKVB]->d, kvs, rows, 2 * D, D, D, 2 * D), st));
+        for (int b = 0; b < S; ++b) {
+            const uint16_t* src = reinterpret_cast<const uint16_t*>(A->mem[l]) + (size_t)b * mem_stride * D;
+            if (mode == MUST3R_MEM_RAW) {  // y_ = norm_y(y) on the stored tokens (layers.py:92)
+                LnArgs la = lnargs(nullptr, nullptr, LP[LF_NYW]->d, LP[LF_NYB]->d, ytmp, nullptr, nullptr, nullptr,
+                                   rows, D, 1e-6f);
+                la.x16 = src;
+                M3R_OK(layernorm_a(c, dt, la, st));
+                src = ytmp;
+            }
+            M3R_OK(gemm(c, dt, EPI_STORE16, gargs(src, wk, LP[LF_PKVB]->d, kvs + (size_t)b * rows * 2 * D, rows, 2 * D, D, D, 2 * D), st));
+        }
         *kptr = kvs;
         if (a8) {
-            M3R_OK(quant8(c, dt, kvs, 2 * D, kvs8, 2 * D, nullptr, 0, (size_t)rows, 2 * D, st));
+            M3R_OK(quant8(c, dt, kvs, 2 * D, kvs8, 2 * D, nullptr, 0, (size_t)kvs_rows, 2 * D, st));
             *kptr = kvs8;
         }
         return 0;
@@ -1057,13 +1094,16 @@ extern "C" int must3r_hip_decode(must3r_hip_ctx* c, const must3r_hip_decode_args
         }
         const void* wcat;
         M3R_OK(w3(c, "decoder.head_dec.proj_ps.weight", dt, &wcat, hs_));
-        for (int gi = 0; gi < A->n_groups; ++gi) {
-            const must3r_hip_group& G = A->groups[gi];
-            const int Rg = G.n_views * G.n_tokens;
-            GemmArgs ga = gargs(hcat + (size_t)grow0[gi] * 3 * D, wcat, p32(c, "decoder.head_dec.proj_ps.bias"), G.pointmaps, Rg, OUT, 3 * D, 3 * D, 0);
-            ga.ntok = G.n_tokens; ga.gw = G.W / 16; ga.H = G.H; ga.Wimg = G.W;
-            M3R_OK(gemm(c, dt, EPI_HEAD, ga, hs_));
-        }
+        for (int b = 0; b < (one_block ? 1 : S); ++b)
+            for (int gi = 0; gi < A->n_groups; ++gi) {
+                const must3r_hip_group& G = A->groups[gi];
+                const int rg = G.n_views * G.n_tokens;                       // rows of this group per scene
+                const int Rg = one_block ? S * rg : rg;                      // one group: all scenes in one launch ([S, n, H, W, 7] is contiguous)
+                GemmArgs ga = gargs(hcat + ((size_t)b * Rs + grow0[gi]) * 3 * D, wcat, p32(c, "decoder.head_dec.proj_ps.bias"),
+                                    G.pointmaps + (size_t)b * G.n_views * G.H * G.W * 7, Rg, OUT, 3 * D, 3 * D, 0);
+                ga.ntok = G.n_tokens; ga.gw = G.W / 16; ga.H = G.H; ga.Wimg = G.W;
+                M3R_OK(gemm(c, dt, EPI_HEAD, ga, hs_));
+            }
     }
     if (update) {
         // --- feedback (feedback_mechanism.py:39-53): offset = layer(LN_1e-5(new_mem[L-1])), added to layers 0..L-2;
@@ -1092,29 +1132,110 @@ extern "C" int must3r_hip_decode(must3r_hip_ctx* c, const must3r_hip_decode_args
                                nullptr, nullptr, L * R, D, 1e-6f);
             la.rows_per_group = R; la.add_groups = L - 1;
             M3R_OK(layernorm_a(c, dt, la, s));
-            // fp8 memory: the GEMM writes the 16-bit staging rows [L][R][2D], one grouped quantisation scatters them into the
-            // layers' memory rows
-            std::vector<void*> outs(2 * (size_t)L);
-            for (int l = 0; l < L; ++l) {
-                void* memrow = reinterpret_cast<char*>(A->mem[l]) + (size_t)Nm * 2 * D * memES;
-                outs[l] = a8 ? static_cast<void*>(kv16 + (size_t)l * R * 2 * D) : memrow;
-                outs[L + l] = memrow;
-            }
-            void* outs_dev = nullptr;
-            M3R_OK(upload_table(c, outs.data(), sizeof(void*) * 2 * L, &outs_dev, s));
+            // fp8 memory: the GEMM writes the 16-bit staging rows [L][S][Rs][2D], one grouped quantisation scatters them into the
+            // layers' memory rows.  Problem g = l * S + b: rows of scene b, weights of layer l = g / S.
             const void* wk;
             M3R_OK(w16(c, "decoder.projkv_all.weight", dt, &wk, s));
-            GemmArgs gk = gargs(yall, wk, p32(c, "decoder.projkv_all.bias"), nullptr, R, 2 * D, D, D, 2 * D);
-            gk.batch = L; gk.strideA = (long long)R * D; gk.strideW = (long long)2 * D * D * (c->wsplit == 2 ? 2 : 1);
-            gk.strideB = 2 * D; gk.out_table = reinterpret_cast<void* const*>(outs_dev);
+            GemmArgs gk = gargs(yall, wk, p32(c, "decoder.projkv_all.bias"), nullptr, Rs, 2 * D, D, D, 2 * D);
+            gk.batch = L * S; gk.wdiv = S; gk.strideA = (long long)Rs * D; gk.strideW = (long long)2 * D * D * (c->wsplit == 2 ? 2 : 1);
+            gk.strideB = 2 * D; gk.out_table = kvout;
             M3R_OK(gemm(c, dt, EPI_STORE16, gk, s));
-            if (a8) M3R_OK(quant8(c, dt, kv16, 2 * D, nullptr, 2 * D, reinterpret_cast<void* const*>(outs_dev) + L, R, (size_t)L * R, 2 * D, s));
+            if (a8) M3R_OK(quant8(c, dt, kv16, 2 * D, nullptr, 2 * D, kvout + (size_t)L * S, Rs, (size_t)L * R, 2 * D, s));
         } else {
             for (int l = 0; l < L; ++l)
                 M3R_OK(kv_project(l, newmem + (size_t)l * R * D, l < L - 1 ? off32 : nullptr, nullptr, s));
         }
     }
 
+    return 0;
+}
+
+// MUSt3R.forward / forward_list (decoder.py:158-350).  Validates everything the launches rely on (so that a non-Python caller
+// cannot overrun a memory buffer or a table) and cuts render calls whose view tables would not fit the staging slot: rendered
+// views (and scenes) are independent of each other, the pieces give the same pointmaps.
+extern "C" int must3r_hip_decode(must3r_hip_ctx* c, const must3r_hip_decode_args* A, void* stream) {
+    if (!c || !A || !A->groups || !A->mem) return fail("decode: null argument");
+    if (!c->fin_dec) return fail("decode: decoder weights not finalized");
+    const int adt = A->dtype & ~MUST3R_ATTN_FP8;
+    if (adt != MUST3R_BF16 && adt != MUST3R_F16 && adt != MUST3R_F16_W2) return fail("decode: bad dtype %d", A->dtype);
+    if (A->mem_mode != MUST3R_MEM_KV && A->mem_mode != MUST3R_MEM_NORM_Y && A->mem_mode != MUST3R_MEM_RAW)
+        return fail("decode: bad mem_mode %d", A->mem_mode);
+    if (A->n_groups <= 0) return fail("decode: no input group");
+    if (A->n_mem < 0) return fail("decode: negative n_mem");
+    if (A->render && (A->first_call || A->n_mem <= 0)) return fail("decode: render needs a memory (decoder.py:278)");
+    if (A->first_call && A->n_mem != 0) return fail("decode: first_call with a non-empty memory");
+    if (A->n_scenes < 0) return fail("decode: negative n_scenes");
+    const int S = A->n_scenes > 1 ? A->n_scenes : 1;
+    long long Rs = 0, views_s = 0;
+    for (int gi = 0; gi < A->n_groups; ++gi) {
+        const must3r_hip_group& G = A->groups[gi];
+        if (!G.tokens || !G.pos || !G.pointmaps) return fail("decode: null buffer in group %d", gi);
+        if (G.n_views <= 0 || G.n_tokens <= 0) return fail("decode: empty group %d", gi);
+        if (G.H % 16 || G.W % 16 || (G.H / 16) * (G.W / 16) != G.n_tokens)
+            return fail("decode: group %d: %dx%d does not give %d tokens", gi, G.H, G.W, G.n_tokens);
+        if (G.H / 16 > c->rope_npos || G.W / 16 > c->rope_npos) return fail("decode: group %d: image too large for the RoPE table", gi);
+        Rs += (long long)G.n_views * G.n_tokens;
+        views_s += G.n_views;
+    }
+    for (int l = 0; l < c->cfg.dec_depth; ++l)
+        if (!A->mem[l]) return fail("decode: null memory buffer for layer %d", l);
+    // capacity: rows [0, n_mem) are read, an update writes rows [n_mem, n_mem + Rs) of every scene's buffer
+    const long long rows_needed = (long long)A->n_mem + (A->render ? 0 : Rs);
+    if (A->mem_capacity <= 0) return fail("decode: mem_capacity must be given (rows each scene's memory buffer can hold)");
+    if (rows_needed > A->mem_capacity)
+        return fail("decode: memory buffers hold %d rows, this call needs %lld (n_mem %d + %lld new)", A->mem_capacity, rows_needed, A->n_mem,
+                    A->render ? 0LL : Rs);
+    if (S > 1 && A->mem_scene_stride < A->mem_capacity)
+        return fail("decode: mem_scene_stride %lld < mem_capacity %d", (long long)A->mem_scene_stride, A->mem_capacity);
+    if ((S - 1) * (S > 1 ? (long long)A->mem_scene_stride : 0) + rows_needed > 0x7fffffffLL || (long long)S * Rs > 0x7fffffffLL / 4096)
+        return fail("decode: call too large (row indices are 32-bit)");
+    // cross-attention staging addresses K|V rows of one scene with 32-bit byte offsets (attention.hip, attn3_kernel)
+    {
+        const long long memD = A->mem_mode == MUST3R_MEM_KV ? 2LL * c->cfg.dec_dim : 1LL * c->cfg.dec_dim;
+        if (rows_needed * 2LL * c->cfg.dec_dim * 2 >= 0x7fffffffLL || rows_needed * memD * 2 >= 0x7fffffffLL)
+            return fail("decode: a scene memory of %lld rows exceeds the 2 GiB the attention staging can address per layer", rows_needed);
+    }
+    // the per-call view tables travel through one staging slot: 2 tables x 24 B per view
+    const long long max_views = (long long)(must3r_hip_ctx::kSlotBytes / (2 * sizeof(AttnView)));
+    if (S * views_s <= max_views) return decode_impl(c, A, stream);
+    if (!A->render) return fail("decode: %lld views in one memory update (limit %lld)", S * views_s, max_views);
+    if (A->feats) return fail("decode: return_feats with %lld rendered views in one call (limit %lld)", S * views_s, max_views);
+    must3r_hip_decode_args sub = *A;
+    if (S > 1) {   // cut the batch into ranges of scenes
+        const int per = views_s <= max_views ? (int)(max_views / views_s) : 1;
+        std::vector<must3r_hip_group> gs(A->n_groups);
+        std::vector<void*> mems(c->cfg.dec_depth);
+        const long long memD = A->mem_mode == MUST3R_MEM_KV ? 2LL * c->cfg.dec_dim : 1LL * c->cfg.dec_dim;
+        const long long memES = ((A->dtype & MUST3R_ATTN_FP8) && A->mem_mode == MUST3R_MEM_KV) ? 1 : 2;
+        for (int b0 = 0; b0 < S; b0 += per) {
+            const int nb = S - b0 < per ? S - b0 : per;
+            for (int gi = 0; gi < A->n_groups; ++gi) {
+                gs[gi] = A->groups[gi];
+                const size_t rg = (size_t)gs[gi].n_views * gs[gi].n_tokens;
+                gs[gi].tokens += (size_t)b0 * rg * c->cfg.enc_dim;
+                gs[gi].pos += (size_t)b0 * rg * 2;
+                gs[gi].pointmaps += (size_t)b0 * gs[gi].n_views * gs[gi].H * gs[gi].W * 7;
+            }
+            for (int l = 0; l < c->cfg.dec_depth; ++l)
+                mems[l] = reinterpret_cast<char*>(A->mem[l]) + (size_t)b0 * A->mem_scene_stride * memD * memES;
+            sub.groups = gs.data(); sub.mem = mems.data(); sub.n_scenes = nb;
+            M3R_OK(must3r_hip_decode(c, &sub, stream));
+        }
+        return 0;
+    }
+    // one scene: cut every group into ranges of views
+    for (int gi = 0; gi < A->n_groups; ++gi) {
+        const must3r_hip_group& G = A->groups[gi];
+        for (long long v0 = 0; v0 < G.n_views; v0 += max_views) {
+            must3r_hip_group g1 = G;
+            g1.n_views = (int)(G.n_views - v0 < max_views ? G.n_views - v0 : max_views);
+            g1.tokens += (size_t)v0 * G.n_tokens * c->cfg.enc_dim;
+            g1.pos += (size_t)v0 * G.n_tokens * 2;
+            g1.pointmaps += (size_t)v0 * G.H * G.W * 7;
+            sub.groups = &g1; sub.n_groups = 1;
+            M3R_OK(decode_impl(c, &sub, stream));
+        }
+    }
     return 0;
 }
 

@@ -163,6 +163,42 @@ def run_scene(encoder, decoder, imgs, true_shape, mem_batches=None, render_bs=No
 
 
 @torch.no_grad()
+def run_scenes(encoder, decoder, imgs, true_shape, mem_batches=None, activate=True, encoder_tokens=None):
+    """S independent scenes of the same shape IN FLIGHT TOGETHER: ``imgs`` fp32 [S,V,3,H,W] (cuda), ``true_shape`` int64 [V,2].
+
+    The schedule of every scene is ``run_scene``'s; the scenes ride the batch dimension of the reference's decoder API
+    (decoder.py:170-186: ``x[i]`` is ``[B, nimg, Ni, Denc]``; the scenes of a batch never interact), which the native decoder runs
+    as ONE launch sequence per call: the strictly sequential memory update -- one view per call, M = 768 rows per GEMM for a
+    lone scene -- becomes M = S x 768, each weight tile staged once per S x the rows.  Encoder and render are batched over all
+    S x V views like ``run_scene`` batches V.
+
+    Returns dict(update=[S,V,H,W,7], render=[S,V,H,W,7], mem=mem_tuple with [S, Nm, mem_D] tensors, x, pos[, pts3d, ...])."""
+    S, V = int(imgs.shape[0]), int(imgs.shape[1])
+    if mem_batches is None:
+        mem_batches = demo_mem_batches(V)
+    true_shape = true_shape.cpu() if true_shape.is_cuda else true_shape
+    if encoder_tokens is not None:
+        x, pos = encoder_tokens
+    else:
+        x, pos = encoder(imgs.reshape(S * V, *imgs.shape[2:]), true_shape.repeat(S, 1))
+    x = x.view(S, V, *x.shape[1:])
+    pos = pos.view(S, V, *pos.shape[1:])
+    ts = true_shape.unsqueeze(0).expand(S, -1, -1)
+    if hasattr(decoder, "reserve_memory_tokens"):
+        decoder.reserve_memory_tokens = sum(mem_batches) * ((imgs.shape[-2] // 16) * (imgs.shape[-1] // 16))
+    mem, upd, i = None, [], 0
+    for nb in mem_batches:
+        mem, pm = decoder(x[:, i:i + nb], pos[:, i:i + nb], ts[:, i:i + nb], mem)
+        upd.append(pm)
+        i += nb
+    _, ren = decoder(x, pos, ts, mem, render=True)
+    out = {"update": torch.cat(upd, dim=1), "render": ren, "mem": mem, "x": x, "pos": pos}
+    if activate:
+        out.update(postprocess(out["render"]))
+    return out
+
+
+@torch.no_grad()
 def run_scene_mixed(encoder, decoder, img_groups, mem_batches=None, activate=True):
     """One scene whose views come in several aspect ratios (BASELINE.json configs[4]: 512 x {384,336,288,256,160}).
 

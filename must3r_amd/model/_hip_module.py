@@ -1,5 +1,8 @@
 """Shared plumbing of the two HIP-backed modules: context lifetime, weight synchronisation,
 operand-dtype policy, stream handling."""
+import operator
+import os
+
 import torch
 import torch.nn as nn
 
@@ -9,6 +12,8 @@ from .. import _lib
 _DT = {"bf16": _lib.BF16, "fp16": _lib.F16, "fp16w2": _lib.F16_W2, torch.bfloat16: _lib.BF16, torch.float16: _lib.F16}
 _TORCH_DT = {_lib.BF16: torch.bfloat16, _lib.F16: torch.float16, _lib.F16_W2: torch.float16}
 PRECISIONS = ("bf16", "fp16", "fp16w2")
+_VERSION_OF = operator.attrgetter("_version")
+_DEBUG_WEIGHTS = bool(int(os.environ.get("M3R_DEBUG_WEIGHTS", "0") or 0))
 
 
 def operand_dtype(precision):
@@ -49,26 +54,69 @@ class HipModule(nn.Module):
         self._synced = None
 
     # -- weights -------------------------------------------------------------------------------
-    # When do the parameters have to be mirrored into the native context again?  Walking all ~600 parameters per forward
-    # ((data_ptr, _version) each) costs ~0.3 ms of host time per call -- more than the launches of a 224x224 decoder call.
-    # In eval mode (every inference caller of the reference) the check is O(1): an epoch counter bumped by everything that
-    # replaces or moves parameters wholesale (`load_state_dict`, `_apply` = .to() / .cuda() / .half() ...) plus the
-    # (data_ptr, _version) of the first and the last parameter as sentinels (an optimizer step or a bulk in-place edit changes
-    # them).  In training mode the full fingerprint is kept.  A caller that edits single parameters in place in eval mode
-    # calls `refresh_weights()`.
+    # When do the parameters have to be mirrored into the native context again?  The full fingerprint ((data_ptr, _version) of all
+    # ~600 parameters) costs ~0.1-0.3 ms of host time per call -- more than the launches of a 224x224 decoder call.  In eval mode
+    # (every inference caller of the reference) the check is:
+    #   * an epoch counter bumped by everything that replaces or moves parameters wholesale -- `load_state_dict` and `_apply`
+    #     (= .to() / .cuda() / .half() ...) of this module AND of every submodule (hooks installed on the children, so that
+    #     `model.blocks_dec[3].half()` or a child's `load_state_dict` is seen);
+    #   * the SUM of `_version` over a cached parameter list (rebuilt when the epoch moves): any in-place edit of any parameter --
+    #     an optimizer step, `p.mul_()`, `p.data.copy_()` -- changes it (~40 us);
+    #   * the data_ptr of the first, the middle and the last parameter.
+    # Not seen: a parameter OBJECT replaced on a child (`child.weight = nn.Parameter(...)`) -- call `refresh_weights()`; the switch
+    # M3R_DEBUG_WEIGHTS=1 asserts the full fingerprint on every forward to find such a caller.  Training mode keeps the full one.
+    def _full_fingerprint(self):
+        return tuple((p.data_ptr(), p._version) for p in self.parameters())
+
     def _fingerprint(self):
         if self.training:
-            return tuple((p.data_ptr(), p._version) for p in self.parameters())
-        ps = getattr(self, "_param_ends", None)
-        if ps is None or ps[2] != self._weights_epoch:
+            return self._full_fingerprint()
+        self._install_child_hooks()
+        ps = getattr(self, "_param_cache", None)
+        if ps is None or ps[1] != self._weights_epoch:
             allp = list(self.parameters())
-            ps = self._param_ends = (allp[0], allp[-1], self._weights_epoch)
-        return (self._weights_epoch, ps[0].data_ptr(), ps[0]._version, ps[1].data_ptr(), ps[1]._version)
+            ps = self._param_cache = (allp, self._weights_epoch, (allp[0], allp[len(allp) // 2], allp[-1]))
+        fp = (self._weights_epoch, sum(map(_VERSION_OF, ps[0])), ps[2][0].data_ptr(), ps[2][1].data_ptr(), ps[2][2].data_ptr())
+        if _DEBUG_WEIGHTS:
+            full = self._full_fingerprint()
+            last = getattr(self, "_debug_full", None)
+            if last is not None and last[0] == fp and last[1] != full:
+                raise AssertionError("must3r_amd: parameters changed without the cheap fingerprint noticing (M3R_DEBUG_WEIGHTS); "
+                                     "call refresh_weights() after replacing parameter objects")
+            self._debug_full = (fp, full)
+        return fp
 
     _weights_epoch = 0
+    _hooked_children = None
 
     def _bump(self):
         self._weights_epoch = self._weights_epoch + 1
+
+    def _install_child_hooks(self):
+        """Make wholesale changes on SUBmodules bump this module's epoch (children are plain nn.Modules)."""
+        mods = list(self.modules())
+        if self._hooked_children == (id(self), len(mods)):
+            return
+        import weakref
+        me = weakref.ref(self)
+
+        def bump(*_a, **_k):
+            m = me()
+            if m is not None:
+                m._bump()
+        for m in mods:
+            owner = getattr(m, "_m3r_hooked", None)
+            if m is self or (owner is not None and owner() is self):
+                continue
+            m.register_load_state_dict_post_hook(bump)
+            orig = m._apply
+
+            def _apply(fn, *a, _orig=orig, **k):
+                bump()
+                return _orig(fn, *a, **k)
+            object.__setattr__(m, "_apply", _apply)
+            object.__setattr__(m, "_m3r_hooked", me)
+        self._hooked_children = (id(self), len(mods))   # (a deepcopy carries the original's hooks: its id differs, it installs its own)
 
     def _apply(self, fn, *a, **k):
         self._bump()

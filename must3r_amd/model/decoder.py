@@ -33,11 +33,13 @@ _MEM_MODE = {"kv": _lib.MEM_KV, "norm_y": _lib.MEM_NORM_Y, "raw": _lib.MEM_RAW}
 
 
 class _MemBuffers:
-    """Per-layer over-allocated K|V buffers; ``valid`` = rows handed out by the newest view."""
+    """Per-layer over-allocated K|V buffers ``[B, cap, mem_D]`` (scene b's rows at ``b * cap``); ``valid`` = rows handed out
+    by the newest view."""
 
-    def __init__(self, depth, cap, mem_D, dtype, device):
-        self.bufs = [torch.empty((1, cap, mem_D), dtype=dtype, device=device) for _ in range(depth)]
+    def __init__(self, depth, cap, mem_D, dtype, device, batch=1):
+        self.bufs = [torch.empty((batch, cap, mem_D), dtype=dtype, device=device) for _ in range(depth)]
         self.cap = cap
+        self.batch = batch
         self.valid = 0
 
     def views(self, n):
@@ -134,17 +136,17 @@ class MUSt3R(HipModule):
         return operand_dtype(self.precision)  # no autocast, or fp16 autocast with an fp16-family precision
 
     # -- memory management ---------------------------------------------------------------------
-    def _writable_memory(self, mem_vals, Nm, R, tdt, device):
-        """Return (buffers, pointers) whose rows [0,Nm) hold ``mem_vals`` and that can take R more rows."""
+    def _writable_memory(self, mem_vals, Nm, R, tdt, device, B=1):
+        """Return the buffers whose rows [0,Nm) (of every scene) hold ``mem_vals`` and that can take R more rows per scene."""
         mem_D = 2 * self.embed_dim if self.memory_mode == "kv" else self.embed_dim
         owner = None
         if mem_vals is not None and len(mem_vals) == self.depth:
             owner = getattr(mem_vals[0], "_m3r_owner", None)
-            ok = owner is not None and owner.valid == Nm and owner.cap >= Nm + R
+            ok = owner is not None and owner.valid == Nm and owner.cap >= Nm + R and owner.batch == B
             if ok:
                 for v, b in zip(mem_vals, owner.bufs):
                     if getattr(v, "_m3r_owner", None) is not owner or v.data_ptr() != b.data_ptr() or v.dtype != tdt \
-                            or v.shape[1] != Nm or v.device != b.device:
+                            or v.shape[0] != B or v.shape[1] != Nm or v.device != b.device:
                         ok = False
                         break
             if not ok:
@@ -154,15 +156,15 @@ class MUSt3R(HipModule):
             # reach (engine.run_scene: keyframes x tokens) can say so through ``reserve_memory_tokens`` and skip the
             # 12 x log2 re-allocation copies of a scene (measured: 49 copies, 0.5 ms per 20-view scene)
             # The hint is ONE-SHOT: it sizes the first buffer of a scene (Nm == 0) and is consumed there, so later fresh
-            # allocations (copy-out after a discarded / older tuple, another scene, the B > 1 path) are not sized for it.
+            # allocations (copy-out after a discarded / older tuple, another scene) are not sized for it.
             hint = int(getattr(self, "reserve_memory_tokens", 0) or 0) if Nm == 0 else 0
             if Nm == 0:
                 self.reserve_memory_tokens = 0
             cap = max(Nm + R, 2 * Nm, 1024, hint)
-            owner = _MemBuffers(self.depth, cap, mem_D, tdt, device)
+            owner = _MemBuffers(self.depth, cap, mem_D, tdt, device, B)
             if Nm > 0:
                 for v, b in zip(mem_vals, owner.bufs):
-                    b[:, :Nm].copy_(v.reshape(1, Nm, mem_D))
+                    b[:, :Nm].copy_(v.reshape(B, Nm, mem_D))
         return owner
 
     # -- forward -------------------------------------------------------------------------------
@@ -179,43 +181,23 @@ class MUSt3R(HipModule):
         poss = list(pos) if is_list else [pos]
         shapes = list(true_shape) if is_list else [true_shape]
         B = int(xs[0].shape[0])
-        if B == 1:
-            out, outs, feats = self._forward_scene(xs, poss, shapes, current_mem, render, return_feats)
-        else:
-            # B > 1 (training-style batches; every inference caller of the reference uses B = 1): the scenes of a batch
-            # never interact -- memory, labels and attention are all per batch element (decoder.py:158-350) -- so a
-            # batch is B independent native calls whose results are stacked.  Each scene gets its own memory buffers;
-            # the stacked copy is what the caller holds, so the in-place append of the B = 1 path does not apply.
-            assert all(int(t.shape[0]) == B for t in xs + poss), "all groups must share the batch size"
-            per = []
-            for b in range(B):
-                mem_b = None
-                if current_mem is not None:
-                    mv, ml, mn, mpi, mpt = current_mem
-                    mem_b = ([v[b:b + 1] for v in mv], ml[b:b + 1], mn, mpi, mpt)
-                per.append(self._forward_scene([t[b:b + 1] for t in xs], [t[b:b + 1] for t in poss],
-                                               [t.reshape(B, -1, 2)[b:b + 1] for t in shapes], mem_b, render, return_feats))
-            if render:
-                out = current_mem   # decoder.py:252 / :339
-            else:
-                o0 = per[0][0]
-                out = ([torch.cat([p[0][0][l] for p in per], dim=0) for l in range(self.depth)],
-                       torch.cat([p[0][1] for p in per], dim=0), o0[2], o0[3], o0[4])
-            outs = [torch.cat([p[1][g] for p in per], dim=0) for g in range(len(xs))]
-            feats = None
-            if return_feats:
-                feats = [[torch.cat([p[2][g][l] for p in per], dim=0) for l in range(self.depth + 1)] for g in range(len(xs))]
+        assert all(int(t.shape[0]) == B for t in xs + poss), "all groups must share the batch size"
+        # B > 1 (the reference's batch dimension, decoder.py:170-186): the scenes of a batch never interact -- memory, labels and
+        # attention are all per batch element -- and are decoded by ONE native call (must3r_hip_decode_args.n_scenes): every GEMM
+        # sees M = B x rows, the attention tables B x views, each scene its own rows of the [B, capacity, mem_D] memory buffers.
+        out, outs, feats = self._forward_scene(xs, poss, shapes, current_mem, render, return_feats)
         if return_feats:
             return out, (outs if is_list else outs[0]), (feats if is_list else feats[0])
         return out, (outs if is_list else outs[0])
 
     def _forward_scene(self, xs, poss, shapes, current_mem, render, return_feats):
-        """One scene (B = 1): the native decode call.  Returns (memory, [pointmaps per group], [feats per group] | None)."""
-        # The per-call view tables travel through a 64 KiB pinned slot (48 B per view: 1365 views).  The reference renders every
-        # view of an aspect ratio in ONE call when the caller sets no max_bs (engine/inference.py:489-522), so a large collection
-        # is cut here: rendered views are independent of each other, the chunks give the same pointmaps.
+        """B scenes of identical shapes: ONE native decode call.  Returns (memory, [pointmaps per group], [feats per group] | None)."""
+        # (The per-call view tables travel through a 64 KiB staging slot, 1365 views; the reference renders every view of an aspect
+        # ratio in ONE call when the caller sets no max_bs (engine/inference.py:489-522), so the LIBRARY cuts larger render calls
+        # into ranges of views / scenes: rendered views are independent.  Only return_feats needs the cut up here, for its buffer.)
         MAXV = 1024
-        if render and sum(int(x.shape[1]) for x in xs) > MAXV:
+        B = int(xs[0].shape[0])
+        if render and return_feats and B == 1 and sum(int(x.shape[1]) for x in xs) > MAXV:
             outs, feats = [], []
             for xi, pi, ti in zip(xs, poss, shapes):
                 pms, fts = [], []
@@ -244,8 +226,7 @@ class MUSt3R(HipModule):
         R = 0
         nimgs, Ns = [], []
         for i, (xi, pi, ti) in enumerate(zip(xs, poss, shapes)):
-            B, n, N, Cenc = xi.shape
-            assert B == 1
+            _, n, N, Cenc = xi.shape
             xi = self._check_input(xi, "x", torch.float32)
             pi = self._check_input(pi, "pos", torch.int64)
             ts = ti.reshape(-1, 2)
@@ -254,7 +235,7 @@ class MUSt3R(HipModule):
             assert bool((ts[0:1] == ts).all()), "true_shape must be all identical"  # head.py:31
             H, W = (int(v) for v in ts[0].tolist())
             assert (H // 16) * (W // 16) == N, (H, W, N)
-            pm = torch.empty((1, n, H, W, 7), dtype=torch.float32, device=device)
+            pm = torch.empty((B, n, H, W, 7), dtype=torch.float32, device=device)
             keep += [xi, pi]
             outs.append(pm)
             groups[i] = _lib.Group(xi.data_ptr(), pi.data_ptr(), n, N, H, W, pm.data_ptr())
@@ -263,31 +244,43 @@ class MUSt3R(HipModule):
             Ns.append(N)
 
         if current_mem is None:
-            mem_vals, mem_labels, mem_nimgs, mem_prot_imgs, mem_prot_tok = None, torch.zeros((1, 0), dtype=torch.int64,
+            mem_vals, mem_labels, mem_nimgs, mem_prot_imgs, mem_prot_tok = None, torch.zeros((B, 0), dtype=torch.int64,
                                                                                             device=device), 0, 0, 0
             Nm = 0
         else:
             mem_vals, mem_labels, mem_nimgs, mem_prot_imgs, mem_prot_tok = current_mem
             Nm = int(mem_vals[0].shape[1])
+            assert all(int(v.shape[0]) == B for v in mem_vals), "memory and inputs must share the batch size"
 
+        mem_D = 2 * D if self.memory_mode == "kv" else D
         if render:
-            vals = []
+            # read-only: any [B, Nm, mem_D] tensors whose rows are contiguous and whose scene stride is the same in every layer
+            # (the prefix views of this module's own buffers are: stride cap x mem_D) are read in place
+            vals, stride = [], None
             for v in mem_vals:
-                if not v.is_cuda or v.dtype != tdt or not v.is_contiguous():
+                if not v.is_cuda or v.dtype != tdt or v.stride(2) != 1 or v.stride(1) != mem_D or (B > 1 and v.stride(0) % mem_D):
                     v = v.to(device=device, dtype=tdt).contiguous()
                 vals.append(v)
+            if B > 1:
+                strides = {int(v.stride(0)) // mem_D for v in vals}
+                if len(strides) != 1 or min(strides) < Nm:
+                    vals = [v.contiguous() for v in vals]
+                stride = int(vals[0].stride(0)) // mem_D
             ptrs = (C.c_void_p * self.depth)(*[v.data_ptr() for v in vals])
             keep += vals
+            cap, stride = Nm, (0 if B == 1 else stride)   # read-only: the rows that exist are the capacity
         else:
-            owner = self._writable_memory(mem_vals, Nm, R, tdt, device)
+            owner = self._writable_memory(mem_vals, Nm, R, tdt, device, B)
             ptrs = (C.c_void_p * self.depth)(*[b.data_ptr() for b in owner.bufs])
+            cap, stride = owner.cap, owner.cap
 
         # return_feats (decoder.py:344-347): [encoder tokens, residual stream after blocks 0..depth-2, norm_dec(last)] -- fp32
         # here (the residual stream is fp32 on this path, bf16 in the reference under autocast)
-        feats_buf = torch.empty((self.depth, R, D), dtype=torch.float32, device=device) if return_feats else None
+        feats_buf = torch.empty((self.depth, B, R, D), dtype=torch.float32, device=device) if return_feats else None
         args = _lib.DecodeArgs(odt | (_lib.ATTN_FP8 if self.attention_fp8 else 0), _MEM_MODE[self.memory_mode],
                                1 if render else 0, 1 if current_mem is None else 0,
-                               len(xs), groups, Nm, ptrs, feats_buf.data_ptr() if return_feats else None)
+                               len(xs), groups, Nm, ptrs, feats_buf.data_ptr() if return_feats else None,
+                               cap, B, stride)
         _lib.check(ctx.lib.must3r_hip_decode(ctx.handle, C.byref(args), self._stream(dev)))
 
         if render:
@@ -302,12 +295,13 @@ class MUSt3R(HipModule):
             runs = [] if Nm == 0 else getattr(mem_labels, "_m3r_runs", None)
             runs = list(runs) if runs is not None and sum(c for _, c in runs) == Nm else None
             for n, N in zip(nimgs, Ns):  # decoder.py:241-249 / :332-334
-                labels.append((torch.arange(n, dtype=torch.int64, device=device) + (mem_nimgs + k)).repeat_interleave(N).view(1, -1))
+                labels.append((torch.arange(n, dtype=torch.int64, device=device) + (mem_nimgs + k)).repeat_interleave(N).view(1, -1)
+                              .expand(B, -1))
                 if runs is not None:
                     runs += [(mem_nimgs + k + j, N) for j in range(n)]
                 k += n
             mem_labels = torch.cat([mem_labels.to(device)] + labels, dim=1)
-            if runs is not None:
+            if runs is not None and B == 1:
                 mem_labels._m3r_runs = runs
             tot = mem_nimgs + sum(nimgs)
             out = (new_vals, mem_labels, tot, tot, mem_labels.shape[1])
@@ -315,7 +309,7 @@ class MUSt3R(HipModule):
         if return_feats:
             feats, r0 = [], 0
             for xi, n, N in zip(xs, nimgs, Ns):
-                feats.append([xi] + [feats_buf[l, r0:r0 + n * N].view(1, n, N, D) for l in range(self.depth)])
+                feats.append([xi] + [feats_buf[l, :, r0:r0 + n * N].reshape(B, n, N, D) for l in range(self.depth)])
                 r0 += n * N
         return out, outs, feats
 
