@@ -705,8 +705,12 @@ extern "C" int must3r_hip_encode(must3r_hip_ctx* c, int dtype, const float* img,
     DeviceGuard dev_guard(c->device);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const int N = (H / 16) * (W / 16);
-    int per = 24576 / N;  // bound the workspace: ~24k token rows per chunk
+    int per = 32768 / N;  // bound the workspace: ~32k token rows per chunk ...
     if (per < 1) per = 1;
+    {   // ... in chunks of equal size (80 views of 768 tokens: 2 x 40 -- 94 % tile fill -- instead of 42 + 38)
+        const int nch = (n_views + per - 1) / per;
+        per = (n_views + nch - 1) / nch;
+    }
     for (int v0 = 0; v0 < n_views; v0 += per) {
         const int nv = (n_views - v0 < per) ? n_views - v0 : per;
         M3R_OK(encode_chunk(c, (DType)dtype, img + (size_t)v0 * 3 * H * W, nv, H, W, out_tokens + (size_t)v0 * N * c->cfg.enc_dim,
