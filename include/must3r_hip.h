@@ -37,11 +37,12 @@ typedef struct must3r_hip_ctx must3r_hip_ctx;
  * for must3r_hip_encode / must3r_hip_decode; buffers are fp16. */
 enum { MUST3R_BF16 = 0, MUST3R_F16 = 1, MUST3R_F16_W2 = 2 };
 /* OR-able flag on `dtype` (BASELINE.json configs[4], "fp8 MFMA attention path"; replaces the attention back ends of
- * must3r/model/blocks/attention.py:57-79): Q, K, V enter the attention products as OCP e4m3 bytes and P = softmax numerators
- * are rounded to e4m3 (v_mfma_f32_16x16x32_fp8_fp8); softmax, accumulators and outputs stay fp32 / 16-bit.
- *   must3r_hip_op_attention: Q, K, V ARE e4m3 arrays (row strides in bytes).
- *   must3r_hip_encode / must3r_hip_decode: the projections are quantised on the fly; with MUST3R_MEM_KV the memory buffers
- *   hold e4m3 K|V rows ([capacity, 2*dec_dim] bytes): half the footprint and half the cross-attention traffic. */
+ * must3r/model/blocks/attention.py:57-79): Q and K enter the score product as OCP e4m3 bytes through the MX-scaled
+ * v_mfma_scale_f32_32x32x64_f8f6f4 (twice the 16-bit MFMA rate); the softmax, its numerators P, V, the accumulators and the outputs
+ * stay fp32 / 16-bit (3 mantissa bits on V alone cost 9e-3 of pointmap error, on Q and K 2e-3: DESIGN.md section 4).
+ *   must3r_hip_op_attention: Q and K ARE e4m3 arrays (ldq, ldk in bytes); V and O 16-bit (ldv, ldo in elements).
+ *   must3r_hip_encode / must3r_hip_decode: q and k are quantised on the fly; with MUST3R_MEM_KV the memory buffers hold rows of
+ *   [K e4m3: dec_dim bytes | V 16-bit: 2*dec_dim bytes] = 3*dec_dim bytes (3/4 of the 16-bit footprint). */
 #define MUST3R_ATTN_FP8 0x100
 
 /* layout of the caller-visible memory tensors; CachedDecoderBlock MEMORY_MODES, must3r/model/blocks/layers.py:9 */
@@ -93,14 +94,14 @@ typedef struct must3r_hip_group {
 
 typedef struct must3r_hip_decode_args {
     int32_t dtype;        /* MUST3R_BF16 / MUST3R_F16 / MUST3R_F16_W2: operand type AND element type of the memory buffers;
-                           * | MUST3R_ATTN_FP8: fp8 attention operands, MUST3R_MEM_KV memory buffers hold e4m3 bytes */
+                           * | MUST3R_ATTN_FP8: e4m3 Q / K, MUST3R_MEM_KV memory rows are [K e4m3 | V 16-bit] = 3*dec_dim bytes */
     int32_t mem_mode;     /* MUST3R_MEM_* */
     int32_t render;       /* decoder.py:267 `render`: memory is read-only, no exclusion mask */
     int32_t first_call;   /* current_mem is None: view 0 of group 0 gets no image2_embed (decoder.py:280-282) */
     int32_t n_groups;
     const must3r_hip_group* groups;
     int32_t n_mem;        /* Nm: valid memory tokens (per scene) before this call */
-    /* per decoder layer: 16-bit (e4m3 with MUST3R_ATTN_FP8 + MUST3R_MEM_KV) [mem_capacity, mem_dim] row-major, mem_dim = 2*dec_dim (KV)
+    /* per decoder layer: 16-bit ([K e4m3 | V 16-bit] byte rows with MUST3R_ATTN_FP8 + MUST3R_MEM_KV) [mem_capacity, mem_dim] row-major, mem_dim = 2*dec_dim (KV)
      * or dec_dim.  Rows [0,n_mem) are read; unless render, rows [n_mem, n_mem + sum(n_views*n_tokens)) are WRITTEN -- the in-place
      * form of torch.concatenate at decoder.py:239/330.  The call is refused when they would not fit mem_capacity. */
     void* const* mem;
@@ -206,7 +207,8 @@ int must3r_hip_op_gemm_splitk(int dtype, const void* A, const void* W2, float* s
 int must3r_hip_rope_table(float freq, float f0, int npos, float* out_host);
 
 /* softmax(Q K^T / 8) V per head of 64; views: int32 [n_views][6] = q_row0, nq, kv_row0, nk, skip_lo, skip_hi
- * (DEVICE pointer).  Q/K/V/O 16-bit with row strides in elements (dtype | MUST3R_ATTN_FP8: Q/K/V e4m3 bytes, O 16-bit).
+ * (DEVICE pointer).  Q/K/V/O 16-bit with row strides in elements (dtype | MUST3R_ATTN_FP8: Q/K e4m3 bytes with ldq/ldk in bytes, V/O 16-bit).
+ * A view's K / V rows must span less than 2 GiB (nk * ld * element size): the staging uses 32-bit byte offsets.
  * nsplit > 1 selects split-KV (flash-decoding) with `scratch` of must3r_hip_attention_scratch_bytes() bytes and
  * total_q_rows = max(q_row0 + nq); nsplit <= 1 needs neither. */
 size_t must3r_hip_attention_scratch_bytes(int nsplit, int total_q_rows, int heads);

@@ -1033,6 +1033,436 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(QW == 
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// attn4_kernel (r03): the same transposed flash formulation on 32 x 32 MFMA tiles.
+//   S^T tile = 32 keys x 32 queries: v_mfma_f32_32x32x16 (4 steps over the 64 head dims) or, with F8, ONE
+//              v_mfma_scale_f32_32x32x64_f8f6f4 on e4m3 operands (MX scales = 1): twice the MFMA rate for Q K^T.
+//   O^T tile = 32 head dims x 32 queries, k = 16 keys per v_mfma_f32_32x32x16 -- always 16-bit operands (P rounded to T, V in T):
+//              a CPU emulation of the operand formats (scripts/emul/fp8_attention.py, MUSt3R_224, 8 views) puts e4m3 Q / K at
+//              1.8e-3 of pointmap error, e4m3 P at 1.3e-3 and e4m3 V at 9e-3 -- V is the operand that cannot take 3 mantissa bits.
+// Why 32 x 32: a 32-cycle MFMA leaves ~5 issue slots in its shadow, a 16-cycle one ~2 (MI355X_MICROARCH.md, per-instruction table);
+// attn3_kernel is bound by the instructions it has to ISSUE beside its 36 short MFMAs per tile, this one issues 16 (8 + 8) long
+// ones (F8: 2 + 8) for the same tile, and no `ones` MFMAs (the row sums are VALU adds in the MFMA shadows).
+// Layouts (lane l: c = l & 31, h = l >> 5):
+//   32x32x16   A[i][k]: i = c, k = 8 h + e (e < 8);   B[k][j]: j = c, k = 8 h + e;   C[i][j]: j = c, i = (r & 3) + 8 (r >> 2) + 4 h (r < 16)
+//   32x32x64 (f8f6f4)   A / B: 32 bytes per lane, k = 32 h + e;   C as above
+//   => lane (q = c, h) holds the scores of ONE query against keys {(r & 3) + 8 (r >> 2) + 4 h} of a 32-key tile; registers 8 m .. 8 m + 7
+//      are keys {16 m + 4 h + (e & 3) + 8 (e >> 2)}: exactly a B fragment of the second product over the 16 keys [16 m, 16 m + 16),
+//      and V^T comes from two transposing reads per fragment keyed the same way (keys base .. +3 and base + 8 .. +11, base = 16 m + 4 h).
+//   Only the running maximum crosses lanes (l <-> l ^ 32, slow path only); the row sums are combined once, at the end.
+// Memory / LDS: K tile [64 keys][64] T (F8: [64][64] bytes), V tile [64][64] T, staged by LDS-DMA exactly like attn3_kernel.
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(8))) int i32x8;
+__device__ __forceinline__ f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ f32x16 mfma32(f16x8 a, f16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+// cbsz = blgp = 0: both operands OCP e4m3; scale bytes 127 = 2^0 (E8M0)
+__device__ __forceinline__ f32x16 mfma32_mx8(i32x8 a, i32x8 b, f32x16 c) { return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c, 0, 0, 0, 127, 0, 127); }
+
+// eight transposing reads = the V^T fragments of one 32-key half tile: (16-key step m = 0, 1) x (head-dim half dh = 0, 1) x (keys base, base + 8);
+// a0 / a1 = the lane's address for dh = 0 / 1, O = byte offset of the half tile's first row (buffer, K|V, row) as an immediate
+template <int O>
+__device__ __forceinline__ void lds_tr_x8_issue(unsigned a0, unsigned a1, u32x2 (&r)[8]) {
+    asm volatile(
+        "ds_read_b64_tr_b16 %0, %8 offset:%10\n\t"
+        "ds_read_b64_tr_b16 %1, %8 offset:%11\n\t"
+        "ds_read_b64_tr_b16 %2, %9 offset:%10\n\t"
+        "ds_read_b64_tr_b16 %3, %9 offset:%11\n\t"
+        "ds_read_b64_tr_b16 %4, %8 offset:%12\n\t"
+        "ds_read_b64_tr_b16 %5, %8 offset:%13\n\t"
+        "ds_read_b64_tr_b16 %6, %9 offset:%12\n\t"
+        "ds_read_b64_tr_b16 %7, %9 offset:%13"
+        : "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]), "=&v"(r[3]), "=&v"(r[4]), "=&v"(r[5]), "=&v"(r[6]), "=&v"(r[7])
+        : "v"(a0), "v"(a1), "n"(O), "n"(O + 8 * 128), "n"(O + 16 * 128), "n"(O + 24 * 128)
+        : "memory");
+}
+// the same, ordered BEFORE the consumers of an earlier fragment set: p[0..3] travel through the statement as read-write operands, so the MFMAs
+// that take them (and, through their accumulators, the rest of that set's MFMAs) cannot be scheduled above these reads
+template <int O>
+__device__ __forceinline__ void lds_tr_x8_issue_after(unsigned a0, unsigned a1, u32x2 (&r)[8], u32x2 (&p)[8]) {
+    asm volatile(
+        "ds_read_b64_tr_b16 %0, %12 offset:%14\n\t"
+        "ds_read_b64_tr_b16 %1, %12 offset:%15\n\t"
+        "ds_read_b64_tr_b16 %2, %13 offset:%14\n\t"
+        "ds_read_b64_tr_b16 %3, %13 offset:%15\n\t"
+        "ds_read_b64_tr_b16 %4, %12 offset:%16\n\t"
+        "ds_read_b64_tr_b16 %5, %12 offset:%17\n\t"
+        "ds_read_b64_tr_b16 %6, %13 offset:%16\n\t"
+        "ds_read_b64_tr_b16 %7, %13 offset:%17"
+        : "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]), "=&v"(r[3]), "=&v"(r[4]), "=&v"(r[5]), "=&v"(r[6]), "=&v"(r[7]), "+v"(p[0]), "+v"(p[1]), "+v"(p[2]), "+v"(p[3])
+        : "v"(a0), "v"(a1), "n"(O), "n"(O + 8 * 128), "n"(O + 16 * 128), "n"(O + 24 * 128)
+        : "memory");
+}
+// the same, ordered after the ARRIVAL of a 128-bit value X the compiler loaded itself (it must wait for X before this statement "modifies" it) and
+// before X's consumer: issued from behind the last K-fragment read of a tile, these reads are not caught by the compiler's own lgkmcnt wait for it
+template <int O, class X>
+__device__ __forceinline__ void lds_tr_x8_issue_behind(unsigned a0, unsigned a1, u32x2 (&r)[8], X& x) {
+    asm volatile(
+        "ds_read_b64_tr_b16 %0, %9 offset:%11\n\t"
+        "ds_read_b64_tr_b16 %1, %9 offset:%12\n\t"
+        "ds_read_b64_tr_b16 %2, %10 offset:%11\n\t"
+        "ds_read_b64_tr_b16 %3, %10 offset:%12\n\t"
+        "ds_read_b64_tr_b16 %4, %9 offset:%13\n\t"
+        "ds_read_b64_tr_b16 %5, %9 offset:%14\n\t"
+        "ds_read_b64_tr_b16 %6, %10 offset:%13\n\t"
+        "ds_read_b64_tr_b16 %7, %10 offset:%14"
+        : "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]), "=&v"(r[3]), "=&v"(r[4]), "=&v"(r[5]), "=&v"(r[6]), "=&v"(r[7]), "+v"(x)
+        : "v"(a0), "v"(a1), "n"(O), "n"(O + 8 * 128), "n"(O + 16 * 128), "n"(O + 24 * 128)
+        : "memory");
+}
+// the reads above land asynchronously: every consumer takes the registers from THIS statement (read-write operands), so nothing
+// the compiler schedules can use them before the counter says they have arrived.  LDS operations return in order, so the wait is
+// also correct (conservative) for any compiler-issued ds_read in flight.
+// (`late`: a value computed just before the consumers -- the first P fragment -- also travels through the statement, which keeps the
+// scheduler from hoisting the wait to right behind the reads it waits for)
+template <class X>
+__device__ __forceinline__ void lds_tr_x8_wait(u32x2 (&r)[8], X& late) {
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7]), "+v"(late)
+                 :
+                 : "memory");
+}
+
+__device__ __forceinline__ float max16x(const f32x16& a) {
+    return max16f(__builtin_shufflevector(a, a, 0, 1, 2, 3), __builtin_shufflevector(a, a, 4, 5, 6, 7), __builtin_shufflevector(a, a, 8, 9, 10, 11),
+                  __builtin_shufflevector(a, a, 12, 13, 14, 15));
+}
+
+template <class T, int QF, bool F8>   // QF: 32-query fragments per wave
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(QF == 1 ? 2 : 1))) attn4_kernel(const AttnArgs p, const int nqb, const int ngrp, const int nsplit) {
+    typedef typename Vec<T>::v8 v8;
+    typedef typename Vec<T>::v4 v4;
+    constexpr int QW = 32 * QF;
+    constexpr int QB = 4 * QW;
+    constexpr int KB = F8 ? ATT_KT * 64 : ATT_KT * 128;     // bytes of a K tile
+    constexpr int VB = ATT_KT * 128;                        // bytes of a V tile
+    constexpr int TB = KB + VB;
+    __shared__ __attribute__((aligned(16))) char smem[2 * TB];   // [buffer][K tile | V tile]
+    typedef __attribute__((address_space(3))) const char* lds_cptr;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lc = lane & 31, lh = lane >> 5;
+
+    int grp, split, qb;
+    if (!attn_block_coords(nqb, ngrp, nsplit, grp, split, qb)) return;
+    const int view = grp / p.heads, head = grp - view * p.heads;
+    const AttnView vw = p.view0_inline ? p.view0 : p.views[view];
+    if (qb * QB >= vw.nq) return;
+
+    const int kes = F8 ? 1 : 2;                              // bytes per Q / K element
+    const char* __restrict__ Qb = reinterpret_cast<const char*>(p.Q);
+    const char* __restrict__ Kb = reinterpret_cast<const char*>(p.K) + ((size_t)vw.kv_row0 * p.ldk + head * 64) * kes;
+    const T* __restrict__ V = reinterpret_cast<const T*>(p.V) + (size_t)vw.kv_row0 * p.ldv + head * 64;
+
+    // ---- Q fragments (B operand of the first product): lane (q = lc, h = lh)
+    const int qr0 = qb * QB + wave * QW;
+    v8 qf_[QF][F8 ? 1 : 4];
+    i32x8 qf8_[QF];
+#pragma unroll
+    for (int f = 0; f < QF; ++f) {
+        int r = qr0 + f * 32 + lc;
+        r = r < vw.nq ? r : vw.nq - 1;
+        const char* src = Qb + ((size_t)(vw.q_row0 + r) * p.ldq + head * 64) * kes;
+        if constexpr (F8) {
+            const i32x4 lo = *reinterpret_cast<const i32x4*>(src + 32 * lh), hi = *reinterpret_cast<const i32x4*>(src + 32 * lh + 16);
+            qf8_[f] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        } else {
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) qf_[f][ks] = *reinterpret_cast<const v8*>(src + (16 * ks + 8 * lh) * 2);
+        }
+    }
+
+    const int nk = vw.nk, slo = vw.skip_lo, shi = vw.skip_hi;
+    const int ntiles = (nk + ATT_KT - 1) / ATT_KT;
+    auto fully_skipped = [&](int t) {
+        const int k0 = t * ATT_KT;
+        const int k1 = (k0 + ATT_KT < nk) ? k0 + ATT_KT : nk;
+        return k0 >= slo && k1 <= shi;
+    };
+    const int tps = (ntiles + nsplit - 1) / nsplit;
+    const int t_begin = split * tps;
+    const int t_end = (t_begin + tps < ntiles) ? t_begin + tps : ntiles;
+    auto advance = [&](int t) {
+        ++t;
+        if (shi > slo)
+            while (t < t_end && fully_skipped(t)) ++t;
+        return t;
+    };
+
+    // ---- staging through buffer descriptors: rows >= nk lie outside the descriptor and read as zero.  16-bit tiles: a wave
+    // instruction moves 8 rows x 128 B (2 K + 2 V pieces per wave and tile); e4m3 K tile: 16 rows x 64 B (1 piece per wave).
+    const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(Kb), 0, ((nk - 1) * p.ldk + 64) * kes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(V), 0, ((nk - 1) * p.ldv + 64) * 2, 0x00020000);
+    int vok[2], vov[2];
+    {
+        const int srow = lane >> 3, pch = lane & 7;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int r = (wave * 2 + i) * 8 + srow;
+            vov[i] = (r * p.ldv + swz_v(r, pch) * 8) * 2;
+            if constexpr (!F8) vok[i] = (r * p.ldk + swz(r, pch) * 8) * 2;
+        }
+        if constexpr (F8) {
+            const int r = wave * 16 + (lane >> 2);
+            vok[0] = r * p.ldk + swz32(r, lane & 3) * 16;
+            vok[1] = 0;
+        }
+    }
+    const int tstride_k = ATT_KT * p.ldk * kes, tstride_v = ATT_KT * p.ldv * 2;
+    auto stage = [&](int t, int buf) {
+        if constexpr (F8) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rk, (__attribute__((address_space(3))) void*)&smem[buf * TB + wave * 16 * 64], 16, vok[0], t * tstride_k, 0, 0);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rk, (__attribute__((address_space(3))) void*)&smem[buf * TB + (wave * 2 + i) * 8 * 128], 16, vok[i],
+                                                         t * tstride_k, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, (__attribute__((address_space(3))) void*)&smem[buf * TB + KB + (wave * 2 + i) * 8 * 128], 16, vov[i],
+                                                     t * tstride_v, 0, 0);
+    };
+
+    // ---- per-lane LDS byte offsets
+    //   K fragment, 16-bit (tile half t, step ks): row 32 t + lc, chunk (2 ks + lh) ^ ((lc >> 1) & 7) = (2 ks) ^ z
+    //   K fragment, e4m3 (tile half t): row 32 t + lc, 16-byte chunks (2 lh) ^ x and (2 lh + 1) ^ x, x = swz32 pattern of the row
+    //   V^T read (tile half t, step m, dim half dh, key group s): row 32 t + 16 m + 8 s + 4 lh' + e, lh' = lane >> 5, group g = lane >> 4,
+    //     position pp = lane & 15 (e = pp >> 2, c = pp & 3), chunk pair (2 dh + (g & 1)) ^ ((rowlane >> 1) & 3), byte 8 c inside the pair
+    // All of them are absolute LDS byte addresses inside buffer 0; after every tile they move by +TB / -TB.  (ONE loop body: the
+    // loop-carried state -- 80+ registers of O, l, m, -m -- stays where it is; a body unrolled over the two buffers, with the buffer
+    // in the immediates, made the register allocator copy the -m operand at every join.)
+    const unsigned lds0 = (unsigned)(size_t)(lds_cptr)(&smem[0]);
+    unsigned kaddr[F8 ? 2 : 4];
+    if constexpr (!F8) {
+        const int z = lh ^ ((lc >> 1) & 7);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) kaddr[ks] = lds0 + (unsigned)(lc * 128 + ((2 * ks) ^ z) * 16);
+    } else {
+        kaddr[0] = lds0 + (unsigned)(lc * 64 + swz32(lc, 2 * lh) * 16);
+        kaddr[1] = lds0 + (unsigned)(lc * 64 + swz32(lc, 2 * lh + 1) * 16);
+    }
+    unsigned vaddr[2];
+    {
+        const int g = lane >> 4, pp = lane & 15;
+        const int rowlane = 4 * (g >> 1) + (pp >> 2);
+        const int x = (rowlane >> 1) & 3;
+#pragma unroll
+        for (int dh = 0; dh < 2; ++dh) vaddr[dh] = lds0 + (unsigned)(KB + rowlane * 128 + (((2 * dh + (g & 1)) ^ x) * 32) + (pp & 3) * 8);
+    }
+
+    // ---- running state: o_[dh][f] = O^T rows 32 dh .. (16 registers), l_[f] = this lane's share of the row sum, m_[f] = reference of
+    // query lc (same in both half waves), nm_[f] = -m/c splat: the C operand of the first MFMA of every score tile (S - m for free)
+    f32x16 o_[2][QF], nm_[QF];
+    float l_[QF], m_[QF];
+    bool any_first = true;
+#pragma unroll
+    for (int f = 0; f < QF; ++f) {
+        m_[f] = -INFINITY;
+        l_[f] = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { nm_[f][r] = 0.f; o_[0][f][r] = 0.f; o_[1][f][r] = 0.f; }
+    }
+    const bool has_skip = shi > slo;
+    const float c = p.q_prescaled ? 1.0f : p.scale * 1.44269504088896340736f;
+    const float inv_c = 1.0f / c;
+
+    auto compute = [&](int t) {
+        // ---- S^T = K Q^T - m : two 32-key tiles
+        f32x16 s_[2][QF];
+        u32x2 tr[2][8];   // V^T fragments; those of the first 32 keys start their trip behind the last K fragment: they are needed after
+                          // the maxima, the decision and the exponentials
+        if constexpr (F8) {
+            i32x4 kq[2][2];
+#pragma unroll
+            for (int th = 0; th < 2; ++th)
+#pragma unroll
+                for (int i = 0; i < 2; ++i) kq[th][i] = *reinterpret_cast<__attribute__((address_space(3))) const i32x4*>((size_t)(kaddr[i] + th * 32 * 64));
+            lds_tr_x8_issue_behind<0>(vaddr[0], vaddr[1], tr[0], kq[1][1]);
+#pragma unroll
+            for (int th = 0; th < 2; ++th) {
+                const i32x8 kfrag = __builtin_shufflevector(kq[th][0], kq[th][1], 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+                for (int f = 0; f < QF; ++f) s_[th][f] = mfma32_mx8(kfrag, qf8_[f], nm_[f]);
+            }
+        } else {
+            v8 kf[2][4];   // all eight fragment reads in flight before the first MFMA
+#pragma unroll
+            for (int th = 0; th < 2; ++th)
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) kf[th][ks] = *reinterpret_cast<__attribute__((address_space(3))) const v8*>((size_t)(kaddr[ks] + th * 32 * 128));
+            lds_tr_x8_issue_behind<0>(vaddr[0], vaddr[1], tr[0], kf[1][3]);
+#pragma unroll
+            for (int th = 0; th < 2; ++th)
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                    for (int f = 0; f < QF; ++f) s_[th][f] = mfma32(kf[th][ks], qf_[f][ks], ks == 0 ? nm_[f] : s_[th][f]);
+        }
+        if (!p.q_prescaled) {
+#pragma unroll
+            for (int th = 0; th < 2; ++th)
+#pragma unroll
+                for (int f = 0; f < QF; ++f) s_[th][f] *= c;
+        }
+        const int k0 = t * ATT_KT;
+        const bool need_mask = (k0 + ATT_KT > nk) || (has_skip && k0 < shi && k0 + ATT_KT > slo);
+        if (need_mask) {
+            // branch-free bit arithmetic (rare path; 32 compare masks would cost 64 SGPRs and spill the loop's scalars):
+            //   key >= nk                 <=>  (nk - 1 - key) < 0
+            //   slo <= key < shi          <=>  ((key - slo) | (shi - 1 - key)) >= 0
+            const int kb = k0 + 4 * lh;
+#pragma unroll
+            for (int th = 0; th < 2; ++th)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = kb + th * 32 + (r & 3) + 8 * (r >> 2);
+                    const int past = (nk - 1 - key) >> 31;                          // all ones: beyond the last key
+                    const int inside = ~(((key - slo) | (shi - 1 - key)) >> 31);   // all ones: inside the excluded range
+                    const float pen = __int_as_float((past | inside) & (int)0xff800000u);   // -inf or +0
+#pragma unroll
+                    for (int f = 0; f < QF; ++f) s_[th][f][r] += pen;
+                }
+        }
+        // ---- does any reference have to move?  one per-lane maximum over the lane's 32 scores of each query
+        float mxa = -INFINITY;
+        float mxl[QF];
+#pragma unroll
+        for (int f = 0; f < QF; ++f) {
+            mxl[f] = fmaxf(max16x(s_[0][f]), max16x(s_[1][f]));
+            mxa = f == 0 ? mxl[f] : fmaxf(mxa, mxl[f]);
+        }
+        if (any_first || __any(mxa > ATT_THR)) {   // wave-uniform, rare after the first tile: everything updated in place
+            bool fst = false;
+#pragma unroll
+            for (int f = 0; f < QF; ++f) {
+                float mx = mxl[f];
+                {   // the other half wave holds the other 32 keys of the same query
+                    const unsigned u = __float_as_uint(mx);
+                    auto q2 = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+                    mx = fmaxf(__uint_as_float(q2[0]), __uint_as_float(q2[1]));
+                }
+                const bool first = (m_[f] == -INFINITY);
+                float d = first ? mx : fmaxf(mx, 0.f);
+                d = (d == -INFINITY) ? 0.f : d;                       // row still has no valid key
+                const float alpha = first ? 1.0f : __builtin_amdgcn_exp2f(-d);
+                s_[0][f] -= d;
+                s_[1][f] -= d;
+                o_[0][f] *= alpha;
+                o_[1][f] *= alpha;
+                l_[f] *= alpha;
+                m_[f] = first ? ((mx == -INFINITY) ? -INFINITY : d) : m_[f] + d;
+                const float nm = (m_[f] == -INFINITY) ? 0.f : -m_[f] * inv_c;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) nm_[f][r] = nm;
+                fst |= (m_[f] == -INFINITY);
+            }
+            any_first = __any(fst);
+        }
+        // ---- O^T += V^T P^T, 16 keys per MFMA; the row sums ride along as VALU adds (four chains per query).  The transposing reads of
+        // a 32-key half are issued one stage ahead of the MFMAs that consume them (the exponentials / the other half's MFMAs in between).
+#pragma unroll
+        for (int th = 0; th < 2; ++th)
+#pragma unroll
+            for (int f = 0; f < QF; ++f)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s_[th][f][r] = __builtin_amdgcn_exp2f(s_[th][f][r]);
+#pragma unroll
+        for (int th = 0; th < 2; ++th) {
+            v8 pb[2][QF];
+#pragma unroll
+            for (int f = 0; f < QF; ++f) {
+                float a0 = s_[th][f][0] + s_[th][f][1], a1 = s_[th][f][2] + s_[th][f][3];
+                float a2 = s_[th][f][4] + s_[th][f][5], a3 = s_[th][f][6] + s_[th][f][7];
+#pragma unroll
+                for (int r = 8; r < 16; r += 4) {
+                    a0 += s_[th][f][r]; a1 += s_[th][f][r + 1]; a2 += s_[th][f][r + 2]; a3 += s_[th][f][r + 3];
+                }
+                l_[f] += (a0 + a1) + (a2 + a3);
+                pb[0][f] = cvt8<T>(__builtin_shufflevector(s_[th][f], s_[th][f], 0, 1, 2, 3, 4, 5, 6, 7));
+                pb[1][f] = cvt8<T>(__builtin_shufflevector(s_[th][f], s_[th][f], 8, 9, 10, 11, 12, 13, 14, 15));
+            }
+            lds_tr_x8_wait(tr[th], pb[0][0]);
+            if (th == 0) lds_tr_x8_issue_after<32 * 128>(vaddr[0], vaddr[1], tr[1], tr[0]);
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int dh = 0; dh < 2; ++dh) {
+                    v4 lo, hi;
+                    __builtin_memcpy(&lo, &tr[th][4 * m + 2 * dh], 8);
+                    __builtin_memcpy(&hi, &tr[th][4 * m + 2 * dh + 1], 8);
+                    const v8 vfrag = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+                    for (int f = 0; f < QF; ++f) o_[dh][f] = mfma32(vfrag, pb[m][f], o_[dh][f]);
+                }
+        }
+    };
+
+    int t = advance(t_begin - 1);
+    int buf = 0;
+    if (t < t_end) stage(t, 0);
+    while (t < t_end) {
+        __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0): this wave's pieces of tile t have landed
+        __syncthreads();
+        const int tn = advance(t);
+        if (tn < t_end) stage(tn, buf ^ 1);
+        compute(t);
+        const unsigned step = buf ? (unsigned)(-TB) : (unsigned)TB;
+#pragma unroll
+        for (int i = 0; i < (F8 ? 2 : 4); ++i) kaddr[i] += step;
+        vaddr[0] += step;
+        vaddr[1] += step;
+        buf ^= 1;
+        t = tn;
+    }
+
+    // ---- normalise and store: lane (q = lc, h) holds O[q][d = 32 dh + 8 j + 4 h + (0..3)] in registers 4 j .. 4 j + 3 of o_[dh]
+    T* __restrict__ O = reinterpret_cast<T*>(p.O);
+#pragma unroll
+    for (int f = 0; f < QF; ++f) {
+        float l = l_[f];
+        {
+            const unsigned u = __float_as_uint(l);
+            auto q2 = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+            l = __uint_as_float(q2[0]) + __uint_as_float(q2[1]);
+        }
+        const int q = qr0 + f * 32 + lc;
+        if (q >= vw.nq) continue;
+        const size_t row = (size_t)(vw.q_row0 + q);
+        const float inv = l > 0.f ? 1.0f / l : 0.f;
+        if (nsplit <= 1 || p.part16) {   // final output, or normalised partial O_s / l_s in the 16-bit type
+            T* dst = nsplit <= 1 ? O + row * p.ldo + head * 64 + lh * 4
+                                 : reinterpret_cast<T*>(p.part_o) + ((size_t)split * p.total_q_rows + row) * ((size_t)p.heads * 64) + head * 64 + lh * 4;
+#pragma unroll
+            for (int dh = 0; dh < 2; ++dh)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    f32x4 w;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) w[r] = o_[dh][f][4 * j + r] * inv;
+                    *reinterpret_cast<v4*>(dst + 32 * dh + 8 * j) = cvt4<T>(w);
+                }
+        } else {
+            float* po = p.part_o + ((size_t)split * p.total_q_rows + row) * ((size_t)p.heads * 64) + head * 64 + lh * 4;
+#pragma unroll
+            for (int dh = 0; dh < 2; ++dh)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    f32x4 w;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) w[r] = o_[dh][f][4 * j + r];
+                    *reinterpret_cast<f32x4*>(po + 32 * dh + 8 * j) = w;
+                }
+        }
+        if (nsplit > 1 && lh == 0) {
+            float* pm = p.part_ml + (((size_t)split * p.total_q_rows + row) * p.heads + head) * 2;
+            pm[0] = m_[f];
+            pm[1] = l;
+        }
+    }
+}
+
 // merge of the split-KV partials: O = sum_s 2^(m_s - m*) O_s / sum_s 2^(m_s - m*) l_s ; one thread = 4 columns
 template <class T>
 __global__ void attn_combine_kernel(const AttnArgs p, const int nsplit) {
@@ -1078,6 +1508,10 @@ size_t attention_split_scratch_bytes(int nsplit, int total_q_rows, int heads) {
     return (size_t)nsplit * total_q_rows * ((size_t)heads * 64 * 4 + (size_t)heads * 8) + 512;
 }
 
+bool attention_is_small(int nviews, int heads, int max_nq, int nsplit) {
+    return nsplit <= 1 && (long)nviews * heads * ((max_nq + ATT_QB - 1) / ATT_QB) < 192;
+}
+
 int attention_pick_split(int nviews, int heads, int max_nq, int max_nk) {
     // Measured model (r02, scripts/bench_attn.py + scripts/probes/attn_trace.hip): a block needs ~1.4 us per 64-key tile whether
     // two or three blocks share its CU (the wave's own QK -> softmax -> PV chain, not the CU's throughput, sets the pace), three
@@ -1121,9 +1555,9 @@ int launch_attention_phase(DType dt, const AttnArgs& a_in, int phase, hipStream_
     AttnArgs a = a_in;
     if (a.nviews <= 0 || a.max_nq <= 0) return 0;
     {   // split-KV partials of the fp16 attn3 path are written normalised, in fp16 (the bf16 / fp8 / older kernels keep fp32)
-        static const int variant0 = getenv("M3R_ATTN") ? atoi(getenv("M3R_ATTN")) : 2;
+        static const int variant0 = getenv("M3R_ATTN") ? atoi(getenv("M3R_ATTN")) : 4;
         static const bool p16 = !(getenv("M3R_ATTN_PART16") && atoi(getenv("M3R_ATTN_PART16")) == 0);
-        a.part16 = (p16 && variant0 == 2 && dt == DT_F16 && !a.fp8 && a.nsplit > 1) ? 1 : 0;
+        a.part16 = (p16 && (variant0 == 2 || variant0 == 4) && dt == DT_F16 && a.nsplit > 1) ? 1 : 0;
     }
     if ((a.ldq % (a.fp8 ? 16 : 8)) || (a.ldk % (a.fp8 ? 16 : 8)) || (a.ldv % (a.fp8 ? 16 : 8)) || (a.ldo % 4)) { *err = "attention: row strides must be 16-byte aligned"; return 1; }
     const int nsplit = a.nsplit > 1 ? a.nsplit : 1;
@@ -1132,7 +1566,13 @@ int launch_attention_phase(DType dt, const AttnArgs& a_in, int phase, hipStream_
     // update: 12 heads x 6 query blocks) run with 16 query rows per wave: twice the blocks, half the serial work each.
     const int ngrp = a.nviews * a.heads;
     // (measured: for the split-KV cross attention the 16-row variant is slower, 24.0 vs 22.7 ms per scene)
-    const bool small = nsplit == 1 && (long)ngrp * ((a.max_nq + ATT_QB - 1) / ATT_QB) < 192;
+    // (fp8 operands only exist for the 32 x 32 kernel, which has no 16-row form: the model keeps such launches on 16-bit operands)
+    const bool small = !a.fp8 && attention_is_small(a.nviews, a.heads, a.max_nq, nsplit);
+    // 32-bit byte offsets inside one view's K / V rows (buffer descriptors, per-lane voffsets): refuse what would wrap
+    if (a.max_nk > 0 && ((long long)a.max_nk * a.ldk * (a.fp8 ? 1 : 2) >= 0x7fffffffLL || (long long)a.max_nk * a.ldv * 2 >= 0x7fffffffLL)) {
+        *err = "attention: a view's K / V rows span 2 GiB or more (32-bit staging offsets)";
+        return 1;
+    }
     // Experiment builds only (make EXTRA=-DM3R_ATTN_EXPERIMENTS): M3R_ATTN_QW = 48 / 64 query rows per wave for the launches that are not
     // `small` (equal / spilling, profiles/r02_attn3_ablation.txt) and the M3R_ATTN_ABL timing ablations of attn3_kernel, which compute
     // WRONG results on purpose -- neither is compiled into the product library.
@@ -1145,7 +1585,11 @@ int launch_attention_phase(DType dt, const AttnArgs& a_in, int phase, hipStream_
 #else
     constexpr int qw_big = 32;
 #endif
-    const int qb_rows = small ? 64 : 4 * qw_big;
+    // M3R_ATTN_QF=2 (experiments): 64 query rows per wave in the 32 x 32 kernel (one wave per SIMD, 512 registers)
+    static const bool qf2_env = getenv("M3R_ATTN_QF") && atoi(getenv("M3R_ATTN_QF")) == 2;
+    static const int variant1 = getenv("M3R_ATTN") ? atoi(getenv("M3R_ATTN")) : 4;
+    const bool qf2 = qf2_env && variant1 == 4 && !small && !a.fp8;
+    const int qb_rows = small ? 64 : (qf2 ? 256 : 4 * qw_big);
     const int nqb_abs = (a.max_nq + qb_rows - 1) / qb_rows;
     const int npairs = ngrp * nsplit;
     // pairs dealt over the 8 XCDs; per-block round robin when that would leave the XCDs more than 10 % apart (see attn_block_coords)
@@ -1165,13 +1609,15 @@ int launch_attention_phase(DType dt, const AttnArgs& a_in, int phase, hipStream_
         static int variant = -1;
         if (variant < 0) {
             const char* e = getenv("M3R_ATTN");
-            variant = e ? atoi(e) : 2;
+            variant = e ? atoi(e) : 4;
         }
 #define M3R_LAUNCH_ATTN(KERNEL) hipLaunchKernelGGL(KERNEL, dim3(grid), dim3(256), 0, s, a, nqb, ngrp, nsplit)
-        if (a.fp8) {
-            if (small) { if (dt == DT_BF16) M3R_LAUNCH_ATTN((attn2_kernel<bf16_t, 16, true>)); else M3R_LAUNCH_ATTN((attn2_kernel<f16_t, 16, true>)); }
-            else { if (dt == DT_BF16) M3R_LAUNCH_ATTN((attn2_kernel<bf16_t, 32, true>)); else M3R_LAUNCH_ATTN((attn2_kernel<f16_t, 32, true>)); }
-        } else if (variant == 2) {
+        if (a.fp8) {   // e4m3 Q / K through the MX-scaled 32x32x64 MFMA, 16-bit P / V
+            if (dt == DT_BF16) M3R_LAUNCH_ATTN((attn4_kernel<bf16_t, 1, true>)); else M3R_LAUNCH_ATTN((attn4_kernel<f16_t, 1, true>));
+        } else if (variant == 4 && !small) {
+            if (qf2) { if (dt == DT_BF16) M3R_LAUNCH_ATTN((attn4_kernel<bf16_t, 2, false>)); else M3R_LAUNCH_ATTN((attn4_kernel<f16_t, 2, false>)); }
+            else if (dt == DT_BF16) M3R_LAUNCH_ATTN((attn4_kernel<bf16_t, 1, false>)); else M3R_LAUNCH_ATTN((attn4_kernel<f16_t, 1, false>));
+        } else if (variant == 2 || variant == 4) {
 #ifdef M3R_ATTN_EXPERIMENTS
             static const int abl = getenv("M3R_ATTN_ABL") ? atoi(getenv("M3R_ATTN_ABL")) : 0;   // timing ablations (wrong results)
             if (!small && dt == DT_F16 && abl == 1) M3R_LAUNCH_ATTN((attn3_kernel<f16_t, 32, 1>));

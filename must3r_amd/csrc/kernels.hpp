@@ -113,13 +113,18 @@ struct AttnArgs {
     int total_q_rows;      // max over views of q_row0 + nq
     int dense_rows;        // every row < total_q_rows belongs to a view of this launch (no (m,l) pre-fill needed)
     int part16;            // set by the launcher: part_o holds O_s / l_s in the 16-bit operand type instead of fp32 O_s
-    int fp8;               // Q, K, V are OCP e4m3 bytes (row strides in bytes); O stays 16-bit.  attn2_kernel<.., F8 = true>
+    int fp8;               // Q and K are OCP e4m3 bytes (ldq / ldk in BYTES): Q K^T runs on v_mfma_scale_f32_32x32x64_f8f6f4; V (ldv in elements), the
+                           // softmax numerators and O stay 16-bit (attn4_kernel<.., F8 = true>; DESIGN.md section 4 for why V does)
+    int max_nk;            // max over views of nk when the host knows it (0: unknown): lets the launcher refuse K / V spans of 2 GiB or more
 };
 // bytes of scratch launch_attention needs for a given split factor
 size_t attention_split_scratch_bytes(int nsplit, int total_q_rows, int heads);
 // heuristic split factor for a launch
 int attention_pick_split(int nviews, int heads, int max_nq, int max_nk);
 int launch_attention(DType dt, const AttnArgs& a, hipStream_t s, const char** err);
+// launches too small to fill the chip with 128-query blocks run the 16-row-per-wave 16 x 16 kernel (16-bit operands only): the model
+// does not quantise Q / K for those
+bool attention_is_small(int nviews, int heads, int max_nq, int nsplit);
 // the three launches of a split-KV attention, separately (profiling): (m,l) pre-fill, main kernel, combine
 int launch_attention_phase(DType dt, const AttnArgs& a, int phase, hipStream_t s, const char** err);
 
@@ -158,9 +163,11 @@ int launch_layernorm(DType dt, const LnArgs& a, hipStream_t s, const char** err)
 int launch_im2col(DType dt, const float* img, void* out16, int V, int H, int W, hipStream_t s, const char** err);
 // fp32 -> 16-bit (and optional low part)
 int launch_cast(DType dt, const float* in, void* out16, void* out16_lo, size_t n, hipStream_t s, const char** err);
-// 16-bit [rows, ld_in] -> e4m3 bytes [rows, ld_out] (clamped to +-448); optional per-group output table (rows_per_group rows each)
+// 16-bit [rows, ld_in] -> e4m3 bytes [rows, ld_out] (clamped to +-448); optional per-group output table (rows_per_group rows each).
+// tail_cols > 0: input columns [cols, cols + tail_cols) are copied verbatim (16-bit) behind the e4m3 bytes: output row =
+// [cols bytes e4m3 | tail_cols x 16-bit] -- the K (e4m3) | V (16-bit) memory rows of the fp8 attention mode.  ld_out in BYTES.
 int launch_quant8(DType dt, const void* in16, int ld_in, void* out8, int ld_out, void* const* out_table, int rows_per_group,
-                  size_t rows, int cols, hipStream_t s, const char** err);
+                  size_t rows, int cols, int tail_cols, hipStream_t s, const char** err);
 // pos int64 [V, gh*gw, 2] = (y, x) row-major grid
 int launch_fill_pos(int64_t* pos, int V, int gh, int gw, hipStream_t s, const char** err);
 // pointmaps [npix,7] fp32 -> pts3d [npix,3], pts3d_local [npix,3], conf [npix]

@@ -163,14 +163,26 @@ int launch_cast(DType dt, const float* in, void* out16, void* out16_lo, size_t n
 // ------------------------------------------------------------------------------------------------
 template <class T>
 __global__ void quant8_kernel(const T* __restrict__ in, int ld_in, unsigned char* __restrict__ out, int ld_out, void* const* out_table,
-                              int rows_per_group, size_t rows, int cols) {
+                              int rows_per_group, size_t rows, int cols, int tail_cols) {
     typedef typename Vec<T>::v8 v8;
-    const int cpr = cols / 8;
+    const int cpr = (cols + tail_cols) / 8;
     const size_t total = rows * (size_t)cpr;
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
         const size_t r = idx / cpr;
         const int c = (int)(idx - r * cpr) * 8;
-        const f32x8 x = __builtin_convertvector(*reinterpret_cast<const v8*>(in + r * ld_in + c), f32x8);
+        const v8 raw = *reinterpret_cast<const v8*>(in + r * ld_in + c);
+        unsigned char* dst = out;
+        size_t rr = r;
+        if (out_table) {
+            const size_t g = r / rows_per_group;
+            dst = reinterpret_cast<unsigned char*>(out_table[g]);
+            rr = r - g * rows_per_group;
+        }
+        if (c >= cols) {   // 16-bit tail, copied as is
+            *reinterpret_cast<v8*>(dst + rr * ld_out + cols + (size_t)(c - cols) * 2) = raw;
+            continue;
+        }
+        const f32x8 x = __builtin_convertvector(raw, f32x8);
         float y[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) y[e] = __builtin_amdgcn_fmed3f(x[e], -448.0f, 448.0f);
@@ -179,25 +191,18 @@ __global__ void quant8_kernel(const T* __restrict__ in, int ld_in, unsigned char
         lo = __builtin_amdgcn_cvt_pk_fp8_f32(y[2], y[3], lo, true);
         hi = __builtin_amdgcn_cvt_pk_fp8_f32(y[4], y[5], hi, false);
         hi = __builtin_amdgcn_cvt_pk_fp8_f32(y[6], y[7], hi, true);
-        unsigned char* dst = out;
-        size_t rr = r;
-        if (out_table) {
-            const size_t g = r / rows_per_group;
-            dst = reinterpret_cast<unsigned char*>(out_table[g]);
-            rr = r - g * rows_per_group;
-        }
         *reinterpret_cast<u32x2*>(dst + rr * ld_out + c) = u32x2{(unsigned)lo, (unsigned)hi};
     }
 }
 
 int launch_quant8(DType dt, const void* in16, int ld_in, void* out8, int ld_out, void* const* out_table, int rows_per_group,
-                  size_t rows, int cols, hipStream_t s, const char** err) {
-    if (!rows || !cols) return 0;
-    if (cols % 8 || ld_in % 8 || ld_out % 8) { *err = "quant8: cols and row strides must be multiples of 8"; return 1; }
-    const size_t total = rows * (size_t)(cols / 8);
+                  size_t rows, int cols, int tail_cols, hipStream_t s, const char** err) {
+    if (!rows || !(cols + tail_cols)) return 0;
+    if (cols % 16 || tail_cols % 8 || ld_in % 8 || ld_out % 16) { *err = "quant8: cols % 16, tail_cols % 8, ld_in % 8, ld_out % 16"; return 1; }
+    const size_t total = rows * (size_t)((cols + tail_cols) / 8);
     const int grid = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
-    if (dt == DT_BF16) hipLaunchKernelGGL(quant8_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t*)in16, ld_in, (unsigned char*)out8, ld_out, out_table, rows_per_group, rows, cols);
-    else hipLaunchKernelGGL(quant8_kernel<f16_t>, dim3(grid), dim3(256), 0, s, (const f16_t*)in16, ld_in, (unsigned char*)out8, ld_out, out_table, rows_per_group, rows, cols);
+    if (dt == DT_BF16) hipLaunchKernelGGL(quant8_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t*)in16, ld_in, (unsigned char*)out8, ld_out, out_table, rows_per_group, rows, cols, tail_cols);
+    else hipLaunchKernelGGL(quant8_kernel<f16_t>, dim3(grid), dim3(256), 0, s, (const f16_t*)in16, ld_in, (unsigned char*)out8, ld_out, out_table, rows_per_group, rows, cols, tail_cols);
     if (hipGetLastError() != hipSuccess) { *err = "quant8: launch failed"; return 1; }
     return 0;
 }

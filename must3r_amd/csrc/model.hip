@@ -221,10 +221,10 @@ static int layernorm(must3r_hip_ctx* c, DType dt, const float* x, const float* a
     return layernorm_a(c, dt, lnargs(x, add, w, b, o16, o16lo, o32, copy, M, C, eps), s);
 }
 static int quant8(must3r_hip_ctx* c, DType dt, const void* in16, int ld_in, void* out8, int ld_out, void* const* out_table,
-                  int rows_per_group, size_t rows, int cols, hipStream_t s) {
+                  int rows_per_group, size_t rows, int cols, int tail_cols, hipStream_t s) {
     const char* err = "";
     ProfScope ps(c, s, PC_MISC, 0.0);
-    if (launch_quant8(dt, in16, ld_in, out8, ld_out, out_table, rows_per_group, rows, cols, s, &err)) return fail("%s", err);
+    if (launch_quant8(dt, in16, ld_in, out8, ld_out, out_table, rows_per_group, rows, cols, tail_cols, s, &err)) return fail("%s", err);
     return 0;
 }
 static int attention(must3r_hip_ctx* c, DType dt, const AttnArgs& a, double flops, int cat, hipStream_t s) {
@@ -631,7 +631,7 @@ static int encode_chunk(must3r_hip_ctx* c, DType dt, const float* img, int V, in
     need = ws_need(need, (size_t)R * 3 * C, 2);
     need = ws_need(need, (size_t)R * C, 2);
     need = ws_need(need, (size_t)R * F, 2);
-    need = ws_need(need, c->attn8 ? (size_t)R * 3 * C : 0, 1);
+    need = ws_need(need, c->attn8 ? (size_t)R * 2 * C : 0, 1);
     M3R_OK(ws_reserve(c, need, s));
     uint16_t* P16 = ws_take<uint16_t>(c, (size_t)R * 768);
     float* x = ws_take<float>(c, (size_t)R * C);
@@ -639,7 +639,7 @@ static int encode_chunk(must3r_hip_ctx* c, DType dt, const float* img, int V, in
     uint16_t* qkv = ws_take<uint16_t>(c, (size_t)R * 3 * C);
     uint16_t* a16 = ws_take<uint16_t>(c, (size_t)R * C);
     uint16_t* g16 = ws_take<uint16_t>(c, (size_t)R * F);
-    uint8_t* q8 = c->attn8 ? ws_take<uint8_t>(c, (size_t)R * 3 * C) : nullptr;
+    uint8_t* q8 = c->attn8 ? ws_take<uint8_t>(c, (size_t)R * 2 * C) : nullptr;
     if (!g16 || (c->attn8 && !q8)) return fail("encode: workspace sizing bug");
 
     {
@@ -671,10 +671,11 @@ static int encode_chunk(must3r_hip_ctx* c, DType dt, const float* img, int V, in
         aa.ldq = aa.ldk = aa.ldv = 3 * C; aa.ldo = C; aa.heads = Hh;
         aa.views = reinterpret_cast<const AttnView*>(views_dev); aa.nviews = V; aa.max_nq = N; aa.scale = 0.125f;
         aa.q_prescaled = 1;
-        if (c->attn8) {   // e4m3 copies of q | k | v (same row layout, one byte per element)
-            M3R_OK(quant8(c, dt, qkv, 3 * C, q8, 3 * C, nullptr, 0, (size_t)R, 3 * C, s));
-            aa.Q = q8; aa.K = q8 + C; aa.V = q8 + 2 * C; aa.fp8 = 1;
+        if (c->attn8 && !attention_is_small(V, Hh, N, 1)) {   // e4m3 copies of q | k (one byte per element); V stays 16-bit
+            M3R_OK(quant8(c, dt, qkv, 3 * C, q8, 2 * C, nullptr, 0, (size_t)R, 2 * C, 0, s));
+            aa.Q = q8; aa.K = q8 + C; aa.ldq = aa.ldk = 2 * C; aa.fp8 = 1;
         }
+        aa.max_nk = N;
         M3R_OK(attention(c, dt, aa, 4.0 * V * (double)N * N * C, PC_ATTN_SA, s));
         M3R_OK(w16p(c, *LP[LF_PROJW], dt, &w, s));
         M3R_OK(gemm(c, dt, EPI_RESID_F32, gargs(a16, w, LP[LF_PROJB]->d, x, R, C, C, C, C), s));
@@ -807,7 +808,8 @@ static int decode_impl(must3r_hip_ctx* c, const must3r_hip_decode_args* A, void*
     // per layer per call into scratch (the reference re-projects them per query view, layers.py:92-96)
     const int mode = A->mem_mode;
     const int memD = mode == MUST3R_MEM_KV ? 2 * D : D;
-    const int memES = (a8 && mode == MUST3R_MEM_KV) ? 1 : 2;   // bytes per memory element: e4m3 K|V rows in fp8-attention mode
+    // bytes of a memory row: 16-bit elements, except the K (e4m3, D bytes) | V (16-bit, 2 D bytes) rows of the fp8-attention mode
+    const size_t memRB = (a8 && mode == MUST3R_MEM_KV) ? (size_t)3 * D : (size_t)memD * 2;
     const size_t kvs_rows1 = mode == MUST3R_MEM_KV ? 0 : (size_t)max_nk_ca;   // per scene
     const size_t kvs_rows = kvs_rows1 * S;
     need = ws_need(need, kvs_rows * 2 * D, 2);
@@ -815,9 +817,9 @@ static int decode_impl(must3r_hip_ctx* c, const must3r_hip_decode_args* A, void*
     // fp8 attention: e4m3 copies of q|k|v (self) / q (cross), 16-bit staging of freshly projected K|V rows before they are
     // quantised into the memory, e4m3 copy of the per-call K|V projection of the 'norm_y' / 'raw' modes
     const size_t kv16_rows = (a8 && mode == MUST3R_MEM_KV && update) ? (size_t)L * R : 0;
-    need = ws_need(need, a8 ? (size_t)R * 3 * D : 0, 1);
+    need = ws_need(need, a8 ? (size_t)R * 2 * D : 0, 1);
     need = ws_need(need, kv16_rows * 2 * D, 2);
-    need = ws_need(need, a8 ? kvs_rows * 2 * D : 0, 1);
+    need = ws_need(need, a8 ? kvs_rows * D : 0, 1);
     M3R_OK(ws_reserve(c, need, s));
     uint16_t* t16 = ws_take<uint16_t>(c, (size_t)R * C);
     float* x = ws_take<float>(c, (size_t)R * D);
@@ -838,9 +840,9 @@ static int decode_impl(must3r_hip_ctx* c, const must3r_hip_decode_args* A, void*
     char* split_ws = split_bytes ? ws_take<char>(c, split_bytes) : nullptr;
     uint16_t* kvs = kvs_rows ? ws_take<uint16_t>(c, kvs_rows * 2 * D) : nullptr;
     uint16_t* ytmp = (mode == MUST3R_MEM_RAW && kvs_rows) ? ws_take<uint16_t>(c, kvs_rows * D) : nullptr;
-    uint8_t* q8 = a8 ? ws_take<uint8_t>(c, (size_t)R * 3 * D) : nullptr;
+    uint8_t* q8 = a8 ? ws_take<uint8_t>(c, (size_t)R * 2 * D) : nullptr;
     uint16_t* kv16 = kv16_rows ? ws_take<uint16_t>(c, kv16_rows * 2 * D) : nullptr;
-    uint8_t* kvs8 = (a8 && kvs_rows) ? ws_take<uint8_t>(c, kvs_rows * 2 * D) : nullptr;
+    uint8_t* kvs8 = (a8 && kvs_rows) ? ws_take<uint8_t>(c, kvs_rows * D) : nullptr;   // e4m3 K of the per-call projection ('norm_y' / 'raw')
     if (!g16 || (update && !off32) || (split_bytes && !split_ws) || (a8 && !q8) || (kv16_rows && !kv16) || (a8 && kvs_rows && !kvs8))
         return fail("decode: workspace sizing bug");
 
@@ -884,7 +886,7 @@ static int decode_impl(must3r_hip_ctx* c, const must3r_hip_decode_args* A, void*
         std::vector<void*> outs(2 * (size_t)L * S);
         for (int l = 0; l < L; ++l)
             for (int b = 0; b < S; ++b) {
-                void* memrow = reinterpret_cast<char*>(A->mem[l]) + ((size_t)b * mem_stride + Nm) * 2 * D * memES;
+                void* memrow = reinterpret_cast<char*>(A->mem[l]) + ((size_t)b * mem_stride + Nm) * memRB;
                 outs[(size_t)l * S + b] = a8 ? static_cast<void*>(kv16 + ((size_t)l * S + b) * Rs * 2 * D) : memrow;
                 outs[(size_t)L * S + (size_t)l * S + b] = memrow;
             }
@@ -945,11 +947,12 @@ static int decode_impl(must3r_hip_ctx* c, const must3r_hip_decode_args* A, void*
         // one problem per scene (same weights): rows [b Rs, (b+1) Rs) -> memory rows of scene b (fp8 memory: 16-bit staging rows first)
         GemmArgs gk = gargs(h16, wk, LP[LF_PKVB]->d, nullptr, Rs, 2 * D, D, D, 2 * D);
         gk.batch = S; gk.strideA = (long long)Rs * D; gk.out_table = kvout + (size_t)l * S;
-        if (S == 1) { gk.batch = 0; gk.out_table = nullptr; gk.out = a8 ? static_cast<void*>(kv16) : reinterpret_cast<char*>(A->mem[l]) + (size_t)Nm * memD * memES; }
+        if (S == 1) { gk.batch = 0; gk.out_table = nullptr; gk.out = a8 ? static_cast<void*>(kv16) : reinterpret_cast<char*>(A->mem[l]) + (size_t)Nm * memRB; }
         M3R_OK(gemm(c, dt, EPI_STORE16, gk, st));
         if (!a8) return 0;
-        return quant8(c, dt, kv16 + (size_t)l * S * Rs * 2 * D * (S > 1 ? 1 : 0), 2 * D, S == 1 ? reinterpret_cast<char*>(A->mem[l]) + (size_t)Nm * memD * memES : nullptr,
-                      2 * D, S > 1 ? kvout + (size_t)L * S + (size_t)l * S : nullptr, Rs, (size_t)R, 2 * D, st);
+        // K -> e4m3, V copied: memory rows [K e4m3 | V 16-bit]
+        return quant8(c, dt, kv16 + (size_t)l * S * Rs * 2 * D * (S > 1 ? 1 : 0), 2 * D, S == 1 ? reinterpret_cast<char*>(A->mem[l]) + (size_t)Nm * memRB : nullptr,
+                      3 * D, S > 1 ? kvout + (size_t)L * S + (size_t)l * S : nullptr, Rs, (size_t)R, D, D, st);
     };
     // K|V rows the cross attention of layer l reads: the memory itself ('kv') or a projection of it into scratch
     auto kv_source = [&](int l, const void** kptr, hipStream_t st) -> int {
@@ -970,10 +973,7 @@ static int decode_impl(must3r_hip_ctx* c, const must3r_hip_decode_args* A, void*
             M3R_OK(gemm(c, dt, EPI_STORE16, gargs(src, wk, LP[LF_PKVB]->d, kvs + (size_t)b * rows * 2 * D, rows, 2 * D, D, D, 2 * D), st));
         }
         *kptr = kvs;
-        if (a8) {
-            M3R_OK(quant8(c, dt, kvs, 2 * D, kvs8, 2 * D, nullptr, 0, (size_t)kvs_rows, 2 * D, st));
-            *kptr = kvs8;
-        }
+        if (a8) M3R_OK(quant8(c, dt, kvs, 2 * D, kvs8, D, nullptr, 0, (size_t)kvs_rows, D, 0, st));   // K -> e4m3 (V is read from kvs)
         return 0;
     };
 
@@ -1012,10 +1012,11 @@ static int decode_impl(must3r_hip_ctx* c, const must3r_hip_decode_args* A, void*
         aa.ldq = aa.ldk = aa.ldv = 3 * D; aa.ldo = D; aa.heads = Hh;
         aa.views = sa_views; aa.nviews = total_views; aa.max_nq = max_n; aa.scale = 0.125f; aa.q_prescaled = 1;
         if (total_views == 1) { aa.view0_inline = 1; aa.view0 = tab[0]; }
-        if (a8) {
-            M3R_OK(quant8(c, dt, qkv, 3 * D, q8, 3 * D, nullptr, 0, (size_t)R, 3 * D, s));
-            aa.Q = q8; aa.K = q8 + D; aa.V = q8 + 2 * D; aa.fp8 = 1;
+        if (a8 && !attention_is_small(total_views, Hh, max_n, 1)) {
+            M3R_OK(quant8(c, dt, qkv, 3 * D, q8, 2 * D, nullptr, 0, (size_t)R, 2 * D, 0, s));
+            aa.Q = q8; aa.K = q8 + D; aa.ldq = aa.ldk = 2 * D; aa.fp8 = 1;
         }
+        aa.max_nk = max_n;
         M3R_OK(attention(c, dt, aa, sa_flops, PC_ATTN_SA, s));
         M3R_OK(w16p(c, *LP[LF_PROJW], dt, &w, s));
         {
@@ -1039,10 +1040,13 @@ static int decode_impl(must3r_hip_ctx* c, const must3r_hip_decode_args* A, void*
         memset(&aa, 0, sizeof(aa));
         aa.Q = q16; aa.K = mk; aa.V = reinterpret_cast<const uint16_t*>(mk) + D; aa.O = a16;
         aa.ldq = D; aa.ldk = aa.ldv = 2 * D; aa.ldo = D; aa.heads = Hh;
-        if (a8) {
-            M3R_OK(quant8(c, dt, q16, D, q8, D, nullptr, 0, (size_t)R, D, s));
-            aa.Q = q8; aa.V = reinterpret_cast<const uint8_t*>(mk) + D; aa.fp8 = 1;
+        if (a8) {   // e4m3 q and K; 'kv' memory rows are [K e4m3 (D bytes) | V 16-bit]: ldk in bytes, ldv in 16-bit elements
+            M3R_OK(quant8(c, dt, q16, D, q8, D, nullptr, 0, (size_t)R, D, 0, s));
+            aa.Q = q8; aa.fp8 = 1;
+            if (mode == MUST3R_MEM_KV) { aa.ldk = 3 * D; aa.ldv = 3 * D / 2; aa.V = reinterpret_cast<const char*>(mk) + D; }
+            else { aa.K = kvs8; aa.ldk = D; }   // per-call projection: K from its e4m3 copy, V from the 16-bit scratch rows
         }
+        aa.max_nk = max_nk_ca;
         aa.views = ca_views; aa.nviews = total_views; aa.max_nq = max_n; aa.scale = 0.125f; aa.q_prescaled = 1;
         if (total_views == 1) { aa.view0_inline = 1; aa.view0 = tab[total_views]; }
         if (ca_split > 1) {
@@ -1144,7 +1148,7 @@ static int decode_impl(must3r_hip_ctx* c, const must3r_hip_decode_args* A, void*
             gk.batch = L * S; gk.wdiv = S; gk.strideA = (long long)Rs * D; gk.strideW = (long long)2 * D * D * (c->wsplit == 2 ? 2 : 1);
             gk.strideB = 2 * D; gk.out_table = kvout;
             M3R_OK(gemm(c, dt, EPI_STORE16, gk, s));
-            if (a8) M3R_OK(quant8(c, dt, kv16, 2 * D, nullptr, 2 * D, kvout + (size_t)L * S, Rs, (size_t)L * R, 2 * D, s));
+            if (a8) M3R_OK(quant8(c, dt, kv16, 2 * D, nullptr, 3 * D, kvout + (size_t)L * S, Rs, (size_t)L * R, D, D, s));
         } else {
             for (int l = 0; l < L; ++l)
                 M3R_OK(kv_project(l, newmem + (size_t)l * R * D, l < L - 1 ? off32 : nullptr, nullptr, s));
@@ -1209,8 +1213,8 @@ extern "C" int must3r_hip_decode(must3r_hip_ctx* c, const must3r_hip_decode_args
         const int per = views_s <= max_views ? (int)(max_views / views_s) : 1;
         std::vector<must3r_hip_group> gs(A->n_groups);
         std::vector<void*> mems(c->cfg.dec_depth);
-        const long long memD = A->mem_mode == MUST3R_MEM_KV ? 2LL * c->cfg.dec_dim : 1LL * c->cfg.dec_dim;
-        const long long memES = ((A->dtype & MUST3R_ATTN_FP8) && A->mem_mode == MUST3R_MEM_KV) ? 1 : 2;
+        const long long memRB = ((A->dtype & MUST3R_ATTN_FP8) && A->mem_mode == MUST3R_MEM_KV) ? 3LL * c->cfg.dec_dim
+                                : (A->mem_mode == MUST3R_MEM_KV ? 4LL : 2LL) * c->cfg.dec_dim;
         for (int b0 = 0; b0 < S; b0 += per) {
             const int nb = S - b0 < per ? S - b0 : per;
             for (int gi = 0; gi < A->n_groups; ++gi) {
@@ -1221,7 +1225,7 @@ extern "C" int must3r_hip_decode(must3r_hip_ctx* c, const must3r_hip_decode_args
                 gs[gi].pointmaps += (size_t)b0 * gs[gi].n_views * gs[gi].H * gs[gi].W * 7;
             }
             for (int l = 0; l < c->cfg.dec_depth; ++l)
-                mems[l] = reinterpret_cast<char*>(A->mem[l]) + (size_t)b0 * A->mem_scene_stride * memD * memES;
+                mems[l] = reinterpret_cast<char*>(A->mem[l]) + (size_t)b0 * A->mem_scene_stride * memRB;
             sub.groups = gs.data(); sub.mem = mems.data(); sub.n_scenes = nb;
             M3R_OK(must3r_hip_decode(c, &sub, stream));
         }

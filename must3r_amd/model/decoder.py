@@ -136,9 +136,10 @@ class MUSt3R(HipModule):
         return operand_dtype(self.precision)  # no autocast, or fp16 autocast with an fp16-family precision
 
     # -- memory management ---------------------------------------------------------------------
-    def _writable_memory(self, mem_vals, Nm, R, tdt, device, B=1):
+    def _writable_memory(self, mem_vals, Nm, R, tdt, device, B=1, mem_D=None):
         """Return the buffers whose rows [0,Nm) (of every scene) hold ``mem_vals`` and that can take R more rows per scene."""
-        mem_D = 2 * self.embed_dim if self.memory_mode == "kv" else self.embed_dim
+        if mem_D is None:
+            mem_D = 2 * self.embed_dim if self.memory_mode == "kv" else self.embed_dim
         owner = None
         if mem_vals is not None and len(mem_vals) == self.depth:
             owner = getattr(mem_vals[0], "_m3r_owner", None)
@@ -146,7 +147,7 @@ class MUSt3R(HipModule):
             if ok:
                 for v, b in zip(mem_vals, owner.bufs):
                     if getattr(v, "_m3r_owner", None) is not owner or v.data_ptr() != b.data_ptr() or v.dtype != tdt \
-                            or v.shape[0] != B or v.shape[1] != Nm or v.device != b.device:
+                            or v.shape[0] != B or v.shape[1] != Nm or v.shape[2] != mem_D or v.device != b.device:
                         ok = False
                         break
             if not ok:
@@ -215,8 +216,9 @@ class MUSt3R(HipModule):
         device = torch.device("cuda", dev)
         odt = self._operand()
         tdt = _TORCH_DT[odt]
-        if self.attention_fp8 and self.memory_mode == "kv":
-            tdt = torch.float8_e4m3fn      # the memory holds e4m3 K|V rows: half the footprint, half the cross-attention traffic
+        fp8_rows = self.attention_fp8 and self.memory_mode == "kv"
+        if fp8_rows:
+            tdt = torch.uint8   # opaque rows [K e4m3: D bytes | V 16-bit: 2 D bytes] = 3/4 of the 16-bit footprint (include/must3r_hip.h)
         D = self.embed_dim
         assert not render or current_mem is not None  # decoder.py:278
 
@@ -252,7 +254,7 @@ class MUSt3R(HipModule):
             Nm = int(mem_vals[0].shape[1])
             assert all(int(v.shape[0]) == B for v in mem_vals), "memory and inputs must share the batch size"
 
-        mem_D = 2 * D if self.memory_mode == "kv" else D
+        mem_D = (3 * D if fp8_rows else 2 * D) if self.memory_mode == "kv" else D
         if render:
             # read-only: any [B, Nm, mem_D] tensors whose rows are contiguous and whose scene stride is the same in every layer
             # (the prefix views of this module's own buffers are: stride cap x mem_D) are read in place
@@ -270,7 +272,7 @@ class MUSt3R(HipModule):
             keep += vals
             cap, stride = Nm, (0 if B == 1 else stride)   # read-only: the rows that exist are the capacity
         else:
-            owner = self._writable_memory(mem_vals, Nm, R, tdt, device, B)
+            owner = self._writable_memory(mem_vals, Nm, R, tdt, device, B, mem_D)
             ptrs = (C.c_void_p * self.depth)(*[b.data_ptr() for b in owner.bufs])
             cap, stride = owner.cap, owner.cap
 

@@ -1,5 +1,5 @@
-"""Microbenchmark of the attention kernels on the scene's shapes.  M3R_ATTN=0 selects the round-1 kernel, default the
-pipelined attn2_kernel; FP8=1 times the e4m3 operand variant.  Prints median / min over interleaved rounds."""
+"""Microbenchmark of the attention kernels on the scene's shapes.  M3R_ATTN=4 (default) = the 32x32-tile attn4_kernel, 2 = attn3_kernel;
+FP8=1 times the e4m3 Q/K variant (MX-scaled 32x32x64 MFMA for Q K^T).  Prints median / min over interleaved rounds."""
 import os, sys, torch, ctypes as C
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from must3r_amd import _lib as lib
@@ -12,13 +12,21 @@ def make(name, heads, nviews, nq, nk, self_attn, nsplit=0):
     dt = torch.float8_e4m3fn if FP8 else torch.float16
     torch.manual_seed(0)
     if self_attn:
-        qkv = (torch.randn((nviews * nq, 3 * D), device="cuda")).to(dt)
+        qkv = (torch.randn((nviews * nq, 3 * D), device="cuda")).half()
         q, k, v = qkv[:, :D], qkv[:, D:2*D], qkv[:, 2*D:]
+        if FP8:   # e4m3 q | k rows, V stays fp16
+            qk8 = qkv[:, :2 * D].to(dt)
+            q, k = qk8[:, :D], qk8[:, D:]
         views = [(i * nq, nq, i * nq, nq, 0, 0) for i in range(nviews)]
     else:
         q = torch.randn((nviews * nq, D), device="cuda").to(dt)
-        kv = torch.randn((nk, 2 * D), device="cuda").to(dt)
-        k, v = kv[:, :D], kv[:, D:]
+        if FP8:   # memory rows [K e4m3 (D bytes) | V fp16 (2 D bytes)]
+            rows = torch.empty((nk, 3 * D), dtype=torch.uint8, device="cuda")
+            k, v = rows[:, :D].view(dt), rows[:, D:].view(torch.float16)
+            k.copy_(torch.randn((nk, D), device="cuda").to(dt)); v.copy_(torch.randn((nk, D), device="cuda").half())
+        else:
+            kv = torch.randn((nk, 2 * D), device="cuda").to(dt)
+            k, v = kv[:, :D], kv[:, D:]
         views = [(i * nq, nq, 0, nk, 0, 0) for i in range(nviews)]
     o = torch.empty((nviews * nq, D), device="cuda", dtype=torch.float16)
     tab = torch.tensor(views, dtype=torch.int32, device="cuda")
@@ -31,6 +39,7 @@ def make(name, heads, nviews, nq, nk, self_attn, nsplit=0):
                                             len(views), nq, nsplit, P(ws), nviews * nq if nsplit > 1 else 0, st))
     return name, go, 4.0 * nviews * nq * nk * D, (q, k, v, o, tab, ws)
 cases = [make("render CA 20v nk15360", 12, 20, 768, 15360, False), make("enc SA 20v n768", 16, 20, 768, 768, True),
+         make("update CA 4v nk7680 (S=4)", 12, 4, 768, 7680, False), make("update CA 4v nk7680 s3 (S=4)", 12, 4, 768, 7680, False, 3),
          make("update CA 1v nk7680 s7", 12, 1, 768, 7680, False, 7), make("update CA 1v nk14592 s8", 12, 1, 768, 14592, False, 8),
          make("update SA 1v n768", 12, 1, 768, 768, True), make("render CA 20v nk1960 (224)", 12, 10, 196, 1960, False),
          make("update CA 1v nk7680 s10", 12, 1, 768, 7680, False, 10), make("update CA 1v nk7680 s14", 12, 1, 768, 7680, False, 14),
@@ -50,7 +59,7 @@ for rnd in range(5):
         for _ in range(iters): go()
         e1.record(); torch.cuda.synchronize()
         res[name].append(e0.elapsed_time(e1) / iters)
-print(f"M3R_ATTN={os.environ.get('M3R_ATTN','0')} QW={os.environ.get('M3R_ATTN_QW','32')} FP8={FP8}")
+print(f"M3R_ATTN={os.environ.get('M3R_ATTN','4')} QF={os.environ.get('M3R_ATTN_QF','1')} FP8={FP8}")
 for name, go, fl, _ in cases:
     r = sorted(res[name]); med, mn = r[len(r)//2], r[0]
     print(f"  {name:28s} median {med*1e3:9.1f} us {fl/med/1e9:8.1f} TF/s   min {mn*1e3:9.1f} us {fl/mn/1e9:8.1f} TF/s", flush=True)

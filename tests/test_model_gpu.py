@@ -66,14 +66,15 @@ def test_scene_matches_reference_fixture(name, precision):
     assert errs["mem_first"] < tol + u and errs["mem_last"] < tol + u, errs
 
 
-FP8_TOL = 5.0e-2   # stated tolerance of the fp8-attention mode (pointmaps, rel-inf vs the reference); measured ~1e-2
+FP8_TOL = 1.0e-2   # stated tolerance of the fp8-attention mode (pointmaps, rel-inf vs the reference); emulated 2e-3 (scripts/emul/fp8_attention.py)
 
 
 @pytest.mark.parametrize("name", ["tiny_48x64_v4", "small_224_v3", "must3r224_v2", "must3r224_v10"])
 def test_fp8_attention_scene_vs_reference_fixture(name):
-    """BASELINE.json configs[4] "fp8 MFMA attention path": Q/K/V and the softmax numerators as e4m3 in every attention of the
-    encoder and the decoder (e4m3 K|V memory), everything else as in fp16w2.  Its error is reported next to fp16w2's: it does NOT
-    meet the 1e-3 target (3 mantissa bits on P), the assertion is the mode's own stated tolerance."""
+    """BASELINE.json configs[4] "fp8 MFMA attention path": Q and K as e4m3 through the MX-scaled 32x32x64 MFMA in every chip-filling
+    attention of the encoder and the decoder (memory rows [K e4m3 | V fp16]), P / V and everything else as in fp16w2.  Its error is
+    reported next to fp16w2's: it does NOT meet the 1e-3 target (3 mantissa bits on Q and K), the assertion is the mode's own stated
+    tolerance (1e-2)."""
     g = load_golden(name)
     cfg = dict(CASES, **BIG_CASES)[name]
     H, W, V, ps, tks = (int(v) for v in g["meta"][:5])
@@ -85,7 +86,7 @@ def test_fp8_attention_scene_vs_reference_fixture(name):
         out = hip_scene(cfg, "fp16w2", H, W, V, mb)
     finally:
         enc.attention_fp8 = dec.attention_fp8 = False
-    assert out["mem"][0][0].dtype == torch.float8_e4m3fn and base["mem"][0][0].dtype == torch.float16
+    assert out["mem"][0][0].dtype == torch.uint8 and out["mem"][0][0].shape[2] == 3 * cfg.dec_dim and base["mem"][0][0].dtype == torch.float16
     errs = {}
     for tag, o in (("fp8", out), ("fp16w2", base)):
         errs[tag] = dict(x=rel_inf(o["x"].cpu()[:, ::tks, ::tks], g["x"]), update=rel_inf(o["update"].cpu()[:, ::ps, ::ps], g["update"]),
@@ -95,7 +96,8 @@ def test_fp8_attention_scene_vs_reference_fixture(name):
     assert torch.isfinite(out["render"]).all() and torch.isfinite(out["update"]).all()
     assert np.array_equal(out["mem"][1].cpu().numpy(), g["labels"])
     assert errs["fp8"]["update"] < FP8_TOL and errs["fp8"]["render"] < FP8_TOL and errs["fp8"]["x"] < FP8_TOL, errs
-    assert errs["fp8"]["render"] > errs["fp16w2"]["render"]      # the flag really changes the arithmetic
+    if V * (H // 16) * (W // 16) >= 2 * 768:   # (scenes whose attention launches are all too small for the fp8 kernel stay 16-bit)
+        assert errs["fp8"]["render"] > errs["fp16w2"]["render"]      # the flag really changes the arithmetic
 
 
 BIG_CASES = {"must3r224_v10": MUST3R_224, "must3r512_v20": MUST3R_512}

@@ -332,20 +332,25 @@ def test_attention(lib, dt, case):
 
 @pytest.mark.parametrize("case", ["sa_196x2", "sa_768", "sa_tiny12", "ca_tail_skip", "ca_aligned_skip", "ca_skip_from_start", "ca_long"])
 def test_attention_fp8(lib, case):
-    """fp8 (e4m3) attention operands (BASELINE.json configs[4]): Q, K, V are e4m3 bytes, P is rounded to e4m3, everything
-    else fp32.  Reference: fp64 attention on the SAME (dequantised) operands, so what is measured is the P rounding (3
-    mantissa bits: 2^-4 relative per element, averaged over the keys of a row) plus accumulation order."""
+    """fp8 attention operands (BASELINE.json configs[4]): Q and K are e4m3 bytes and meet in v_mfma_scale_f32_32x32x64_f8f6f4;
+    V, the softmax numerators and O stay fp16.  Reference: fp64 attention on the SAME (dequantised) operands, so what is measured
+    is the kernel (layouts, masks, split-KV) and the fp16 rounding of P -- the operand quantisation itself is the model tests'."""
     heads, views, Rq, Rk, is_self = ATT_CASES[case]
     D = heads * 64
     g = torch.Generator(device="cuda").manual_seed(17)
     f8 = torch.float8_e4m3fn
     if is_self:
-        qkv = (torch.randn((Rq, 3 * D), device="cuda", generator=g) * 1.5).to(f8)
-        q, k, v = qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:]
-    else:
+        qk = (torch.randn((Rq, 2 * D), device="cuda", generator=g) * 1.5).to(f8)
+        q, k = qk[:, :D], qk[:, D:]
+        v = (torch.randn((Rq, 3 * D), device="cuda", generator=g) * 1.5).half()[:, 2 * D:]
+    else:   # memory rows [K e4m3 (D bytes) | V fp16 (2 D bytes)]
         q = (torch.randn((Rq, D), device="cuda", generator=g) * 1.5).to(f8)
-        kvm = (torch.randn((Rk, 2 * D), device="cuda", generator=g) * 1.5).to(f8)
-        k, v = kvm[:, :D], kvm[:, D:]
+        rows = torch.empty((Rk, 3 * D), dtype=torch.uint8, device="cuda")
+        k = rows[:, :D].view(f8)
+        v = rows[:, D:].view(torch.float16)
+        k.copy_((torch.randn((Rk, D), device="cuda", generator=g) * 1.5).to(f8))
+        v.copy_((torch.randn((Rk, D), device="cuda", generator=g) * 1.5).half())
+    assert k.stride(0) == (2 * D if is_self else 3 * D) and v.stride(0) == (3 * D if is_self else 3 * D // 2)
     ref = attn_ref(q.float().cpu(), k.float().cpu(), v.float().cpu(), views, heads)
     tab = torch.tensor(views, dtype=torch.int32, device="cuda")
     errs = {}
@@ -361,7 +366,7 @@ def test_attention_fp8(lib, case):
         assert torch.isfinite(o.float()).all()
         errs[ns] = rel_inf(o.cpu(), ref)
     record("attention_fp8", case=case, err=errs[0], split_err=errs[3])
-    assert max(errs.values()) < 3e-2, errs      # stated tolerance of the fp8 path at operator level (measured: see profiles/)
+    assert max(errs.values()) < 8 * 2.0 ** -11, errs      # exact e4m3 products, fp32 sums: what is left is the fp16 rounding of P and O
 
 
 @pytest.mark.parametrize("dt", ["bf16", "fp16"])
