@@ -1195,7 +1195,7 @@ extern "C" int must3r_hip_decode(must3r_hip_ctx* c, const must3r_hip_decode_args
                     A->render ? 0LL : Rs);
     if (S > 1 && A->mem_scene_stride < A->mem_capacity)
         return fail("decode: mem_scene_stride %lld < mem_capacity %d", (long long)A->mem_scene_stride, A->mem_capacity);
-    if ((S - 1) * (S > 1 ? (long long)A->mem_scene_stride : 0) + rows_needed > 0x7fffffffLL || (long long)S * Rs > 0x7fffffffLL / 4096)
+    if ((S - 1) * (S > 1 ? (long long)A->mem_scene_stride : 0) + rows_needed > 0x7fffffffLL || (long long)S * Rs > (1LL << 24))
         return fail("decode: call too large (row indices are 32-bit)");
     // cross-attention staging addresses K|V rows of one scene with 32-bit byte offsets (attention.hip, attn3_kernel)
     {
