@@ -23,14 +23,6 @@ constexpr int ATT_QB = 4 * ATT_QW;       // per block (default geometry, used by
 constexpr int ATT_KT = 64;               // keys per tile
 constexpr float ATT_THR = 6.0f;          // lazy-rescale threshold in log2 units (P <= 64)
 
-#ifdef ATTN_TRACE   // scripts/probes/attn_trace.hip: shader-cycle stamps of one wave of one block, per key tile
-__device__ unsigned long long g_attn_trace[4 * 64 * 8];
-#define ATT_STAMP(slot) do { if (blockIdx.x == ATTN_TRACE && lane == 0 && itc < 64) g_attn_trace[(wave * 64 + itc) * 8 + (slot)] = __builtin_readcyclecounter(); } while (0)
-#else
-#define ATT_STAMP(slot) do { } while (0)
-#endif
-
-
 // blockIdx -> (group = view x head, key split, query block).  The blocks that share K/V tiles are the query blocks of one
 // (group, split) PAIR; a pair stays on one XCD (blockIdx % 8: observed placement, speed only) so its tiles are L2 hits, and the
 // pairs are dealt round-robin over the XCDs.  (Round 1 dealt whole groups: the 12 heads of a one-view launch -- every cross /
@@ -55,648 +47,8 @@ __device__ __forceinline__ bool attn_block_coords(int nqb_signed, int ngrp, int 
     return true;
 }
 
-template <class T, int QW>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) attn_kernel(const AttnArgs p, const int nqb, const int ngrp, const int nsplit) {
-    typedef typename Vec<T>::v8 v8;
-    typedef typename Vec<T>::v4 v4;
-    constexpr int QF = QW / 16;
-    constexpr int QB = 4 * QW;               // query rows per block
-    // ONE __shared__ object: with two, hipcc drains the in-flight LDS-DMA (vmcnt(0)) before every first ds_read of a
-    // tile, which serialises prefetch and compute (cdna_hip_programming.md, ".s-level traps" (a)).
-    __shared__ __attribute__((aligned(16))) T smem_kv[2][2][ATT_KT * 64];   // [buffer][K|V][64 keys x 64]
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int fr = lane & 15, fg = lane >> 4;
-
-    int grp, split, qb;
-    if (!attn_block_coords(nqb, ngrp, nsplit, grp, split, qb)) return;
-    const int view = grp / p.heads, head = grp - view * p.heads;
-    const AttnView vw = p.view0_inline ? p.view0 : p.views[view];
-    if (qb * QB >= vw.nq) return;
-
-    const T* __restrict__ Q = reinterpret_cast<const T*>(p.Q);
-    const T* __restrict__ K = reinterpret_cast<const T*>(p.K) + (size_t)vw.kv_row0 * p.ldk + head * 64;
-    const T* __restrict__ V = reinterpret_cast<const T*>(p.V) + (size_t)vw.kv_row0 * p.ldv + head * 64;
-
-    // ---- Q fragments (B operand): lane (j = fr, g = fg) holds Q[q = 16 qf + j][d = 32 ks + 8 g ..+7]
-    const int qr0 = qb * QB + wave * QW;
-    v8 qf_[QF][2];
-#pragma unroll
-    for (int f = 0; f < QF; ++f) {
-        int r = qr0 + f * 16 + fr;
-        r = r < vw.nq ? r : vw.nq - 1;
-        const T* src = Q + (size_t)(vw.q_row0 + r) * p.ldq + head * 64 + fg * 8;
-        qf_[f][0] = *reinterpret_cast<const v8*>(src);
-        qf_[f][1] = *reinterpret_cast<const v8*>(src + 32);
-    }
-
-    const int nk = vw.nk, slo = vw.skip_lo, shi = vw.skip_hi;
-    const int ntiles = (nk + ATT_KT - 1) / ATT_KT;
-    auto fully_skipped = [&](int t) {
-        const int k0 = t * ATT_KT;
-        const int k1 = (k0 + ATT_KT < nk) ? k0 + ATT_KT : nk;
-        return k0 >= slo && k1 <= shi;
-    };
-    // this block's share of the key tiles
-    const int tps = (ntiles + nsplit - 1) / nsplit;
-    const int t_begin = split * tps;
-    const int t_end = (t_begin + tps < ntiles) ? t_begin + tps : ntiles;
-    auto advance = [&](int t) {
-        ++t;
-        while (t < t_end && fully_skipped(t)) ++t;
-        return t;
-    };
-
-    // ---- staging: per tile 8 wave-instructions for K and 8 for V (8 rows x 128 B each); 2 + 2 per wave
-    const int srow = lane >> 3, pch = lane & 7;
-    auto stage = [&](int t, int buf) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int piece = wave * 2 + i;
-            const int r = piece * 8 + srow;
-            int key = t * ATT_KT + r;
-            key = key < nk ? key : nk - 1;
-            glds16(K + (size_t)key * p.ldk + swz(r, pch) * 8, &smem_kv[buf][0][piece * 8 * 64]);
-            glds16(V + (size_t)key * p.ldv + swz_v(r, pch) * 8, &smem_kv[buf][1][piece * 8 * 64]);
-        }
-    };
-
-    // Online softmax state, all per query = per lane column (base-2 domain):
-    //   m_  reference exponent (-inf until a valid key has been seen); P = 2^(S - m_)
-    //   o_  un-normalised O^T accumulators; ol_ accumulates the row sums through one extra MFMA whose A operand is a row
-    //       of ones (sum_k P[q][k] lands in every row of ol_) -- 4 MFMAs per tile instead of 32 VALU adds + shuffles.
-    // The softmax is VALU/exp-bound at head dim 64, so the steady state is kept to {max, exp2, cvt}: the S accumulators
-    // are INITIALISED with -m_ (the MFMA then delivers S - m_ for free) and m_ only moves when the tile maximum exceeds
-    // it by more than ATT_THR (lazy rescale: P <= 2^ATT_THR, harmless in fp32 accumulators and in fp16/bf16 P).
-    f32x4 o_[4][QF], ol_[QF];
-    float m_[QF];
-#pragma unroll
-    for (int f = 0; f < QF; ++f) {
-        m_[f] = -INFINITY;
-        ol_[f] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int d = 0; d < 4; ++d) o_[d][f] = f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-    // when the q projection already folded scale*log2(e) into Q the scores need no multiply
-    const float c = p.q_prescaled ? 1.0f : p.scale * 1.44269504088896340736f;
-    const float inv_c = 1.0f / c;
-    v8 ones;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) ones[e] = (T)1.0f;
-
-    int t = t_begin - 1;
-    t = advance(t);
-    if (t < t_end) stage(t, 0);
-    int buf = 0;
-#ifdef ATTN_TRACE
-    int itc = 0;
-#endif
-    while (t < t_end) {
-        ATT_STAMP(0);
-        __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0)
-        ATT_STAMP(1);
-        __syncthreads();
-        ATT_STAMP(2);
-        const int tn = advance(t);
-        if (tn < t_end) stage(tn, buf ^ 1);
-        ATT_STAMP(3);
-
-        const T* k_ = smem_kv[buf][0];
-        const T* v_ = smem_kv[buf][1];
-        // ---- S^T = K Q^T
-        f32x4 s_[4][QF];
-        float mref[QF];
-#pragma unroll
-        for (int f = 0; f < QF; ++f) {
-            mref[f] = (m_[f] == -INFINITY) ? 0.f : m_[f];
-            const float ini = -mref[f] * inv_c;
-#pragma unroll
-            for (int kf = 0; kf < 4; ++kf) s_[kf][f] = f32x4{ini, ini, ini, ini};
-        }
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-#pragma unroll
-            for (int kf = 0; kf < 4; ++kf) {
-                const int r = kf * 16 + fr;
-                const v8 kfrag = *reinterpret_cast<const v8*>(k_ + r * 64 + swz(r, ks * 4 + fg) * 8);
-#pragma unroll
-                for (int f = 0; f < QF; ++f) s_[kf][f] = mfma16(kfrag, qf_[f][ks], s_[kf][f]);
-            }
-        }
-        if (!p.q_prescaled) {   // generic entry (operator tests): bring (S/c - m/c) to the base-2 domain
-#pragma unroll
-            for (int kf = 0; kf < 4; ++kf)
-#pragma unroll
-                for (int f = 0; f < QF; ++f) s_[kf][f] *= c;
-        }
-#ifdef ATTN_TRACE
-#pragma unroll
-        for (int kf = 0; kf < 4; ++kf)
-#pragma unroll
-            for (int f = 0; f < QF; ++f) asm volatile("" ::"v"(s_[kf][f]));
-#endif
-        ATT_STAMP(4);
-        // ---- exclusion / tail mask: s_[kf][f][r] is key k0 + 16 kf + 4 fg + r
-        const int k0 = t * ATT_KT;
-        const bool need_mask = (k0 + ATT_KT > nk) || (k0 < shi && k0 + ATT_KT > slo);
-        if (need_mask) {  // wave-uniform branch; inside, a branch-free per-lane select
-#pragma unroll
-            for (int kf = 0; kf < 4; ++kf)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int key = k0 + kf * 16 + fg * 4 + r;
-                    const bool bad = (key >= nk) | ((key >= slo) & (key < shi));
-                    const float pen = bad ? -INFINITY : 0.f;
-#pragma unroll
-                    for (int f = 0; f < QF; ++f) s_[kf][f][r] += pen;   // finite + (-inf) = -inf
-                }
-        }
-        // ---- online softmax: s_ holds S - m_ (base 2); keys of a query live in lanes fr + 16*g
-#pragma unroll
-        for (int f = 0; f < QF; ++f) {
-            float mx = -INFINITY;
-#pragma unroll
-            for (int kf = 0; kf < 4; ++kf)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s_[kf][f][r]);
-            mx = quad_row_max(mx);
-            const bool first = (m_[f] == -INFINITY);
-            const bool grow = first ? (mx != -INFINITY) : (mx > ATT_THR);
-            if (__any(grow)) {   // wave-uniform slow path: move the reference
-                // first valid tile of this row: shift to its maximum (either sign); later: only upwards
-                float d = first ? mx : fmaxf(mx, 0.f);
-                if (d == -INFINITY) d = 0.f;                      // row still has no valid key
-#pragma unroll
-                for (int kf = 0; kf < 4; ++kf)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) s_[kf][f][r] = __builtin_amdgcn_exp2f(s_[kf][f][r] - d);
-                if (!first) {                                      // O and the row sums are still zero on the first tile
-                    const float alpha = __builtin_amdgcn_exp2f(-d);
-#pragma unroll
-                    for (int dd = 0; dd < 4; ++dd) o_[dd][f] *= alpha;
-                    ol_[f] *= alpha;
-                    m_[f] = mref[f] + d;
-                } else if (mx != -INFINITY) {
-                    m_[f] = d;                                     // mref was 0
-                }
-            } else {
-#pragma unroll
-                for (int kf = 0; kf < 4; ++kf)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) s_[kf][f][r] = __builtin_amdgcn_exp2f(s_[kf][f][r]);
-            }
-        }
-#ifdef ATTN_TRACE
-#pragma unroll
-        for (int kf = 0; kf < 4; ++kf)
-#pragma unroll
-            for (int f = 0; f < QF; ++f) asm volatile("" ::"v"(s_[kf][f]));
-#endif
-        ATT_STAMP(5);
-        // ---- O^T += V^T P^T ; k-slot e of lane group g <-> keys {4g+e (e<4), 16+4g+e-4 (e>=4)} of the 32-key slot
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            v8 pb[QF];
-#pragma unroll
-            for (int f = 0; f < QF; ++f) {
-                f32x8 pv;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    pv[r] = s_[2 * ks][f][r];
-                    pv[4 + r] = s_[2 * ks + 1][f][r];
-                }
-                pb[f] = cvt8<T>(pv);
-                ol_[f] = mfma16(ones, pb[f], ol_[f]);   // row sums of the (rounded) P actually multiplied into O
-            }
-            // transposing reads: chunk m = fr of the 16-lane group = row (m>>2), d-columns 4*(m&3)..+3
-            v4 tr[8];
-            {
-                const int r0 = ks * 32 + fg * 4 + (fr >> 2), r1 = r0 + 16;
-                const int c0 = (fr & 3) * 4;                       // d = 16*dd + c0
-                const T* a[8];
-#pragma unroll
-                for (int d = 0; d < 4; ++d) {
-                    const int dc = d * 16 + c0;
-                    a[2 * d] = v_ + r0 * 64 + swz_v(r0, dc >> 3) * 8 + (dc & 7);
-                    a[2 * d + 1] = v_ + r1 * 64 + swz_v(r1, dc >> 3) * 8 + (dc & 7);
-                }
-                lds_read_tr4_x8<T>(a[0], a[1], a[2], a[3], a[4], a[5], a[6], a[7], tr);
-            }
-#pragma unroll
-            for (int d = 0; d < 4; ++d) {
-                const v8 vfrag = __builtin_shufflevector(tr[2 * d], tr[2 * d + 1], 0, 1, 2, 3, 4, 5, 6, 7);
-#pragma unroll
-                for (int f = 0; f < QF; ++f) o_[d][f] = mfma16(vfrag, pb[f], o_[d][f]);
-            }
-        }
-#ifdef ATTN_TRACE
-#pragma unroll
-        for (int d = 0; d < 4; ++d)
-#pragma unroll
-            for (int f = 0; f < QF; ++f) asm volatile("" ::"v"(o_[d][f]));
-        ATT_STAMP(6);
-        ++itc;
-#endif
-        t = tn;
-        buf ^= 1;
-    }
-
-    // ---- normalise and store: lane (q = fr, g) holds O[q][d = 16 dd + 4 g + r]
-    T* __restrict__ O = reinterpret_cast<T*>(p.O);
-#pragma unroll
-    for (int f = 0; f < QF; ++f) {
-        const float l = ol_[f][0];   // every row of the ones-product holds the full row sum
-        const int q = qr0 + f * 16 + fr;
-        if (q >= vw.nq) continue;
-        const size_t row = (size_t)(vw.q_row0 + q);
-        if (nsplit <= 1) {
-            const float inv = l > 0.f ? 1.0f / l : 0.f;
-            T* dst = O + row * p.ldo + head * 64 + fg * 4;
-#pragma unroll
-            for (int d = 0; d < 4; ++d) *reinterpret_cast<v4*>(dst + d * 16) = cvt4<T>(o_[d][f] * inv);
-        } else {
-            const size_t D = (size_t)p.heads * 64;
-            float* po = p.part_o + ((size_t)split * p.total_q_rows + row) * D + head * 64 + fg * 4;
-#pragma unroll
-            for (int d = 0; d < 4; ++d) *reinterpret_cast<f32x4*>(po + d * 16) = o_[d][f];
-            if (fg == 0) {
-                float* pm = p.part_ml + (((size_t)split * p.total_q_rows + row) * p.heads + head) * 2;
-                pm[0] = m_[f];
-                pm[1] = l;
-            }
-        }
-    }
-}
-
 // ------------------------------------------------------------------------------------------------------------------
-// attn2_kernel: the same transposed flash formulation, software-pipelined across key tiles, for 16-bit or fp8 (e4m3) operands.
-//
-// attn_kernel above serialises, per wave and tile, [QK^T MFMAs] -> [softmax VALU, with a data-dependent branch per 16 queries]
-// -> [PV MFMAs]: the matrix pipe idles through the softmax (r01 PMC: MFMA pipe 32 % busy, 36 % of the wave time stalled on the
-// MFMA -> softmax -> MFMA chain).  Here iteration i issues, in this order,
-//     S(next) = K(next) Q^T                       16 MFMAs, independent of everything in flight
-//     O      += V(cur)^T P(cur)  (+ row sums)     20 MFMAs
-//     softmax(S(next)) -> P(next), m, alpha       VALU, in the SAME basic block as the PV MFMAs (no branch inside), so the
-//                                                 compiler interleaves it with them: the matrix pipe stays fed by one wave
-// The online-softmax reference m only moves when a row maximum exceeds it by more than ATT_THR (lazy rescale, P <= 2^6); the
-// decision is per query = per lane (selects, no branch); O *= alpha is applied at the top of the NEXT iteration under one
-// wave-uniform branch that is almost never taken.  K and V are staged separately (K one tile ahead of V), still two buffers
-// each and one barrier per tile.
-//
-// F8: Q, K, V are OCP e4m3 bytes (probe: scripts/probes/fp8_probe.hip -> profiles/r02_fp8_probe.txt).  v_mfma_f32_16x16x32_fp8_fp8
-// takes 8 bytes per lane with the k-slot layout of the 16-bit shape (lane group g, byte e <-> k = 8g + e), so the C layout of
-// S^T is again the B layout of the second product with k-slot (g, e) <-> key {4g + e, 16 + 4g + e - 4} of a 32-key slot; V^T
-// comes from ds_read_b64_tr_b8 (16 lanes pass the 8-byte chunks of an 8 x 16 byte matrix and receive its columns): the 16 lanes
-// of group g pass the chunks of exactly those 8 key rows.  P is rounded to e4m3 (P <= 64 < 448: no clamp needed); the softmax,
-// the accumulators and the output stay fp32 / 16-bit.  Half the LDS and HBM bytes per key of the 16-bit kernel.
-template <class T, bool F8> struct AttnOperand;
-template <class T> struct AttnOperand<T, false> {
-    typedef T elem;
-    typedef typename Vec<T>::v8 frag;
-    static __device__ __forceinline__ f32x4 mma(frag a, frag b, f32x4 c) { return mfma16(a, b, c); }
-};
-template <class T> struct AttnOperand<T, true> {
-    typedef unsigned char elem;
-    typedef long frag;
-    static __device__ __forceinline__ f32x4 mma(long a, long b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(a, b, c, 0, 0, 0); }
-};
-
-// [rows][64 bytes] fp8 tiles: four rows share a 256-byte bank row.  XOR on the 16-byte PAIR index (the DMA granule):
-//   K  ds_read_b64 of 16 consecutive rows x 2 adjacent 8-byte chunks per 32-lane half: rows r, r+4, r+8, r+12 must differ
-//   V  ds_read_b64_tr_b8: a 32-lane half reads rows {4g..4g+3, 16+4g..} for g, g+1: rows r, r+4, r+16, r+20 must differ
-__device__ __forceinline__ int swz8_k(int row) { return (row >> 2) & 3; }
-__device__ __forceinline__ int swz8_v(int row) { return ((row >> 2) & 1) | (((row >> 4) & 1) << 1); }
-
-__device__ __forceinline__ void lds_read_tr8_x4(unsigned a0, unsigned a1, unsigned a2, unsigned a3, long (&out)[4]) {
-    u32x2 r0, r1, r2, r3;
-    asm volatile(
-        "ds_read_b64_tr_b8 %0, %4\n\t"
-        "ds_read_b64_tr_b8 %1, %5\n\t"
-        "ds_read_b64_tr_b8 %2, %6\n\t"
-        "ds_read_b64_tr_b8 %3, %7\n\t"
-        "s_waitcnt lgkmcnt(0)"
-        : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3)
-        : "v"(a0), "v"(a1), "v"(a2), "v"(a3)
-        : "memory");
-    const u32x2 r[4] = {r0, r1, r2, r3};
-#pragma unroll
-    for (int i = 0; i < 4; ++i) __builtin_memcpy(&out[i], &r[i], 8);
-}
-
-template <class T, int QW, bool F8>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) attn2_kernel(const AttnArgs p, const int nqb, const int ngrp, const int nsplit) {
-    typedef AttnOperand<T, F8> OP;
-    typedef typename OP::elem E;
-    typedef typename OP::frag frag;
-    typedef typename Vec<T>::v4 v4;
-    constexpr int QF = QW / 16;
-    constexpr int QB = 4 * QW;
-    constexpr int TILE = ATT_KT * 64;            // elements of one K (or V) tile
-    __shared__ __attribute__((aligned(16))) E smem_kv[2][2][TILE];   // [K|V][buffer][64 keys x 64]
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int fr = lane & 15, fg = lane >> 4;
-
-    int grp, split, qb;
-    if (!attn_block_coords(nqb, ngrp, nsplit, grp, split, qb)) return;
-    const int view = grp / p.heads, head = grp - view * p.heads;
-    const AttnView vw = p.view0_inline ? p.view0 : p.views[view];
-    if (qb * QB >= vw.nq) return;
-
-    const E* __restrict__ Q = reinterpret_cast<const E*>(p.Q);
-    const E* __restrict__ K = reinterpret_cast<const E*>(p.K) + (size_t)vw.kv_row0 * p.ldk + head * 64;
-    const E* __restrict__ V = reinterpret_cast<const E*>(p.V) + (size_t)vw.kv_row0 * p.ldv + head * 64;
-
-    const int qr0 = qb * QB + wave * QW;
-    frag qf_[QF][2];
-#pragma unroll
-    for (int f = 0; f < QF; ++f) {
-        int r = qr0 + f * 16 + fr;
-        r = r < vw.nq ? r : vw.nq - 1;
-        const E* src = Q + (size_t)(vw.q_row0 + r) * p.ldq + head * 64 + fg * 8;
-        qf_[f][0] = *reinterpret_cast<const frag*>(src);
-        qf_[f][1] = *reinterpret_cast<const frag*>(src + 32);
-    }
-
-    const int nk = vw.nk, slo = vw.skip_lo, shi = vw.skip_hi;
-    const int ntiles = (nk + ATT_KT - 1) / ATT_KT;
-    auto fully_skipped = [&](int t) {
-        const int k0 = t * ATT_KT;
-        const int k1 = (k0 + ATT_KT < nk) ? k0 + ATT_KT : nk;
-        return k0 >= slo && k1 <= shi;
-    };
-    const int tps = (ntiles + nsplit - 1) / nsplit;
-    const int t_begin = split * tps;
-    const int t_end = (t_begin + tps < ntiles) ? t_begin + tps : ntiles;
-    auto advance = [&](int t) {
-        ++t;
-        while (t < t_end && fully_skipped(t)) ++t;
-        return t;
-    };
-
-    // ---- staging.  16-bit: a wave instruction moves 8 rows x 128 B, 8 pieces per tile, 2 per wave; fp8: 16 rows x 64 B, 4 pieces
-    // per tile, 1 per wave.  Lane-linear LDS image, swizzle on the source address (and again on the read side).
-    auto stage = [&](const E* __restrict__ base, int ld, int which, int t, int buf) {
-        if constexpr (!F8) {
-            const int srow = lane >> 3, pch = lane & 7;
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int piece = wave * 2 + i;
-                const int r = piece * 8 + srow;
-                int key = t * ATT_KT + r;
-                key = key < nk ? key : nk - 1;
-                const int ch = which == 0 ? swz(r, pch) : swz_v(r, pch);
-                glds16(base + (size_t)key * ld + ch * 8, &smem_kv[which][buf][piece * 8 * 64]);
-            }
-        } else {
-            const int srow = lane >> 2, pp = lane & 3;
-            const int r = wave * 16 + srow;
-            int key = t * ATT_KT + r;
-            key = key < nk ? key : nk - 1;
-            const int pr = pp ^ (which == 0 ? swz8_k(r) : swz8_v(r));
-            glds16(base + (size_t)key * ld + pr * 16, &smem_kv[which][buf][wave * 16 * 64]);
-        }
-    };
-
-    f32x4 o_[4][QF], ol_[QF];
-    float m_[QF], alpha_[QF];
-#pragma unroll
-    for (int f = 0; f < QF; ++f) {
-        m_[f] = -INFINITY;
-        alpha_[f] = 1.0f;
-        ol_[f] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int d = 0; d < 4; ++d) o_[d][f] = f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-    const float c = p.q_prescaled ? 1.0f : p.scale * 1.44269504088896340736f;
-    const float inv_c = 1.0f / c;
-    frag ones;
-    if constexpr (F8) ones = 0x3838383838383838L;   // e4m3 1.0
-    else {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) ones[e] = (T)1.0f;
-    }
-
-    // ---- S^T(t) = K(t) Q^T - m  (base-2 domain), masked
-    auto qk = [&](int t, int buf, f32x4 (&s_)[4][QF]) {
-        const E* k_ = smem_kv[0][buf];
-#pragma unroll
-        for (int f = 0; f < QF; ++f) {
-            const float mref = (m_[f] == -INFINITY) ? 0.f : m_[f];
-            const float ini = -mref * inv_c;
-#pragma unroll
-            for (int kf = 0; kf < 4; ++kf) s_[kf][f] = f32x4{ini, ini, ini, ini};
-        }
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-#pragma unroll
-            for (int kf = 0; kf < 4; ++kf) {
-                const int r = kf * 16 + fr;
-                frag kfrag;
-                if constexpr (!F8) kfrag = *reinterpret_cast<const frag*>(k_ + r * 64 + swz(r, ks * 4 + fg) * 8);
-                else kfrag = *reinterpret_cast<const frag*>(k_ + r * 64 + ((ks * 2 + (fg >> 1)) ^ swz8_k(r)) * 16 + (fg & 1) * 8);
-#pragma unroll
-                for (int f = 0; f < QF; ++f) s_[kf][f] = OP::mma(kfrag, qf_[f][ks], s_[kf][f]);
-            }
-        }
-        if (!p.q_prescaled) {
-#pragma unroll
-            for (int kf = 0; kf < 4; ++kf)
-#pragma unroll
-                for (int f = 0; f < QF; ++f) s_[kf][f] *= c;
-        }
-        const int k0 = t * ATT_KT;
-        const bool need_mask = (k0 + ATT_KT > nk) || (k0 < shi && k0 + ATT_KT > slo);
-        if (need_mask) {
-#pragma unroll
-            for (int kf = 0; kf < 4; ++kf)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int key = k0 + kf * 16 + fg * 4 + r;
-                    const bool bad = (key >= nk) | ((key >= slo) & (key < shi));
-                    const float pen = bad ? -INFINITY : 0.f;
-#pragma unroll
-                    for (int f = 0; f < QF; ++f) s_[kf][f][r] += pen;
-                }
-        }
-    };
-    // ---- online softmax of one tile, per query = per lane column, no branch: P = 2^(S - d), reference m moves by d
-    auto softmax = [&](f32x4 (&s_)[4][QF], frag (&pb)[QF][2], bool& any_grow) {
-        any_grow = false;
-#pragma unroll
-        for (int f = 0; f < QF; ++f) {
-            float mx = -INFINITY;
-#pragma unroll
-            for (int kf = 0; kf < 4; ++kf)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s_[kf][f][r]);
-            mx = quad_row_max(mx);
-            // fp8: P is stored with 3 mantissa bits and flushes below 2^-10, so its window is moved up: the reference follows the
-            // running maximum more closely (threshold 2 instead of 6) and P carries a constant factor 2^6 (P <= 2^8 < 448); the
-            // factor is in O and in the row sums alike and cancels in O / l (also across split-KV partials).
-            constexpr float THR = F8 ? 2.0f : ATT_THR;
-            constexpr float PSH = F8 ? 6.0f : 0.0f;
-            const bool first = (m_[f] == -INFINITY);
-            const bool grow = first ? (mx != -INFINITY) : (mx > THR);
-            const float d = grow ? mx : 0.f;
-            const float dp = d - PSH;
-            alpha_[f] = (grow && !first) ? __builtin_amdgcn_exp2f(-d) : 1.0f;
-            m_[f] = grow ? (first ? d : m_[f] + d) : m_[f];
-            any_grow |= (grow && !first);
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                float e_[8];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    e_[r] = __builtin_amdgcn_exp2f(s_[2 * ks][f][r] - dp);
-                    e_[4 + r] = __builtin_amdgcn_exp2f(s_[2 * ks + 1][f][r] - dp);
-                }
-                if constexpr (!F8) {
-                    f32x8 pv;
-#pragma unroll
-                    for (int r = 0; r < 8; ++r) pv[r] = e_[r];
-                    pb[f][ks] = cvt8<T>(pv);
-                } else {
-                    int lo = 0, hi = 0;
-                    lo = __builtin_amdgcn_cvt_pk_fp8_f32(e_[0], e_[1], lo, false);
-                    lo = __builtin_amdgcn_cvt_pk_fp8_f32(e_[2], e_[3], lo, true);
-                    hi = __builtin_amdgcn_cvt_pk_fp8_f32(e_[4], e_[5], hi, false);
-                    hi = __builtin_amdgcn_cvt_pk_fp8_f32(e_[6], e_[7], hi, true);
-                    pb[f][ks] = (long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
-                }
-            }
-        }
-        any_grow = __any(any_grow);
-    };
-    // ---- O^T += V(t)^T P^T and the row sums (ones row); k-slot (g, e) <-> keys {4g+e, 16+4g+e-4} of each 32-key slot
-    auto pv_mma = [&](int buf, frag (&pb)[QF][2]) {
-        const E* v_ = smem_kv[1][buf];
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-#pragma unroll
-            for (int f = 0; f < QF; ++f) ol_[f] = OP::mma(ones, pb[f][ks], ol_[f]);
-            frag vfrag[4];
-            if constexpr (!F8) {
-                // two d-fragments at a time: 8 live registers of V^T instead of 16 (163 instead of 171 VGPRs: 3 waves per SIMD)
-                const int r0 = ks * 32 + fg * 4 + (fr >> 2), r1 = r0 + 16;
-                const int c0 = (fr & 3) * 4;
-#pragma unroll
-                for (int dh = 0; dh < 2; ++dh) {
-                    v4 tr[4];
-                    const T* a[4];
-#pragma unroll
-                    for (int d = 0; d < 2; ++d) {
-                        const int dc = (dh * 2 + d) * 16 + c0;
-                        a[2 * d] = v_ + r0 * 64 + swz_v(r0, dc >> 3) * 8 + (dc & 7);
-                        a[2 * d + 1] = v_ + r1 * 64 + swz_v(r1, dc >> 3) * 8 + (dc & 7);
-                    }
-                    lds_read_tr4_x4<T>(a[0], a[1], a[2], a[3], tr);
-#pragma unroll
-                    for (int d = 0; d < 2; ++d) {
-                        const frag vf = __builtin_shufflevector(tr[2 * d], tr[2 * d + 1], 0, 1, 2, 3, 4, 5, 6, 7);
-#pragma unroll
-                        for (int f = 0; f < QF; ++f) o_[dh * 2 + d][f] = OP::mma(vf, pb[f][ks], o_[dh * 2 + d][f]);
-                    }
-                }
-                continue;
-            } else {
-                const int e = fr >> 1;
-                const int row = ks * 32 + (e < 4 ? 4 * fg + e : 16 + 4 * fg + (e - 4));
-                const unsigned base = (unsigned)(size_t)(__attribute__((address_space(3))) const E*)(v_) + row * 64 + (fr & 1) * 8;
-                const int sw = swz8_v(row);
-                long t4[4];
-                lds_read_tr8_x4(base + ((0 ^ sw) << 4), base + ((1 ^ sw) << 4), base + ((2 ^ sw) << 4), base + ((3 ^ sw) << 4), t4);
-#pragma unroll
-                for (int d = 0; d < 4; ++d) vfrag[d] = t4[d];
-            }
-#pragma unroll
-            for (int d = 0; d < 4; ++d)
-#pragma unroll
-                for (int f = 0; f < QF; ++f) o_[d][f] = OP::mma(vfrag[d], pb[f][ks], o_[d][f]);
-        }
-    };
-    auto rescale = [&]() {
-#pragma unroll
-        for (int f = 0; f < QF; ++f) {
-#pragma unroll
-            for (int d = 0; d < 4; ++d) o_[d][f] *= alpha_[f];
-            ol_[f] *= alpha_[f];
-        }
-    };
-
-    // ---- pipeline.  LDS: K(t) lives in K buffer (i & 1) of ITS iteration i, V alike; iteration i multiplies P(cur) V(cur) and
-    // computes S(next): it needs V(cur) and K(next), both issued during iteration i-1 (or the prologue), and refills the buffers
-    // whose tiles were last read in iteration i-1 (K(cur), V(prev)) after the barrier.
-    int cur = advance(t_begin - 1);
-    if (cur < t_end) {
-        int nxt = advance(cur);
-        stage(K, p.ldk, 0, cur, 0);
-        stage(V, p.ldv, 1, cur, 0);
-        if (nxt < t_end) stage(K, p.ldk, 0, nxt, 1);
-        __builtin_amdgcn_s_waitcnt(0x0f70);   // (K(cur) alone would do for the first product; one wait keeps the prologue simple)
-        __syncthreads();
-        frag pcur[QF][2];
-        bool grew = false;
-        {
-            f32x4 s0[4][QF];
-            qk(cur, 0, s0);
-            softmax(s0, pcur, grew);    // first tile: alpha = 1 by construction
-        }
-        int it = 0;
-        while (nxt < t_end) {
-            __builtin_amdgcn_s_waitcnt(0x0f70);   // V(cur), K(nxt) of this wave have landed
-            __syncthreads();                      // ... everyone's have; K(cur) / V(prev) are no longer being read
-            const int nxt2 = advance(nxt);
-            if (nxt2 < t_end) stage(K, p.ldk, 0, nxt2, it & 1);
-            stage(V, p.ldv, 1, nxt, (it + 1) & 1);
-            f32x4 s_[4][QF];
-            qk(nxt, (it + 1) & 1, s_);
-            if (grew) rescale();                  // wave-uniform, rare: O *= alpha before P(cur) is added
-            pv_mma(it & 1, pcur);
-            softmax(s_, pcur, grew);              // same basic block as the PV MFMAs above: interleaved by the scheduler
-            cur = nxt;
-            nxt = nxt2;
-            ++it;
-        }
-        __builtin_amdgcn_s_waitcnt(0x0f70);
-        __syncthreads();
-        if (grew) rescale();
-        pv_mma(it & 1, pcur);
-    }
-
-    // ---- normalise and store: lane (q = fr, g) holds O[q][d = 16 dd + 4 g + r]
-    T* __restrict__ O = reinterpret_cast<T*>(p.O);
-#pragma unroll
-    for (int f = 0; f < QF; ++f) {
-        const float l = ol_[f][0];
-        const int q = qr0 + f * 16 + fr;
-        if (q >= vw.nq) continue;
-        const size_t row = (size_t)(vw.q_row0 + q);
-        if (nsplit <= 1) {
-            const float inv = l > 0.f ? 1.0f / l : 0.f;
-            T* dst = O + row * p.ldo + head * 64 + fg * 4;
-#pragma unroll
-            for (int d = 0; d < 4; ++d) *reinterpret_cast<v4*>(dst + d * 16) = cvt4<T>(o_[d][f] * inv);
-        } else {
-            const size_t D = (size_t)p.heads * 64;
-            float* po = p.part_o + ((size_t)split * p.total_q_rows + row) * D + head * 64 + fg * 4;
-#pragma unroll
-            for (int d = 0; d < 4; ++d) *reinterpret_cast<f32x4*>(po + d * 16) = o_[d][f];
-            if (fg == 0) {
-                float* pm = p.part_ml + (((size_t)split * p.total_q_rows + row) * p.heads + head) * 2;
-                pm[0] = m_[f];
-                pm[1] = l;
-            }
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------------------------
-// attn3_kernel: attn_kernel with the per-tile instruction count cut down.  The r02 cycle trace (scripts/probes/attn_trace.hip)
+// attn3_kernel: the round-1 kernel (16 x 16 tiles, removed in r03) with the per-tile instruction count cut down.  The r02 cycle trace (scripts/probes/attn_trace.hip)
 // and the QW / pipelining experiments say that a SIMD spends ~1500 cycles per (wave, key tile) however many waves share it and
 // however the work is arranged: 576 of them are the 36 MFMAs, the rest is the ~265 other instructions the loop body issues
 // (177 VALU, 28 LDS / DMA, ~60 scalar) -- the kernel is bound by what it ISSUES, and most of that was bookkeeping:
@@ -710,8 +62,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) a
 //     from the PER-LANE maxima (`any lane above the threshold`, one compare per 16 queries), the permlane exchanges, the
 //     first-tile selects and the rescale live in one wave-uniform slow block that updates S, O, the row sums and m IN PLACE
 //     (no second register version of the accumulators, no copies at a join).
-// Same arithmetic as attn_kernel on the fast path (S - m from the accumulator init, exp2, P rounded to T, row sums from the
-// ones MFMA); the slow path subtracts the shift before the exp2 like attn_kernel does.
+// Arithmetic: S - m from the accumulator init, exp2, P rounded to T, row sums from the ones MFMA; the slow path subtracts the
+// shift before the exp2.
 template <int O0, int O1>
 __device__ __forceinline__ void lds_tr_x8_imm(unsigned a0, unsigned a1, unsigned a2, unsigned a3, u32x2 (&r)[8]) {
     asm volatile(
@@ -1554,10 +906,9 @@ int launch_tr_probe(short* out, hipStream_t s) {
 int launch_attention_phase(DType dt, const AttnArgs& a_in, int phase, hipStream_t s, const char** err) {
     AttnArgs a = a_in;
     if (a.nviews <= 0 || a.max_nq <= 0) return 0;
-    {   // split-KV partials of the fp16 attn3 path are written normalised, in fp16 (the bf16 / fp8 / older kernels keep fp32)
-        static const int variant0 = getenv("M3R_ATTN") ? atoi(getenv("M3R_ATTN")) : 4;
+    {   // split-KV partials of the fp16 paths are written normalised, in fp16 (bf16 keeps fp32)
         static const bool p16 = !(getenv("M3R_ATTN_PART16") && atoi(getenv("M3R_ATTN_PART16")) == 0);
-        a.part16 = (p16 && (variant0 == 2 || variant0 == 4) && dt == DT_F16 && a.nsplit > 1) ? 1 : 0;
+        a.part16 = (p16 && dt == DT_F16 && a.nsplit > 1) ? 1 : 0;
     }
     if ((a.ldq % (a.fp8 ? 16 : 8)) || (a.ldk % (a.fp8 ? 16 : 8)) || (a.ldv % (a.fp8 ? 16 : 8)) || (a.ldo % 4)) { *err = "attention: row strides must be 16-byte aligned"; return 1; }
     const int nsplit = a.nsplit > 1 ? a.nsplit : 1;
@@ -1585,10 +936,13 @@ int launch_attention_phase(DType dt, const AttnArgs& a_in, int phase, hipStream_
 #else
     constexpr int qw_big = 32;
 #endif
-    // M3R_ATTN_QF=2 (experiments): 64 query rows per wave in the 32 x 32 kernel (one wave per SIMD, 512 registers)
-    static const bool qf2_env = getenv("M3R_ATTN_QF") && atoi(getenv("M3R_ATTN_QF")) == 2;
-    static const int variant1 = getenv("M3R_ATTN") ? atoi(getenv("M3R_ATTN")) : 4;
-    const bool qf2 = qf2_env && variant1 == 4 && !small && !a.fp8;
+#ifdef M3R_ATTN_EXPERIMENTS
+    // M3R_ATTN=4 M3R_ATTN_QF=2: 64 query rows per wave in the 32 x 32 kernel (one wave per SIMD, 512 registers)
+    static const bool qf2_env = getenv("M3R_ATTN_QF") && atoi(getenv("M3R_ATTN_QF")) == 2 && getenv("M3R_ATTN") && atoi(getenv("M3R_ATTN")) == 4;
+    const bool qf2 = qf2_env && !small && !a.fp8;
+#else
+    constexpr bool qf2 = false;
+#endif
     const int qb_rows = small ? 64 : (qf2 ? 256 : 4 * qw_big);
     const int nqb_abs = (a.max_nq + qb_rows - 1) / qb_rows;
     const int npairs = ngrp * nsplit;
@@ -1604,23 +958,23 @@ int launch_attention_phase(DType dt, const AttnArgs& a_in, int phase, hipStream_
                                a.part_ml, n2);
         }
     } else if (phase == 1) {
-        // 16-bit operands: attn3_kernel (M3R_ATTN=2, default): render cross attention 892 TF/s against 739 for attn_kernel (M3R_ATTN=0)
-        // and 689-720 for the pipelined attn2_kernel (M3R_ATTN=1), which stays the fp8 kernel (profiles/r02_attn_ab.txt).
-        static int variant = -1;
-        if (variant < 0) {
-            const char* e = getenv("M3R_ATTN");
-            variant = e ? atoi(e) : 4;
-        }
+        // 16-bit operands: attn3_kernel (16 x 16 tiles).  The 32 x 32-tile attn4_kernel measures EQUAL on every shape of the scene (r03:
+        // render cross attention 840 vs 852 TF/s, encoder self attention 699 vs 710; 64 query rows per wave at one wave per SIMD: 497 --
+        // profiles/r03_attn_ab.txt), so the 16 x 16 kernel -- whose 16-row form also serves the launches too small to fill the chip, with
+        // the same per-query arithmetic, i.e. bit-identical batched and per-view calls -- stays the 16-bit path, and attn4 is the
+        // fp8 (MX-scaled Q K^T) path: 983-1003 TF/s on the render shape.  M3R_ATTN=4 (experiment builds) runs its 16-bit instantiation.
 #define M3R_LAUNCH_ATTN(KERNEL) hipLaunchKernelGGL(KERNEL, dim3(grid), dim3(256), 0, s, a, nqb, ngrp, nsplit)
         if (a.fp8) {   // e4m3 Q / K through the MX-scaled 32x32x64 MFMA, 16-bit P / V
             if (dt == DT_BF16) M3R_LAUNCH_ATTN((attn4_kernel<bf16_t, 1, true>)); else M3R_LAUNCH_ATTN((attn4_kernel<f16_t, 1, true>));
-        } else if (variant == 4 && !small) {
-            if (qf2) { if (dt == DT_BF16) M3R_LAUNCH_ATTN((attn4_kernel<bf16_t, 2, false>)); else M3R_LAUNCH_ATTN((attn4_kernel<f16_t, 2, false>)); }
-            else if (dt == DT_BF16) M3R_LAUNCH_ATTN((attn4_kernel<bf16_t, 1, false>)); else M3R_LAUNCH_ATTN((attn4_kernel<f16_t, 1, false>));
-        } else if (variant == 2 || variant == 4) {
+        } else {
 #ifdef M3R_ATTN_EXPERIMENTS
+            static const int variant = getenv("M3R_ATTN") ? atoi(getenv("M3R_ATTN")) : 2;
             static const int abl = getenv("M3R_ATTN_ABL") ? atoi(getenv("M3R_ATTN_ABL")) : 0;   // timing ablations (wrong results)
-            if (!small && dt == DT_F16 && abl == 1) M3R_LAUNCH_ATTN((attn3_kernel<f16_t, 32, 1>));
+            if (variant == 4 && !small) {
+                if (qf2) { if (dt == DT_BF16) M3R_LAUNCH_ATTN((attn4_kernel<bf16_t, 2, false>)); else M3R_LAUNCH_ATTN((attn4_kernel<f16_t, 2, false>)); }
+                else if (dt == DT_BF16) M3R_LAUNCH_ATTN((attn4_kernel<bf16_t, 1, false>)); else M3R_LAUNCH_ATTN((attn4_kernel<f16_t, 1, false>));
+            }
+            else if (!small && dt == DT_F16 && abl == 1) M3R_LAUNCH_ATTN((attn3_kernel<f16_t, 32, 1>));
             else if (!small && dt == DT_F16 && abl == 2) M3R_LAUNCH_ATTN((attn3_kernel<f16_t, 32, 2>));
             else if (!small && dt == DT_F16 && abl == 3) M3R_LAUNCH_ATTN((attn3_kernel<f16_t, 32, 3>));
             else if (!small && dt == DT_F16 && abl == 4) M3R_LAUNCH_ATTN((attn3_kernel<f16_t, 32, 4>));
@@ -1630,17 +984,6 @@ int launch_attention_phase(DType dt, const AttnArgs& a_in, int phase, hipStream_
 #endif
             if (small) { if (dt == DT_BF16) M3R_LAUNCH_ATTN((attn3_kernel<bf16_t, 16>)); else M3R_LAUNCH_ATTN((attn3_kernel<f16_t, 16>)); }
             else { if (dt == DT_BF16) M3R_LAUNCH_ATTN((attn3_kernel<bf16_t, 32>)); else M3R_LAUNCH_ATTN((attn3_kernel<f16_t, 32>)); }
-        } else if (variant == 0) {
-#ifdef M3R_ATTN_EXPERIMENTS
-            if (!small && qw_big == 48 && dt == DT_F16) M3R_LAUNCH_ATTN((attn_kernel<f16_t, 48>));
-            else if (!small && qw_big == 64 && dt == DT_F16) M3R_LAUNCH_ATTN((attn_kernel<f16_t, 64>));
-            else
-#endif
-            if (small) { if (dt == DT_BF16) M3R_LAUNCH_ATTN((attn_kernel<bf16_t, 16>)); else M3R_LAUNCH_ATTN((attn_kernel<f16_t, 16>)); }
-            else { if (dt == DT_BF16) M3R_LAUNCH_ATTN((attn_kernel<bf16_t, 32>)); else M3R_LAUNCH_ATTN((attn_kernel<f16_t, 32>)); }
-        } else {
-            if (small) { if (dt == DT_BF16) M3R_LAUNCH_ATTN((attn2_kernel<bf16_t, 16, false>)); else M3R_LAUNCH_ATTN((attn2_kernel<f16_t, 16, false>)); }
-            else { if (dt == DT_BF16) M3R_LAUNCH_ATTN((attn2_kernel<bf16_t, 32, false>)); else M3R_LAUNCH_ATTN((attn2_kernel<f16_t, 32, false>)); }
         }
 #undef M3R_LAUNCH_ATTN
     } else if (nsplit > 1) {

@@ -1295,7 +1295,8 @@ int launch_gemm(DType dt, Epi epi, const GemmArgs& a, hipStream_t s, const char*
         *err = "gemm: LN-fold outputs need the RESID_F32 / F32 epilogue";
         return 1;
     }
-    if (a.stats_out && a.N % 16 != 0) { *err = "gemm: stats_out needs N % 16 == 0"; return 1; }
+    // the consumer of the statistics reads LNF_SLOTS fragments per row (its K = 768): a producer of another width would pair with misaligned rows
+    if (a.stats_out && a.N != 16 * LNF_SLOTS) { *err = "gemm: stats_out (LN-fold producer) needs N = 768"; return 1; }
     if (a.ksplit > 1) {   // split-K: fp32 partial slabs, no bias, 96 x 96 tiles with split weights only
         if (epi != EPI_F32 || a.bias != nullptr || a.bias2 != nullptr || a.accumulate || a.wsplit != 2 || dt != DT_F16 || a.N % 96 ||
             (a.K / 64) % a.ksplit || a.slab_stride < (long long)a.M * a.ldc) {

@@ -234,7 +234,7 @@ static int attention(must3r_hip_ctx* c, DType dt, const AttnArgs& a, double flop
         if (launch_attention_phase(dt, a, 0, s, &err)) return fail("%s", err);
     }
     {
-        ProfScope ps(c, s, cat, flops);   // attn_kernel alone: what rocprofv3 reports under that symbol
+        ProfScope ps(c, s, cat, flops);   // the attention kernel alone: what rocprofv3 reports under its symbol
         if (launch_attention_phase(dt, a, 1, s, &err)) return fail("%s", err);
     }
     if (a.nsplit > 1) {

@@ -188,8 +188,8 @@ __global__ void __launch_bounds__(256) l2_normalize_rows_kernel(float* __restric
 
 // F.normalize(x, dim) of a contiguous tensor seen as [outer, L, inner] (Whitener(l2norm=dim), retrieval/model.py:77-78): one thread per
 // (outer, inner) column, fp32 sum of squares in index order, x / max(|x|_2, 1e-12).  inner == 1 takes the wave-per-row kernel above.
-__global__ void __launch_bounds__(256) l2_normalize_strided_kernel(const float* __restrict__ x, long long outer, int L, long long inner,
-                                                                   float* __restrict__ out) {
+__global__ void __launch_bounds__(256) l2_normalize_strided_kernel(const float* x, long long outer, int L, long long inner,
+                                                                   float* out) {   // out may alias x (no __restrict__)
     const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
     if (t >= outer * inner) return;
     const long long o = t / inner, i = t - o * inner;
@@ -203,7 +203,7 @@ __global__ void __launch_bounds__(256) l2_normalize_strided_kernel(const float* 
     const float inv = 1.0f / fmaxf(sqrtf(s), 1e-12f);
     for (int l = 0; l < L; ++l) dst[(long long)l * inner] = src[(long long)l * inner] * inv;
 }
-__global__ void __launch_bounds__(256) l2_normalize_rows_copy_kernel(const float* __restrict__ x, long long M, int C, float* __restrict__ out) {
+__global__ void __launch_bounds__(256) l2_normalize_rows_copy_kernel(const float* x, long long M, int C, float* out) {   // out may alias x (no __restrict__)
     const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (row >= M) return;

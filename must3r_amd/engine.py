@@ -263,7 +263,19 @@ def _label_runs(mem_labels):
     runs = getattr(mem_labels, "_m3r_runs", None)
     if runs is None or mem_labels.dim() != 2 or mem_labels.shape[0] != 1 or sum(c for _, c in runs) != mem_labels.shape[1]:
         return None
+    # an in-place edit of the labels outside these helpers (the reference's own _restore_label_in_mem does that, user code may) leaves
+    # the attribute on the tensor but makes it stale: the mirror is only trusted while the tensor's version counter is the one it was
+    # attached at
+    if getattr(mem_labels, "_m3r_runs_version", None) != mem_labels._version:
+        return None
     return runs
+
+
+def attach_label_runs(mem_labels, runs):
+    """Attach the host mirror of the label layout to ``mem_labels`` (valid until the tensor is next modified in place)."""
+    mem_labels._m3r_runs = runs
+    mem_labels._m3r_runs_version = mem_labels._version
+    return mem_labels
 
 
 def _ranges_of(runs, idx):
@@ -312,7 +324,7 @@ def remove_from_mem(mem_values, mem_labels, idx):
         else:
             vals = [torch.cat([v[:, :first], v[:, tail_idx]], dim=1) for v in mem_values]
         labels = torch.cat([mem_labels[:, :first], mem_labels[:, tail_idx]], dim=1)
-        labels._m3r_runs = new_runs
+        attach_label_runs(labels, new_runs)
         return vals, labels
     keep = mem_labels != idx
     if not in_place:
@@ -327,10 +339,10 @@ def remove_from_mem(mem_values, mem_labels, idx):
 
 def restore_label_in_mem(mem_labels, old_idx_to_restore, new_idx_to_remove):
     """``_restore_label_in_mem`` (engine/inference.py:216-219), in place."""
-    runs = getattr(mem_labels, "_m3r_runs", None)
+    runs = _label_runs(mem_labels)
     mem_labels[mem_labels == new_idx_to_remove] = old_idx_to_restore
     if runs is not None:
-        mem_labels._m3r_runs = [(old_idx_to_restore if lab == new_idx_to_remove else lab, cnt) for lab, cnt in runs]
+        attach_label_runs(mem_labels, [(old_idx_to_restore if lab == new_idx_to_remove else lab, cnt) for lab, cnt in runs])
     return mem_labels
 
 

@@ -286,7 +286,7 @@ class MUSt3R(HipModule):
         _lib.check(ctx.lib.must3r_hip_decode(ctx.handle, C.byref(args), self._stream(dev)))
 
         if render:
-            out = (mem_vals, mem_labels, mem_nimgs, mem_prot_imgs, mem_prot_tok)  # decoder.py:252 / :339
+            out = current_mem  # decoder.py:252 / :339: the memory comes back untouched
         else:
             owner.valid = Nm + R
             new_vals = owner.views(Nm + R)
@@ -294,7 +294,8 @@ class MUSt3R(HipModule):
             k = 0
             # host mirror of the label layout (engine._label_runs): lets the L3 memory surgery build its indices without
             # reading the labels back from the device
-            runs = [] if Nm == 0 else getattr(mem_labels, "_m3r_runs", None)
+            from ..engine import _label_runs, attach_label_runs
+            runs = [] if Nm == 0 else _label_runs(mem_labels)    # None: no mirror, or the labels were edited in place since it was attached
             runs = list(runs) if runs is not None and sum(c for _, c in runs) == Nm else None
             for n, N in zip(nimgs, Ns):  # decoder.py:241-249 / :332-334
                 labels.append((torch.arange(n, dtype=torch.int64, device=device) + (mem_nimgs + k)).repeat_interleave(N).view(1, -1)
@@ -304,7 +305,7 @@ class MUSt3R(HipModule):
                 k += n
             mem_labels = torch.cat([mem_labels.to(device)] + labels, dim=1)
             if runs is not None and B == 1:
-                mem_labels._m3r_runs = runs
+                attach_label_runs(mem_labels, runs)
             tot = mem_nimgs + sum(nimgs)
             out = (new_vals, mem_labels, tot, tot, mem_labels.shape[1])
         feats = None

@@ -1,4 +1,4 @@
-"""Microbenchmark of the attention kernels on the scene's shapes.  M3R_ATTN=4 (default) = the 32x32-tile attn4_kernel, 2 = attn3_kernel;
+"""Microbenchmark of the attention kernels on the scene's shapes.  default = attn3_kernel; M3R_ATTN=4 on an experiment build (make EXTRA=-DM3R_ATTN_EXPERIMENTS) = the 16-bit 32x32-tile attn4_kernel;
 FP8=1 times the e4m3 Q/K variant (MX-scaled 32x32x64 MFMA for Q K^T).  Prints median / min over interleaved rounds."""
 import os, sys, torch, ctypes as C
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -59,7 +59,7 @@ for rnd in range(5):
         for _ in range(iters): go()
         e1.record(); torch.cuda.synchronize()
         res[name].append(e0.elapsed_time(e1) / iters)
-print(f"M3R_ATTN={os.environ.get('M3R_ATTN','4')} QF={os.environ.get('M3R_ATTN_QF','1')} FP8={FP8}")
+print(f"M3R_ATTN={os.environ.get('M3R_ATTN','2')} QF={os.environ.get('M3R_ATTN_QF','1')} FP8={FP8}")
 for name, go, fl, _ in cases:
     r = sorted(res[name]); med, mn = r[len(r)//2], r[0]
     print(f"  {name:28s} median {med*1e3:9.1f} us {fl/med/1e9:8.1f} TF/s   min {mn*1e3:9.1f} us {fl/mn/1e9:8.1f} TF/s", flush=True)

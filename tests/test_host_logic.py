@@ -237,3 +237,22 @@ def test_backend_switch_dispatch_without_the_reference(monkeypatch):
     assert mod.load_model is ref_load_model and early.load_model is ref_load_model and not hasattr(mod, "toggle_hip_backend")
     assert calls == [("ref", "a.pth", None, None, "cpu", 224, None, True), ("hip", "b.pth", None, None, "cuda:1", 512, "kv", False),
                      ("ref", "c.pth", None, None, "cuda", None, None, True)]
+
+
+def test_label_run_mirror_is_dropped_when_the_labels_are_edited_in_place():
+    """engine._label_runs: the host mirror of the label layout is only trusted while the tensor's version counter is the one it
+    was attached at -- an in-place edit outside the helpers (the reference's own _restore_label_in_mem, user code) makes it stale,
+    and a stale mirror would evict / overwrite the wrong rows."""
+    from must3r_amd import engine as E
+    labels = torch.tensor([[0, 0, 1, 1, 2, 2]])
+    E.attach_label_runs(labels, [(0, 2), (1, 2), (2, 2)])
+    assert E._label_runs(labels) == [(0, 2), (1, 2), (2, 2)]
+    vals = [torch.arange(6.0).view(1, 6, 1)]
+    v2, l2 = E.remove_from_mem(vals, labels, 1)
+    assert l2.tolist() == [[0, 0, 2, 2]] and E._label_runs(l2) == [(0, 2), (2, 2)] and v2[0].flatten().tolist() == [0, 1, 4, 5]
+    labels[labels == 2] = 7                       # in place, behind the helpers' back
+    assert E._label_runs(labels) is None          # stale mirror rejected: the helpers take the mask path
+    v3, l3 = E.remove_from_mem(vals, labels, 7)
+    assert l3.tolist() == [[0, 0, 1, 1]] and v3[0].flatten().tolist() == [0, 1, 2, 3]
+    l4 = E.restore_label_in_mem(l2, 5, 2)         # the helper keeps its own mirror fresh
+    assert l4.tolist() == [[0, 0, 5, 5]] and E._label_runs(l4) == [(0, 2), (5, 2)]

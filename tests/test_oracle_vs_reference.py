@@ -459,7 +459,8 @@ class _InPlaceMemoryDecoder:
         owner.valid = Nm + R
         labels = new_mem[1]
         if self.host_labels:
-            runs = [] if current_mem is None else getattr(current_mem[1], "_m3r_runs", None)
+            from must3r_amd.engine import _label_runs, attach_label_runs
+            runs = [] if current_mem is None else _label_runs(current_mem[1])
             if runs is not None and sum(c for _, c in runs) == Nm:
                 runs = list(runs)
                 first = 0 if current_mem is None else int(current_mem[2])
@@ -467,7 +468,7 @@ class _InPlaceMemoryDecoder:
                     runs += [(first + j, int(xg.shape[2])) for j in range(int(xg.shape[1]))]
                     first += int(xg.shape[1])
                 assert sum(c for _, c in runs) == Nm + R
-                labels._m3r_runs = runs
+                attach_label_runs(labels, runs)
                 self.mirrored = getattr(self, "mirrored", 0) + 1
         return (owner.views(Nm + R), labels, *new_mem[2:]), pm
 
@@ -499,7 +500,8 @@ def test_drivers_on_in_place_memory_equal_reference(video, host_labels):
     assert native_like.appends > 0 and native_like.copies == 0, (native_like.appends, native_like.copies)
     assert getattr(got[0][0][0], "_m3r_owner", None) is not None
     if host_labels:   # the mirror survived every surgery step and still describes the final labels
-        runs = getattr(got[0][1], "_m3r_runs", None)
+        from must3r_amd.engine import _label_runs
+        runs = _label_runs(got[0][1])
         assert runs is not None and native_like.mirrored == native_like.appends + 1
         assert torch.equal(torch.cat([torch.full((c,), l) for l, c in runs]).view(1, -1), got[0][1])
     if not video:
