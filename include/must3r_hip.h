@@ -35,7 +35,10 @@ typedef struct must3r_hip_ctx must3r_hip_ctx;
 /* MUST3R_F16_W2: fp16 operands with every weight matrix split as W_hi + W_lo (two MFMA passes per GEMM, fp32
  * accumulation): removes the weight-rounding term that dominates the fp16 error (precision). Only valid
  * for must3r_hip_encode / must3r_hip_decode; buffers are fp16. */
-enum { MUST3R_BF16 = 0, MUST3R_F16 = 1, MUST3R_F16_W2 = 2 };
+/* MUST3R_F16_WA: as MUST3R_F16_W2 for the attention-side Linears (qkv, proj, projq, projk, projv, cross proj), the patch / enc->dec
+ * embeddings and the head, but the Mlp weights (fc1, fc2, feedback Mlp) are plain fp16: 2/3 of the GEMM FLOPs run ONE MFMA pass.
+ * Measured / emulated error: between the two; inside the 1e-3 target. */
+enum { MUST3R_BF16 = 0, MUST3R_F16 = 1, MUST3R_F16_W2 = 2, MUST3R_F16_WA = 3 };
 /* OR-able flag on `dtype` (BASELINE.json configs[4], "fp8 MFMA attention path"; replaces the attention back ends of
  * must3r/model/blocks/attention.py:57-79): Q and K enter the score product as OCP e4m3 bytes through the MX-scaled
  * v_mfma_scale_f32_32x32x64_f8f6f4 (twice the 16-bit MFMA rate); the softmax, its numerators P, V, the accumulators and the outputs

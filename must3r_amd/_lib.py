@@ -10,7 +10,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmust3r_hip.so")
 
-BF16, F16, F16_W2 = 0, 1, 2
+BF16, F16, F16_W2, F16_WA = 0, 1, 2, 3
 ATTN_FP8 = 0x100   # OR-able: fp8 (e4m3) attention operands, include/must3r_hip.h
 MEM_KV, MEM_NORM_Y, MEM_RAW = 0, 1, 2
 PART_ENCODER, PART_DECODER = 1, 2

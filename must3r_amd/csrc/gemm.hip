@@ -716,14 +716,13 @@ static int launch_256(const GemmArgs& a, hipStream_t s) {
 // With 144 tiles of 64 x 64 the other 112 CUs idle; 48 x 48 tiles put all 256 CUs to work with 2 DMA + 6 LDS reads + 4
 // MFMAs per wave and K-tile.  Measured (split weights, M = N = 768): proj 8.0 -> 6.9 us, fc2 20.6 -> 18.9 us, same bits.
 // (The K-loop slope stays ~0.33 us per tile even here, so per-wave issue is not the whole story either; the gain is in
-// the fixed part.)  Split weights only: with plain weights the 12 pieces do not divide evenly over 9 waves.
+// the fixed part.)  Plain weights (r03): 12 pieces over 9 waves -- waves 0-2 issue two per tile, the others one, each counting its own.
 template <class T, int EPI, int WS, int NST>
 __global__ void __launch_bounds__(576) gemm48_kernel(const GemmArgs p) {
     typedef typename Vec<T>::v8 v8;
     constexpr int BM = 48, BN = 48, BK = 64, NW = 9, RPP = 8;
     constexpr int ROWS = BM + WS * BN;                 // staging region: A rows, then W rows (hi, then lo)
-    static_assert((ROWS / RPP) % NW == 0, "every wave must issue the same number of DMA pieces per tile (counted vmcnt)");
-    constexpr int NPIECE = ROWS / RPP;                 // 18 (split) or 12 (plain)
+    constexpr int NPIECE = ROWS / RPP;                 // 18 (split: 2 per wave) or 12 (plain: waves 0-2 issue 2, the others 1)
     constexpr int STAGE = ROWS * BK;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     T* const lds = reinterpret_cast<T*>(smem);
@@ -752,6 +751,8 @@ __global__ void __launch_bounds__(576) gemm48_kernel(const GemmArgs p) {
 
     // pieces dealt round-robin: piece = t * NW + wave (split weights: 18 pieces, 2 per wave)
     constexpr int TMAX = (NPIECE + NW - 1) / NW;
+    constexpr int NFULL = NPIECE - NW * (TMAX - 1);   // waves that issue TMAX pieces per tile; the others TMAX - 1 (their counted vmcnt differs)
+    const bool full_wave = wave < NFULL;
     const int srow = lane >> 3, pch = lane & 7;
     const T* src[TMAX];
     bool has[TMAX];
@@ -802,8 +803,10 @@ __global__ void __launch_bounds__(576) gemm48_kernel(const GemmArgs p) {
     int buf = 0;
     for (int kt = 0; kt < nk; ++kt) {
         // tile kt landed: at most NST-2 younger tiles x TMAX loads may still be in flight (tail: drain)
-        if (kt + NST - 2 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * TMAX) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (kt + NST - 2 < nk) {
+            if (NFULL == NW || full_wave) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * TMAX) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * (TMAX - 1)) : "memory");
+        } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         const int nt = kt + NST - 1;
         if (nt < nk) {
@@ -1254,7 +1257,13 @@ static int launch_epi(const GemmArgs& a, hipStream_t s, const char** err) {
         const long tiles128 = (long)((a.M + 127) / 128) * (a.N / 128) * nb;
         const long t256 = rb256 * (a.N / 256);
         const bool ok256 = a.N % 256 == 0 && a.K % 32 == 0;
-        if (ok256 && (mode == 2 || (mode == 1 && t256 >= 200 && fill256(t256) >= 80))) rc = launch_256<T, EPI, 1, 256>(a, s);
+        if (a.ln_stats != nullptr) {
+            // LN-fold consumers on plain weights (the Mlp fc1 of a one-view update in MUST3R_F16_WA mode): the 64 x 64 ring kernel
+            if constexpr (EPI == EPI_STORE16_GELU || EPI == EPI_STORE16 || EPI == EPI_QKV_ROPE) rc = launch_cfg<T, 64, 64, 2, 2, EPI, 4, 1>(a, s);
+            else rc = 1;
+        } else if (EPI != EPI_QKV_ROPE && EPI != EPI_HEAD && sizeof(T) == 2 && use_48(a, nb)) {
+            rc = launch_48<T, EPI == EPI_QKV_ROPE || EPI == EPI_HEAD ? EPI_STORE16 : EPI, 1>(a, s);   // N = 768 one-view launches: 256 tiles of 48 x 48
+        } else if (ok256 && (mode == 2 || (mode == 1 && t256 >= 200 && fill256(t256) >= 80))) rc = launch_256<T, EPI, 1, 256>(a, s);
         else if (n128 && tiles128 >= min_big(false)) rc = launch_cfg<T, 128, 128, 2, 2, EPI, 2, 1>(a, s);
         else if (small8((long)((a.M + 63) / 64) * (a.N / 64) * nb)) rc = launch_cfg<T, 64, 64, SMALL_WGM, 2, EPI, SMALL8_NST_PLAIN, 1, 64, 1>(a, s);
         else rc = launch_cfg<T, 64, 64, 2, 2, EPI, 4, 1>(a, s);
@@ -1286,8 +1295,8 @@ int launch_gemm(DType dt, Epi epi, const GemmArgs& a, hipStream_t s, const char*
     if (epi == EPI_HEAD && (a.N % 112 != 0 || a.ntok <= 0 || a.gw <= 0)) { *err = "gemm: head epilogue geometry"; return 1; }
     if (a.ln_stats != nullptr) {
         const bool epi_ok = epi == EPI_STORE16 || epi == EPI_STORE16_GELU || epi == EPI_QKV_ROPE;
-        if (!epi_ok || a.ln_s == nullptr || a.wsplit != 2 || dt != DT_F16 || a.K != 16 * LNF_SLOTS || (a.batch > 1)) {
-            *err = "gemm: LN fold needs a 16-bit-store epilogue, ln_s, split fp16 weights, K = 768, no batch";
+        if (!epi_ok || a.ln_s == nullptr || (a.wsplit != 2 && a.wsplit != 0) || dt != DT_F16 || a.K != 16 * LNF_SLOTS || (a.batch > 1)) {
+            *err = "gemm: LN fold needs a 16-bit-store epilogue, ln_s, fp16 weights, K = 768, no batch";
             return 1;
         }
     }

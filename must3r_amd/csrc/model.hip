@@ -75,7 +75,8 @@ struct must3r_hip_ctx {
     bool fin_enc = false, fin_dec = false;
     // per-layer parameter tables (resolved once: no string building / map lookups per launch); entries of absent parameters are null
     std::vector<std::vector<struct Param*>> enc_tab, dec_tab;
-    int wsplit = 0;            // 2 while a forward runs in MUST3R_F16_W2 mode
+    int wsplit = 0;            // 2 while a forward runs in MUST3R_F16_W2 / MUST3R_F16_WA mode
+    int mlp_plain = 0;         // 1 in MUST3R_F16_WA mode: the Mlp Linears take plain fp16 weights (one MFMA pass)
     int attn8 = 0;             // 1 while a forward runs with MUST3R_ATTN_FP8 (e4m3 attention operands)
     float* rope_tab = nullptr;
     int rope_npos = 0;
@@ -184,14 +185,16 @@ static void prof_flush(must3r_hip_ctx* c) {
 // ------------------------------------------------------------------------------------------------
 // launch wrappers
 // ------------------------------------------------------------------------------------------------
-static int gemm(must3r_hip_ctx* c, DType dt, Epi epi, GemmArgs a, hipStream_t s) {
+// ws_override >= 0: the caller chose the weight layout of THIS launch (wmlp below); otherwise the context's mode decides
+static int gemm(must3r_hip_ctx* c, DType dt, Epi epi, GemmArgs a, hipStream_t s, int ws_override = -1) {
     const char* err = "";
     const long nbat = a.batch > 1 ? a.batch : 1;
-    const int ws = (c && epi != EPI_HEAD) ? c->wsplit : a.wsplit;
+    const int ws = ws_override >= 0 ? ws_override : ((c && epi != EPI_HEAD) ? c->wsplit : a.wsplit);
     const long tiles128 = (long)((a.M + 127) / 128) * (a.N / 128) * nbat;
     const int cat = ws == 2 ? (((long)((a.M + 127) / 128) * (a.N / 64) * nbat >= 384) ? PC_GEMM128 : PC_GEMM64)
                             : ((a.N % 128 == 0 && tiles128 >= 192) ? PC_GEMM128 : PC_GEMM64);
-    if (c && epi != EPI_HEAD) a.wsplit = c->wsplit;
+    if (ws_override >= 0) a.wsplit = ws_override;
+    else if (c && epi != EPI_HEAD) a.wsplit = c->wsplit;
     ProfScope ps(c, s, cat, 2.0 * a.M * a.N * a.K * (a.batch > 1 ? a.batch : 1));
     if (launch_gemm(dt, epi, a, s, &err)) return fail("%s (M=%d N=%d K=%d epi=%d)", err, a.M, a.N, a.K, (int)epi);
     return 0;
@@ -355,6 +358,13 @@ static int w16p(must3r_hip_ctx* c, Param& p, DType dt, const void** hi, hipStrea
     }
     *hi = p.x2[dt];
     return 0;
+}
+// weight operand of an Mlp Linear (fc1, fc2, the feedback Mlp): the plain 16-bit copy in MUST3R_F16_WA mode -- the launch then runs
+// one MFMA pass (*ws = 0) -- and the context's layout otherwise
+static int wmlp(must3r_hip_ctx* c, Param& p, DType dt, const void** w, int* ws, hipStream_t s) {
+    if (c->wsplit == 2 && c->mlp_plain) { *ws = 0; return p16p(c, p, dt, false, w, nullptr, s); }
+    *ws = c->wsplit;
+    return w16p(c, p, dt, w, s);
 }
 static void build_layer_tables(must3r_hip_ctx* c, bool decoder) {
     std::vector<std::vector<Param*>>& tab = decoder ? c->dec_tab : c->enc_tab;
@@ -681,10 +691,11 @@ static int encode_chunk(must3r_hip_ctx* c, DType dt, const float* img, int V, in
         M3R_OK(gemm(c, dt, EPI_RESID_F32, gargs(a16, w, LP[LF_PROJB]->d, x, R, C, C, C, C), s));
         M3R_OK(layernorm(c, dt, x, nullptr, LP[LF_N2W]->d, LP[LF_N2B]->d, h16, nullptr, nullptr,
                          nullptr, R, C, 1e-6f, s));
-        M3R_OK(w16p(c, *LP[LF_FC1W], dt, &w, s));
-        M3R_OK(gemm(c, dt, EPI_STORE16_GELU, gargs(h16, w, LP[LF_FC1B]->d, g16, R, F, C, C, F), s));
-        M3R_OK(w16p(c, *LP[LF_FC2W], dt, &w, s));
-        M3R_OK(gemm(c, dt, EPI_RESID_F32, gargs(g16, w, LP[LF_FC2B]->d, x, R, C, F, F, C), s));
+        int ws;
+        M3R_OK(wmlp(c, *LP[LF_FC1W], dt, &w, &ws, s));
+        M3R_OK(gemm(c, dt, EPI_STORE16_GELU, gargs(h16, w, LP[LF_FC1B]->d, g16, R, F, C, C, F), s, ws));
+        M3R_OK(wmlp(c, *LP[LF_FC2W], dt, &w, &ws, s));
+        M3R_OK(gemm(c, dt, EPI_RESID_F32, gargs(g16, w, LP[LF_FC2B]->d, x, R, C, F, F, C), s, ws));
     }
     M3R_OK(layernorm(c, dt, x, nullptr, p32(c, "encoder.norm_enc.weight"), p32(c, "encoder.norm_enc.bias"), nullptr, nullptr,
                      out_tokens, nullptr, R, C, 1e-6f, s));
@@ -697,9 +708,10 @@ extern "C" int must3r_hip_encode(must3r_hip_ctx* c, int dtype, const float* img,
     if (!c->fin_enc) return fail("encode: encoder weights not finalized");
     c->attn8 = (dtype & MUST3R_ATTN_FP8) ? 1 : 0;
     dtype &= ~MUST3R_ATTN_FP8;
-    if (dtype != MUST3R_BF16 && dtype != MUST3R_F16 && dtype != MUST3R_F16_W2) return fail("encode: bad dtype %d", dtype);
-    c->wsplit = dtype == MUST3R_F16_W2 ? 2 : 0;
-    if (dtype == MUST3R_F16_W2) dtype = MUST3R_F16;
+    if (dtype != MUST3R_BF16 && dtype != MUST3R_F16 && dtype != MUST3R_F16_W2 && dtype != MUST3R_F16_WA) return fail("encode: bad dtype %d", dtype);
+    c->wsplit = (dtype == MUST3R_F16_W2 || dtype == MUST3R_F16_WA) ? 2 : 0;
+    c->mlp_plain = dtype == MUST3R_F16_WA ? 1 : 0;
+    if (dtype == MUST3R_F16_W2 || dtype == MUST3R_F16_WA) dtype = MUST3R_F16;
     if (n_views <= 0) return 0;
     if (H <= 0 || W <= 0 || H % 16 || W % 16) return fail("encode: H=%d W=%d must be positive multiples of 16", H, W);
     if (H / 16 > c->rope_npos || W / 16 > c->rope_npos) return fail("encode: image too large for the RoPE table");
@@ -727,8 +739,9 @@ extern "C" int must3r_hip_encode(must3r_hip_ctx* c, int dtype, const float* img,
 static int decode_impl(must3r_hip_ctx* c, const must3r_hip_decode_args* A, void* stream) {
     const int adt = A->dtype & ~MUST3R_ATTN_FP8;
     c->attn8 = (A->dtype & MUST3R_ATTN_FP8) ? 1 : 0;
-    if (adt != MUST3R_BF16 && adt != MUST3R_F16 && adt != MUST3R_F16_W2) return fail("decode: bad dtype %d", A->dtype);
-    c->wsplit = adt == MUST3R_F16_W2 ? 2 : 0;
+    if (adt != MUST3R_BF16 && adt != MUST3R_F16 && adt != MUST3R_F16_W2 && adt != MUST3R_F16_WA) return fail("decode: bad dtype %d", A->dtype);
+    c->wsplit = (adt == MUST3R_F16_W2 || adt == MUST3R_F16_WA) ? 2 : 0;
+    c->mlp_plain = adt == MUST3R_F16_WA ? 1 : 0;
     if (A->mem_mode != MUST3R_MEM_KV && A->mem_mode != MUST3R_MEM_NORM_Y && A->mem_mode != MUST3R_MEM_RAW)
         return fail("decode: bad mem_mode %d", A->mem_mode);
     if (A->n_groups <= 0) return fail("decode: no input group");
@@ -737,7 +750,7 @@ static int decode_impl(must3r_hip_ctx* c, const must3r_hip_decode_args* A, void*
     DeviceGuard dev_guard(c->device);
     if (c->dec_tab.empty()) build_layer_tables(c, true);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    const DType dt = adt == MUST3R_F16_W2 ? DT_F16 : (DType)adt;
+    const DType dt = (adt == MUST3R_F16_W2 || adt == MUST3R_F16_WA) ? DT_F16 : (DType)adt;
     const bool a8 = c->attn8 != 0;
     const must3r_hip_config& g = c->cfg;
     const int C = g.enc_dim, D = g.dec_dim, Hh = g.dec_heads, F = g.mlp_ratio * D, L = g.dec_depth, Nm = A->n_mem;
@@ -796,7 +809,7 @@ static int decode_impl(must3r_hip_ctx* c, const must3r_hip_decode_args* A, void*
     // Measured in the scene (r02, same box, interleaved): the GEMM class loses 0.9 ms and the LayerNorm class gains 0.9 ms (the four
     // 2.4 MB slabs per launch) -- a wash, so the route is OFF by default (M3R_FC2_SPLITK=1 enables it; operator-level tests cover it).
     static const bool fc2_splitk_on = getenv("M3R_FC2_SPLITK") && atoi(getenv("M3R_FC2_SPLITK")) != 0;
-    const bool fc2_splitk = !lnf && fc2_splitk_on && c->wsplit == 2 && dt == DT_F16 && !need_pre_kv && !A->feats && D % 96 == 0 &&
+    const bool fc2_splitk = !lnf && fc2_splitk_on && c->wsplit == 2 && !c->mlp_plain && dt == DT_F16 && !need_pre_kv && !A->feats && D % 96 == 0 &&
                             (F / 64) % KS == 0 && (long)((R + 95) / 96) * (D / 96) * KS <= 256;
     need = ws_need(need, fc2_splitk ? (size_t)KS * R * D : 0, 4);   // slabs
     // split-KV cross attention when the launch cannot fill the chip (sequential memory update: one view per call)
@@ -1065,13 +1078,14 @@ static int decode_impl(must3r_hip_ctx* c, const must3r_hip_decode_args* A, void*
         if (!lnf)
             M3R_OK(layernorm(c, dt, x, nullptr, LP[LF_N3W]->d, LP[LF_N3B]->d, h16, nullptr, nullptr, nullptr,
                              R, D, 1e-6f, s));
-        M3R_OK(w16p(c, *LP[lnf ? LF_FC1LN_W : LF_FC1W], dt, &w, s));
+        int ws_mlp;
+        M3R_OK(wmlp(c, *LP[lnf ? LF_FC1LN_W : LF_FC1W], dt, &w, &ws_mlp, s));
         {
             GemmArgs g1 = gargs(h16, w, LP[LF_FC1B]->d, g16, R, F, D, D, F);
             if (lnf) fold_in(g1, LF_FC1LN_S);
-            M3R_OK(gemm(c, dt, EPI_STORE16_GELU, g1, s));
+            M3R_OK(gemm(c, dt, EPI_STORE16_GELU, g1, s, ws_mlp));
         }
-        M3R_OK(w16p(c, *LP[LF_FC2W], dt, &w, s));
+        M3R_OK(wmlp(c, *LP[LF_FC2W], dt, &w, &ws_mlp, s));
         if (fc2_splitk) {
             GemmArgs gs = gargs(g16, w, nullptr, slabs, R, D, F, F, D);
             gs.ksplit = KS; gs.slab_stride = (long long)R * D;
@@ -1080,7 +1094,7 @@ static int decode_impl(must3r_hip_ctx* c, const must3r_hip_decode_args* A, void*
         } else {
             GemmArgs g2 = gargs(g16, w, LP[LF_FC2B]->d, x, R, D, F, F, D);
             if (lnf && l + 1 < L) fold_out(g2, newmem + (size_t)(l + 1) * R * D);   // the next block's norm1 input
-            M3R_OK(gemm(c, dt, EPI_RESID_F32, g2, s));
+            M3R_OK(gemm(c, dt, EPI_RESID_F32, g2, s, ws_mlp));
         }
         if (A->feats && l < L - 1)   // return_feats: the residual stream after block l (decoder.py:321)
             HIP_OK(hipMemcpyAsync(A->feats + (size_t)l * R * D, x, (size_t)R * D * sizeof(float), hipMemcpyDeviceToDevice, s));
@@ -1122,10 +1136,11 @@ static int decode_impl(must3r_hip_ctx* c, const must3r_hip_decode_args* A, void*
             M3R_OK(layernorm(c, dt, newmem + (size_t)(L - 1) * R * D, nullptr, p32(c, "decoder.feedback_norm.weight"),
                              p32(c, "decoder.feedback_norm.bias"), h16, nullptr, nullptr, nullptr, R, D, 1e-5f, s));
         if (fb_mlp) {
-            M3R_OK(w16(c, "decoder.feedback_layer.fc1.weight", dt, &w, s));
-            M3R_OK(gemm(c, dt, EPI_STORE16_GELU, gargs(h16, w, p32(c, "decoder.feedback_layer.fc1.bias"), g16, R, 4 * D, D, D, 4 * D), s));
-            M3R_OK(w16(c, "decoder.feedback_layer.fc2.weight", dt, &w, s));
-            M3R_OK(gemm(c, dt, EPI_F32, gargs(g16, w, p32(c, "decoder.feedback_layer.fc2.bias"), off32, R, D, 4 * D, 4 * D, D), s));
+            int ws_fb;
+            M3R_OK(wmlp(c, c->params.at("decoder.feedback_layer.fc1.weight"), dt, &w, &ws_fb, s));
+            M3R_OK(gemm(c, dt, EPI_STORE16_GELU, gargs(h16, w, p32(c, "decoder.feedback_layer.fc1.bias"), g16, R, 4 * D, D, D, 4 * D), s, ws_fb));
+            M3R_OK(wmlp(c, c->params.at("decoder.feedback_layer.fc2.weight"), dt, &w, &ws_fb, s));
+            M3R_OK(gemm(c, dt, EPI_F32, gargs(g16, w, p32(c, "decoder.feedback_layer.fc2.bias"), off32, R, D, 4 * D, 4 * D, D), s, ws_fb));
         } else if (fb_lin) {
             M3R_OK(w16(c, "decoder.feedback_layer.weight", dt, &w, s));
             M3R_OK(gemm(c, dt, EPI_F32, gargs(h16, w, p32(c, "decoder.feedback_layer.bias"), off32, R, D, D, D, D), s));
@@ -1165,7 +1180,7 @@ extern "C" int must3r_hip_decode(must3r_hip_ctx* c, const must3r_hip_decode_args
     if (!c || !A || !A->groups || !A->mem) return fail("decode: null argument");
     if (!c->fin_dec) return fail("decode: decoder weights not finalized");
     const int adt = A->dtype & ~MUST3R_ATTN_FP8;
-    if (adt != MUST3R_BF16 && adt != MUST3R_F16 && adt != MUST3R_F16_W2) return fail("decode: bad dtype %d", A->dtype);
+    if (adt != MUST3R_BF16 && adt != MUST3R_F16 && adt != MUST3R_F16_W2 && adt != MUST3R_F16_WA) return fail("decode: bad dtype %d", A->dtype);
     if (A->mem_mode != MUST3R_MEM_KV && A->mem_mode != MUST3R_MEM_NORM_Y && A->mem_mode != MUST3R_MEM_RAW)
         return fail("decode: bad mem_mode %d", A->mem_mode);
     if (A->n_groups <= 0) return fail("decode: no input group");

@@ -8,10 +8,11 @@ import torch.nn as nn
 
 from .. import _lib
 
-# 'fp16w2' = fp16 operands with split weights (W_hi + W_lo): the mode that meets the 1e-3 parity target with margin
-_DT = {"bf16": _lib.BF16, "fp16": _lib.F16, "fp16w2": _lib.F16_W2, torch.bfloat16: _lib.BF16, torch.float16: _lib.F16}
-_TORCH_DT = {_lib.BF16: torch.bfloat16, _lib.F16: torch.float16, _lib.F16_W2: torch.float16}
-PRECISIONS = ("bf16", "fp16", "fp16w2")
+# 'fp16w2' = fp16 operands with split weights (W_hi + W_lo): the mode that meets the 1e-3 parity target with the widest margin
+# 'fp16wa' = the same with PLAIN fp16 weights in the Mlp Linears (2/3 of the GEMM FLOPs in one MFMA pass): inside the target too
+_DT = {"bf16": _lib.BF16, "fp16": _lib.F16, "fp16w2": _lib.F16_W2, "fp16wa": _lib.F16_WA, torch.bfloat16: _lib.BF16, torch.float16: _lib.F16}
+_TORCH_DT = {_lib.BF16: torch.bfloat16, _lib.F16: torch.float16, _lib.F16_W2: torch.float16, _lib.F16_WA: torch.float16}
+PRECISIONS = ("bf16", "fp16", "fp16w2", "fp16wa")
 _VERSION_OF = operator.attrgetter("_version")
 _DEBUG_WEIGHTS = bool(int(os.environ.get("M3R_DEBUG_WEIGHTS", "0") or 0))
 
