@@ -137,11 +137,13 @@ def main():
     if world > 1:
         gidx = torch.arange(rank * V, (rank + 1) * V)
         keyframes = (gidx % world == 0)                    # 20 keyframes spread over all ranks
+        # the schedule is static: every rank knows every rank's keyframe count (no count exchange, no read-back in the step)
+        kf_counts = [int((torch.arange(r * V, (r + 1) * V) % world == 0).sum()) for r in range(world)]
     n_key = V
 
     def step():
         if world > 1:
-            return run_scene_sharded(enc, dec, imgs, ts, keyframes, comm_dtype=tdt)
+            return run_scene_sharded(enc, dec, imgs, ts, keyframes, comm_dtype=tdt, keyframe_counts=kf_counts)
         return run_scene(enc, dec, imgs, ts, overlap=args.overlap, enc_chunk=args.enc_chunk)
 
     def sync():
@@ -365,7 +367,8 @@ def main():
             lo, hi = shard_range(V, rank, world)
             simgs, sts = simgs[lo:hi].to(device), sts[lo:hi].to(device)
             kf_all = torch.ones(hi - lo, dtype=torch.bool)
-            fns = lambda: run_scene_sharded(enc, dec, simgs, sts, kf_all, comm_dtype=tdt)  # noqa: E731
+            kc_all = [shard_range(V, r, world)[1] - shard_range(V, r, world)[0] for r in range(world)]
+            fns = lambda: run_scene_sharded(enc, dec, simgs, sts, kf_all, comm_dtype=tdt, keyframe_counts=kc_all)  # noqa: E731
             fns()
             d = timed(fns, ksteps)
             configs.append({"config": f"configs[2] STRONG scaling: the same {V}-view 384x512 scene sharded over {world} ranks "
@@ -377,13 +380,26 @@ def main():
             vimgs, vts = S.make_images(F, H, W, seed=7)
             lo, hi = shard_range(F, rank, world)
             vimgs, vts = vimgs[lo:hi].to(device), vts[lo:hi].to(device)
-            fnv = lambda: run_video_sharded(enc, dec, vimgs, vts, comm_dtype=tdt, render=False)  # noqa: E731
+            fc_all = [shard_range(F, r, world)[1] - shard_range(F, r, world)[0] for r in range(world)]
+            fnv = lambda: run_video_sharded(enc, dec, vimgs, vts, comm_dtype=tdt, render=False, frame_counts=fc_all)  # noqa: E731
             fnv()
             d = timed(fnv, 1)
             configs.append({"config": f"configs[3] MUSt3R_512 {F}-frame online streaming memory, frames sharded over {world} ranks "
                                       "(encode sharded, all-gather of all frame tokens, per-frame memory update replicated)",
                             "value": round(F / d, 2), "unit": "frames/s", "ms_per_step": round(d * 1e3, 2), "frames": F,
                             "scaling": "strong", "dtype": dtype_label})
+            del vimgs
+            # REPLICAS: independent scenes per rank -- the metric's whole-node definition ("independent scenes ->
+            # pure replicas"): every rank runs its own S scenes in flight, no data-path collective; whole-node views/s = sum over ranks
+            Sn = max(1, args.scenes)
+            rimgs = torch.stack([S.make_images(V, H, W, seed=5000 + rank * 64 + b)[0].to(device) for b in range(Sn)])
+            fnr = (lambda: run_scenes(enc, dec, rimgs, ts)) if Sn > 1 else (lambda: run_scene(enc, dec, rimgs[0], ts))  # noqa: E731
+            fnr()
+            d = timed(fnr, ksteps)
+            configs.append({"config": f"configs[2] REPLICAS: {world} ranks x {Sn} independent {V}-view 384x512 scenes in flight per rank "
+                                      "(no data-path collective; barrier + max over ranks around the timed region)",
+                            "value": round(world * Sn * V * ksteps / d, 2), "unit": "views/s", "ms_per_step": round(d / ksteps * 1e3, 3),
+                            "scaling": "weak", "dtype": dtype_label})
 
     cpu_baseline, parity = None, None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -459,6 +475,9 @@ def main():
                        "H": H, "W": W, "parallelism": "single" if world == 1 else f"view-sharded x{world} + all-gather(keyframe tokens) [{backend}]"},
             "roofline": roofline, "roofline_gemm": roofline_gemm, "cpu_baseline": cpu_baseline, "parity_vs_cpu_oracle": parity,
             "kernel_classes": classes, "stages_ms": stages, "scenes_in_flight": flight, "alt": alt, "configs": configs, "postprocess_cam": cam,
+            "multi_gpu": ("this line is a 1-GPU run; no RCCL run of the N > 1 path has happened in the build environment (one GPU per box): the "
+                          "sharded path is covered by world-size-2 gloo tests and a 2-rank gloo dry run of this script" if world == 1 else
+                          f"{world} ranks, backend {backend}"),
             "scene_tflop": round(flops / 1e12, 2) if flops else None,
             "end_to_end_mfma_frac": round(flops * args.steps / dt / 1e12 / PEAK_TFLOPS[args.precision], 4) if flops else None,
         }

@@ -76,9 +76,14 @@ def all_gather_varlen(t, group=None, counts=None):
     else:
         pad = torch.zeros((kmax,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
         pad[: t.shape[0]] = t
-    out = [torch.empty_like(pad) for _ in range(world)]
-    dist.all_gather(out, pad, group=group)
-    return torch.cat([o[:c] for o, c in zip(out, counts)], dim=0)
+    # ONE flat destination (all_gather_into_tensor: a single collective writing every rank's block at its offset, no per-rank
+    # tensor list and no concatenation afterwards); ragged shards are compacted with one index_select
+    out = torch.empty((world * kmax,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+    dist.all_gather_into_tensor(out, pad, group=group)
+    if min(counts) == kmax:
+        return out
+    keep = torch.cat([torch.arange(r * kmax, r * kmax + c) for r, c in enumerate(counts)]).to(t.device)
+    return out.index_select(0, keep)
 
 
 def _encode_local(encoder, imgs_local, true_shape_local):
@@ -91,11 +96,16 @@ def _encode_local(encoder, imgs_local, true_shape_local):
             torch.zeros((0, N, 2), dtype=torch.int64, device=imgs_local.device))
 
 
-def _gather_keyframes(x, pos, true_shape_local, keyframe_local, group, comm_dtype):
+def _gather_keyframes(x, pos, true_shape_local, keyframe_local, group, comm_dtype, counts=None):
     """All-gather of the encoded keyframe tokens (+ positions, shapes) in rank order.  The keyframe selection is a host
-    index list (no boolean-mask indexing on the device = no nonzero() sync)."""
+    index list (no boolean-mask indexing on the device = no nonzero() sync).  ``counts``: keyframes per rank when the caller
+    knows the schedule (a benchmark, a fixed keyframe stride): no count exchange, no device->host read-back at all."""
     idx = torch.nonzero(keyframe_local.cpu()).flatten()
-    counts = gather_counts(int(idx.numel()), x.device, group)               # one exchange for all three gathers
+    if counts is None:
+        counts = gather_counts(int(idx.numel()), x.device, group)           # one exchange for all three gathers
+    else:
+        counts = [int(c) for c in counts]
+        assert counts[_world(group)[0]] == int(idx.numel()), (counts, int(idx.numel()))
     idx_d = idx.to(x.device)
     kx = x.index_select(0, idx_d)
     if comm_dtype is not None:
@@ -115,16 +125,17 @@ def _render_local(decoder, x, pos, true_shape_local, mem, imgs_local):
 
 @torch.no_grad()
 def run_scene_sharded(encoder, decoder, imgs_local, true_shape_local, keyframe_local, group=None, comm_dtype=None,
-                      mem_batches=None, gather_outputs=False):
+                      mem_batches=None, gather_outputs=False, keyframe_counts=None):
     """One scene whose views are sharded over the ranks of ``group``.
 
     imgs_local [v,3,H,W], true_shape_local [v,2]: this rank's views (global order = rank order, then local order; v may be
     0 when there are fewer views than ranks).  keyframe_local bool[v]: which local views enter the memory.  Returns
     dict(render=[v,H,W,7] local pointmaps, mem=memory tuple (identical on all ranks), n_keyframes) (+ render_all when
     gather_outputs).  With all views keyframes this is the STRONG-scaling form of the 20-view benchmark scene.
+    ``keyframe_counts``: keyframes per rank, when known on the host (skips the count exchange).
     """
     x, pos = _encode_local(encoder, imgs_local, true_shape_local)
-    kx, kpos, kts = _gather_keyframes(x, pos, true_shape_local, keyframe_local, group, comm_dtype)
+    kx, kpos, kts = _gather_keyframes(x, pos, true_shape_local, keyframe_local, group, comm_dtype, keyframe_counts)
     K = kx.shape[0]
     if K == 0:
         raise ValueError("run_scene_sharded: no keyframe on any rank")
@@ -144,7 +155,7 @@ def run_scene_sharded(encoder, decoder, imgs_local, true_shape_local, keyframe_l
 
 @torch.no_grad()
 def run_video_sharded(encoder, decoder, imgs_local, true_shape_local, group=None, comm_dtype=None, local_context_size=25,
-                      is_keyframe=lambda i: i % 3 == 0, init_num_images=2, render=True, gather_outputs=False):
+                      is_keyframe=lambda i: i % 3 == 0, init_num_images=2, render=True, gather_outputs=False, frame_counts=None):
     """Online / streaming memory over a sharded frame sequence (BASELINE.json configs[3]; schedule of
     ``inference_video_multi_ar``, engine/inference.py:232-366, via ``engine.run_video``).
 
@@ -158,7 +169,7 @@ def run_video_sharded(encoder, decoder, imgs_local, true_shape_local, group=None
     from .engine import run_video
     x, pos = _encode_local(encoder, imgs_local, true_shape_local)
     all_kf = torch.ones(x.shape[0], dtype=torch.bool)
-    ax, apos, ats = _gather_keyframes(x, pos, true_shape_local, all_kf, group, comm_dtype)
+    ax, apos, ats = _gather_keyframes(x, pos, true_shape_local, all_kf, group, comm_dtype, frame_counts)
     mem, pm0, keyframes = run_video(None, decoder, None, ats, local_context_size=local_context_size, is_keyframe=is_keyframe,
                                     init_num_images=init_num_images, encoder_tokens=(ax, apos))
     out = {"mem": mem, "keyframes": keyframes, "pointmaps_0": pm0}

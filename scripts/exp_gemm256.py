@@ -16,7 +16,8 @@ L = lib.load()
 P = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None  # noqa: E731
 st = torch.cuda.current_stream().cuda_stream
 split = int(os.environ.get("SPLIT", "0"))
-tdt, dti = (torch.float16, 1) if split else (torch.bfloat16, 0)
+plain16 = int(os.environ.get("PLAIN16", "0"))   # fp16 operands with plain weights (the Mlp Linears of MUST3R_F16_WA)
+tdt, dti = (torch.float16, 1) if (split or plain16) else (torch.bfloat16, 0)
 shapes = [("enc qkv", 15360, 3072, 1024, lib.EPI_STORE16), ("enc proj", 15360, 1024, 1024, lib.EPI_RESID_F32),
           ("enc fc1", 15360, 4096, 1024, lib.EPI_STORE16_GELU), ("enc fc2", 15360, 1024, 4096, lib.EPI_RESID_F32),
           ("dec qkv", 15360, 2304, 768, lib.EPI_STORE16), ("dec proj", 15360, 768, 768, lib.EPI_RESID_F32),
@@ -62,4 +63,4 @@ for name, M, N, K, epi in shapes:
         tot_t += ms
         tot_f += fl
     print(f"{name:10s} M={M:6d} N={N:5d} K={K:5d} {ms * 1e3:8.1f} us {fl / ms / 1e9:7.1f} TF/s  err {err:.2e}  sha {digest}", flush=True)
-print(f"mode {os.environ.get('M3R_GEMM256', '1')} split {split}: big shapes {tot_t * 1e3:.0f} us, {tot_f / tot_t / 1e9:.1f} TF/s (algorithmic)")
+print(f"mode {os.environ.get('M3R_GEMM256', '1')} G256S {os.environ.get('M3R_G256S', '0')} split {split} plain16 {plain16}: big shapes {tot_t * 1e3:.0f} us, {tot_f / tot_t / 1e9:.1f} TF/s (algorithmic)")

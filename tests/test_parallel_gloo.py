@@ -51,6 +51,10 @@ def _worker(rank, world, port, out_dir):
         enc, dec = _oracle_pair()
         with torch.no_grad():
             out = run_scene_sharded(enc, dec, imgs[lo:hi], ts[lo:hi], _keyframes()[lo:hi], gather_outputs=True)
+            # the same with the keyframe counts of both ranks known on the host (no count exchange): identical result
+            kc = [int(_keyframes()[a:b].sum()) for a, b in (shard_range(V, r, world) for r in range(world))]
+            out_s = run_scene_sharded(enc, dec, imgs[lo:hi], ts[lo:hi], _keyframes()[lo:hi], gather_outputs=True, keyframe_counts=kc)
+            assert torch.equal(out_s["render_all"], out["render_all"]) and torch.equal(out_s["mem"][0][-1], out["mem"][0][-1])
         torch.save({"render_all": out["render_all"], "mem_last": out["mem"][0][-1], "labels": out["mem"][1], "K": out["n_keyframes"]},
                    os.path.join(out_dir, f"r{rank}.pt"))
         # a rank WITHOUT views (fewer views than ranks): empty encoder batch skipped, [0,H,W,7] render, gather still works
