@@ -695,246 +695,15 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(OCC ==
     }
 }
 
-// ------------------------------------------------------------------------------------------------------------------
-// gemm256s_kernel (r03): the same tile, ring and epilogues, but ALL EIGHT waves multiply all the time and every wave streams its own
-// fragments under its own MFMAs -- no read interval / multiply interval, no hand-over between wave groups.
-//   Why: the staggered two-group loop above loses ~360 ticks at every hand-over barrier (profiles/r02_gemm256_trace*.txt): 24 % of a
-//   64-MFMA interval with split weights, 39 % of the 32-MFMA interval of PLAIN weights (MUST3R_F16_WA runs 2/3 of its GEMM FLOPs on plain
-//   weights).  Here a K-tile costs ONE block barrier, and the fragment reads are spread over the tile: the weight fragments of a K-tile
-//   (NF x WS, they serve all 8 row fragments) are held, the activation fragments are streamed one row fragment ahead of their MFMAs, and
-//   the first fragments of tile t+1 are read while the last row fragments of tile t are multiplied (after the barrier that publishes t+1).
-//   Registers: 128 accumulators + 2 x NF x WS weight fragments + 2 activation fragments (plain: 168, split: 200 + addresses).
-//   RAW  a wave waits (counted vmcnt) for ITS pieces of tile t+1 before the barrier inside tile t; nobody reads tile t+1 before it.
-//   WAR  tile t+NST-1 lands in the buffer of tile t-1; it is issued after the barrier inside tile t, which every wave reaches only after
-//        its last read of tile t-1 has been consumed by an MFMA of tile t-1 (program order).
-// Same accumulation order per output as every other tile shape (k ascending, hi before lo): identical bits.
-template <class T, int EPI, int WS, int BN>
-__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) gemm256s_kernel(const GemmArgs p) {
-    typedef typename Vec<T>::v8 v8;
-    constexpr int BM = 256, BK = 32;
-    constexpr int WR = WS * BN;
-    constexpr int NST = WR >= 384 ? 3 : 4;
-    constexpr int WN = BN / 4;
-    constexpr int MF = 8, NF = WN / 16;
-    constexpr int PW = WR / 128;
-    constexpr int IPT = 2 + PW;
-    constexpr int STAGE = (BM + WR) * BK;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    T* const lds = reinterpret_cast<T*>(smem);
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wave >> 2, wc = wave & 3;
-
-    const int nbn = p.N / BN;
-    const int nbm = (p.M + BM - 1) / BM;
-    const int nwg = nbm * nbn;
-    int bid = blockIdx.x;
-    {
-        const int xcd = bid & 7, slot = bid >> 3;
-        const int q = nwg >> 3, r = nwg & 7;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
-    }
-    constexpr int GM = 4;
-    const int tpg = GM * nbn;
-    const int gidx = bid / tpg;
-    const int gfirst = gidx * GM;
-    const int gsz = (nbm - gfirst < GM) ? nbm - gfirst : GM;
-    const int gin = bid - gidx * tpg;
-    const int m0 = (gfirst + gin % gsz) * BM;
-    const int n0 = (gin / gsz) * BN;
-
-    const int grp = blockIdx.y;
-    const T* __restrict__ A = reinterpret_cast<const T*>(p.A) + (size_t)grp * p.strideA;
-    const int wgrp = p.wdiv > 1 ? grp / p.wdiv : grp;
-    const T* __restrict__ W = reinterpret_cast<const T*>(p.W) + (size_t)wgrp * p.strideW;
-    const float* __restrict__ bias = p.bias ? p.bias + (size_t)wgrp * p.strideB : nullptr;
-    void* const outp = p.out_table ? p.out_table[grp] : p.out;
-
-    const int srow = lane >> 2, pch = lane & 3;
-    const T* a_src[2];
-    const T* w_src[PW];
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        const int r = (wave * 2 + t) * 16 + srow;
-        int gr = m0 + r;
-        gr = gr < p.M ? gr : p.M - 1;
-        a_src[t] = A + (size_t)gr * p.lda + swz32(r, pch) * 8;
-    }
-#pragma unroll
-    for (int t = 0; t < PW; ++t) {
-        const int r = (wave * PW + t) * 16 + srow;
-        const int part = r / BN, wrow = r - part * BN;
-        w_src[t] = W + (size_t)(n0 + wrow) * (size_t)(p.K * WS) + (size_t)part * p.K + swz32(r, pch) * 8;
-    }
-    auto stage = [&](int kt, int buf) {
-        T* base = lds + buf * STAGE;
-#pragma unroll
-        for (int t = 0; t < 2; ++t) glds16(a_src[t] + kt * BK, base + (wave * 2 + t) * 16 * BK);
-#pragma unroll
-        for (int t = 0; t < PW; ++t) glds16(w_src[t] + kt * BK, base + BM * BK + (wave * PW + t) * 16 * BK);
-    };
-
-    f32x4 acc[MF][NF];
-#pragma unroll
-    for (int i = 0; i < MF; ++i)
-#pragma unroll
-        for (int j = 0; j < NF; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    const int fr = lane & 15, fg = lane >> 4;
-    const int nk = p.K / BK;
-    int a_off[MF], w_off[WS][NF];
-#pragma unroll
-    for (int i = 0; i < MF; ++i) {
-        const int r = wr * 128 + i * 16 + fr;
-        a_off[i] = r * BK + swz32(r, fg) * 8;
-    }
-#pragma unroll
-    for (int part = 0; part < WS; ++part)
-#pragma unroll
-        for (int j = 0; j < NF; ++j) {
-            const int r = part * BN + wc * WN + j * 16 + fr;
-            w_off[part][j] = BM * BK + r * BK + swz32(r, fg) * 8;
-        }
-    auto wait_tile = [&](int u) {
-        const int younger = nk - 1 - u;
-        if (NST >= 4 && younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * IPT) : "memory");
-        else if (NST >= 3 && younger >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(IPT) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    };
-
-#pragma unroll
-    for (int t = 0; t < NST - 1; ++t)
-        if (t < nk) stage(t, t);
-    wait_tile(0);
-    __builtin_amdgcn_s_barrier();
-    // ---- fragment reads: inline asm + hand-counted lgkmcnt (LDS operations return in order).  Per tile a wave issues, in program order,
-    //   phase i (row fragment i):  A(i+2)  [tile t+1's A(0), A(1) in phases 6, 7]   then, in phases 6 / 7, half of tile t+1's weight fragments
-    // and consumes A(i) behind them.  Reads younger than A(i) when it is needed: 2 (phases 1-5), 2 + NW2 (phase 6), 2 + 2 NW2 (phase 7);
-    // phase 0 also needs ALL weight fragments of its tile (issued in phases 6 / 7 of the previous one): 1 younger read (its own A(2)).
-    // The activation fragments live in a ring of four registers sets (fragment i in slot i & 3: tile t+1's fragments 0 / 1 land in slots
-    // 0 / 1 without a copy), the weight fragments in two sets that alternate with the tile parity (the loop is unrolled by two).
-    constexpr int NW2 = NF * WS / 2;
-    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) const char*)smem;
-    const unsigned a_lane = lds0 + (unsigned)a_off[0] * 2, w_lane = lds0 + (unsigned)w_off[0][0] * 2;
-    v8 wf[2][WS][NF], af[4];
-#define M3R_DSR(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
-#define M3R_LGKM(n, x) asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(x) : "n"(n))
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // scalar loads share the counter: none may be in flight under the counted waits
-#pragma unroll
-    for (int part = 0; part < WS; ++part)
-#pragma unroll
-        for (int j = 0; j < NF; ++j) M3R_DSR(wf[0][part][j], w_lane, (part * BN * BK + j * 16 * BK) * 2);
-    M3R_DSR(af[0], a_lane, 0);
-    M3R_DSR(af[1], a_lane, 16 * BK * 2);
-    constexpr int PUB = MF - 3;   // the barrier that publishes tile t+1 sits in front of row fragment PUB of tile t
-    int buf = 0;
-    auto tile = [&](int t, auto parc) {
-        constexpr int PAR = decltype(parc)::value;
-        const int nbuf = buf + 1 == NST ? 0 : buf + 1;
-        const unsigned a_cur = a_lane + (unsigned)(buf * STAGE * 2), a_nxt = a_lane + (unsigned)(nbuf * STAGE * 2);
-        const unsigned w_nxt = w_lane + (unsigned)(nbuf * STAGE * 2);
-        const bool more = t + 1 < nk;
-#pragma unroll
-        for (int i = 0; i < MF; ++i) {
-            if (i == PUB) {
-                // every wave has consumed its reads of tile t-1 long ago: its buffer takes tile t+NST-1; tile t+1 becomes visible
-                if (more) wait_tile(t + 1);
-                __builtin_amdgcn_s_barrier();
-                if (t + NST - 1 < nk) {
-                    int sb = buf + NST - 1;
-                    sb = sb >= NST ? sb - NST : sb;
-                    stage(t + NST - 1, sb);
-                }
-            }
-            // (the LAST tile issues the "next tile" reads too -- they fetch stale ring contents nobody uses: the counted waits are then the
-            //  same in every tile, with no branch around a statement that carries an in-flight register.  A branch there makes the register
-            //  allocator copy the fragment at the join, possibly BEFORE the wait, i.e. before the data has landed.)
-            if (i + 2 < MF) M3R_DSR(af[(i + 2) & 3], a_cur, (i + 2) * 16 * BK * 2);
-            else M3R_DSR(af[(i + 2) & 3], a_nxt, (i + 2 - MF) * 16 * BK * 2);
-            if (i > PUB) {   // next tile's weight fragments: half of them behind each of the last two row fragments
-#pragma unroll
-                for (int part = 0; part < WS; ++part)
-#pragma unroll
-                    for (int j = 0; j < NF; ++j)
-                        if ((part * NF + j) / NW2 == i - PUB - 1) M3R_DSR(wf[PAR ^ 1][part][j], w_nxt, (part * BN * BK + j * 16 * BK) * 2);
-            }
-            // wait for A(i) (phase 0: and for every weight fragment of this tile)
-            if (i == 0) {
-                M3R_LGKM(1, af[0]);
-#pragma unroll
-                for (int part = 0; part < WS; ++part)
-#pragma unroll
-                    for (int j = 0; j < NF; ++j) asm volatile("" : "+v"(wf[PAR][part][j]));
-            } else if (i < MF - 2) {
-                M3R_LGKM(2, af[i & 3]);
-            } else if (i == MF - 2) {
-                M3R_LGKM(2 + NW2, af[i & 3]);
-            } else {
-                M3R_LGKM(2 + 2 * NW2, af[i & 3]);
-            }
-            __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-            for (int part = 0; part < WS; ++part)
-#pragma unroll
-                for (int j = 0; j < NF; ++j) acc[i][j] = mfma16(wf[PAR][part][j], af[i & 3], acc[i][j]);
-            __builtin_amdgcn_s_setprio(0);
-        }
-        buf = nbuf;
-    };
-    for (int t = 0; t < nk; t += 2) {
-        tile(t, std::integral_constant<int, 0>{});
-        if (t + 1 < nk) tile(t + 1, std::integral_constant<int, 1>{});
-    }
-    // the last tile's dummy reads are still in flight: their destination registers (nk is even -- K % 64 == 0 -- so the last tile has
-    // parity 1 and they are wf[0] and the activation slots 0 / 1) stay LIVE up to this wait, or the epilogue would reuse them under the
-    // landing data (scripts/checks/asm_inflight_regs.py walks the generated code for exactly that)
-    if constexpr (WS == 2 && NF == 4)
-        asm volatile("s_waitcnt lgkmcnt(0)"
-                     : "+v"(af[0]), "+v"(af[1]), "+v"(wf[0][0][0]), "+v"(wf[0][0][1]), "+v"(wf[0][0][2]), "+v"(wf[0][0][3]), "+v"(wf[0][1][0]),
-                       "+v"(wf[0][1][1]), "+v"(wf[0][1][2]), "+v"(wf[0][1][3])
-                     :
-                     : "memory");
-    else if constexpr (WS == 2 && NF == 3)
-        asm volatile("s_waitcnt lgkmcnt(0)"
-                     : "+v"(af[0]), "+v"(af[1]), "+v"(wf[0][0][0]), "+v"(wf[0][0][1]), "+v"(wf[0][0][2]), "+v"(wf[0][1][0]), "+v"(wf[0][1][1]),
-                       "+v"(wf[0][1][2])
-                     :
-                     : "memory");
-    else if constexpr (WS == 2 && NF == 2)
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(af[0]), "+v"(af[1]), "+v"(wf[0][0][0]), "+v"(wf[0][0][1]), "+v"(wf[0][1][0]), "+v"(wf[0][1][1]) : : "memory");
-    else {
-        static_assert(WS == 2 || NF == 4, "gemm256s: add the drain statement for this geometry");
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(af[0]), "+v"(af[1]), "+v"(wf[0][0][0]), "+v"(wf[0][0][1]), "+v"(wf[0][0][2]), "+v"(wf[0][0][3]) : : "memory");
-    }
-#undef M3R_DSR
-#undef M3R_LGKM
-
-#pragma unroll
-    for (int i = 0; i < MF; ++i) {
-        const int m = m0 + wr * 128 + i * 16 + fr;
-        if (m >= p.M) continue;
-        f32x4 v[NF];
-#pragma unroll
-        for (int j = 0; j < NF; ++j) v[j] = acc[i][j];
-        epilogue_row<T, EPI, NF>(p, outp, bias, m, n0 + wc * WN, fg, v);
-    }
-}
-
-template <class T, int EPI, int WS, int BN>
-static int launch_256s(const GemmArgs& a, hipStream_t s) {
-    const int nbn = a.N / BN, nbm = (a.M + 255) / 256;
-    const size_t lds = (size_t)(WS * BN >= 384 ? 3 : 4) * (256 + WS * BN) * 32 * sizeof(T);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256s_kernel<T, EPI, WS, BN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
-    }
-    hipLaunchKernelGGL((gemm256s_kernel<T, EPI, WS, BN>), dim3(nbm * nbn, a.batch > 1 ? a.batch : 1), dim3(512), lds, s, a);
-    return hipGetLastError() == hipSuccess ? 0 : 1;
-}
-
+// (r03, built / measured / removed: `gemm256s_kernel` -- the same tile, ring and epilogues with ALL EIGHT waves multiplying all the time,
+// every wave streaming its own fragments under its own MFMAs (activation fragments two row fragments ahead, the next tile's weight fragments
+// behind the last two, hand-counted lgkmcnt from inline-asm reads, ONE block barrier per K-tile, no hand-over between wave groups).  Same bits;
+// nine chip-filling shapes: 907 us against 913 us on plain fp16 weights, 1382 against 1323 us on split weights (profiles/r03_gemm256s_ab.txt).
+// Two loop structures this different landing on the same time says the hand-over hole is not the limit: a K-tile costs a SIMD the SUM of what
+// its two waves issue -- 2 x (32 MFMAs x 16 + 4 LDS-DMA pieces x ~64 + 12 ds_read_b128 x ~27 cycles) = ~2200 cycles against 1024 of MFMA time
+// (plain weights; measured ~2000) -- whichever wave issues what when.  Only fewer non-MFMA issue cycles per MFMA move it: weight fragments
+// straight from L2 into registers (no DMA, no ds_read for them), or 128 x 128 wave tiles.  The kernel is in the git history
+// (commit "gemm256s_kernel: streamed-fragment 256-row GEMM"); scripts/checks/asm_inflight_regs.py, written for it, stays.)
 template <class T, int EPI, int WS, int BN, int OCC = 1>
 static int launch_256(const GemmArgs& a, hipStream_t s) {
     const int nbn = a.N / BN, nbm = (a.M + 255) / 256;
@@ -1427,15 +1196,6 @@ static int fill256(long tiles) {   // percentage of the CU slots of its rounds t
     const long rounds = (tiles + 255) / 256;
     return (int)(tiles * 100 / (rounds * 256));
 }
-// M3R_G256S: the streamed-fragment 256-row kernel (gemm256s_kernel) instead of the two-group one: 1 = plain-weight launches, 2 = split ones too
-static int g256s_mode() {
-    static int v = -1;
-    if (v < 0) {
-        const char* e = getenv("M3R_G256S");
-        v = e ? atoi(e) : 0;
-    }
-    return v;
-}
 static int g256_bn_override() {    // experiments: M3R_G256_BN = 128 / 256 forces the split-mode tile width
     static int v = -1;
     if (v < 0) {
@@ -1488,8 +1248,8 @@ static int launch_epi(const GemmArgs& a, hipStream_t s, const char** err) {
             } else if (EPI == EPI_STORE16_GELU && gelu_occ2 && mode != 0 && ok128 && t128 >= 1024) rc = launch_256<T, EPI, 2, 128, 2>(a, s);
             else if (EPI != EPI_HEAD && use_96(a, nb)) rc = launch_96<T, EPI == EPI_HEAD ? EPI_STORE16 : EPI>(a, s);
             else if (EPI != EPI_QKV_ROPE && EPI != EPI_HEAD && use_48(a, nb)) rc = launch_48<T, EPI == EPI_QKV_ROPE || EPI == EPI_HEAD ? EPI_STORE16 : EPI, 2>(a, s);
-            else if (pick == 256) rc = g256s_mode() >= 2 ? launch_256s<T, EPI, 2, 256>(a, s) : launch_256<T, EPI, 2, 256>(a, s);
-            else if (pick == 192) rc = g256s_mode() >= 2 ? launch_256s<T, EPI == EPI_QKV_ROPE ? EPI_STORE16 : EPI, 2, 192>(a, s) : launch_256<T, EPI == EPI_QKV_ROPE ? EPI_STORE16 : EPI, 2, 192>(a, s);
+            else if (pick == 256) rc = launch_256<T, EPI, 2, 256>(a, s);
+            else if (pick == 192) rc = launch_256<T, EPI == EPI_QKV_ROPE ? EPI_STORE16 : EPI, 2, 192>(a, s);
             else if (pick == 128) {
                 static const bool occ2 = getenv("M3R_G256_OCC2") && atoi(getenv("M3R_G256_OCC2")) != 0;   // experiments: every 128-column launch
                 rc = occ2 ? launch_256<T, EPI, 2, 128, 2>(a, s) : launch_256<T, EPI, 2, 128>(a, s);
@@ -1512,7 +1272,7 @@ static int launch_epi(const GemmArgs& a, hipStream_t s, const char** err) {
             else rc = 1;
         } else if (EPI != EPI_QKV_ROPE && EPI != EPI_HEAD && sizeof(T) == 2 && use_48(a, nb)) {
             rc = launch_48<T, EPI == EPI_QKV_ROPE || EPI == EPI_HEAD ? EPI_STORE16 : EPI, 1>(a, s);   // N = 768 one-view launches: 256 tiles of 48 x 48
-        } else if (ok256 && (mode == 2 || (mode == 1 && t256 >= 200 && fill256(t256) >= 80))) rc = g256s_mode() >= 1 ? launch_256s<T, EPI, 1, 256>(a, s) : launch_256<T, EPI, 1, 256>(a, s);
+        } else if (ok256 && (mode == 2 || (mode == 1 && t256 >= 200 && fill256(t256) >= 80))) rc = launch_256<T, EPI, 1, 256>(a, s);
         else if (n128 && tiles128 >= min_big(false)) rc = launch_cfg<T, 128, 128, 2, 2, EPI, 2, 1>(a, s);
         else if (small8((long)((a.M + 63) / 64) * (a.N / 64) * nb)) rc = launch_cfg<T, 64, 64, SMALL_WGM, 2, EPI, SMALL8_NST_PLAIN, 1, 64, 1>(a, s);
         else rc = launch_cfg<T, 64, 64, 2, 2, EPI, 4, 1>(a, s);

@@ -1,6 +1,6 @@
 """Static check of hand-counted LDS waits in the generated assembly (build-time helper, not part of the product).
 
-Kernels that issue their fragment reads from inline asm (gemm256s_kernel) count `lgkmcnt` by hand.  The property to hold on EVERY
+Kernels that issue their fragment reads from inline asm (the r03 gemm256s_kernel experiment, attn4_kernel) count `lgkmcnt` by hand.  The property to hold on EVERY
 path through the kernel: between a `ds_read_b128 vDST, ...` and an `s_waitcnt lgkmcnt(N)` that guarantees its arrival, no
 instruction reads or writes a register of vDST (the register allocator may otherwise copy a fragment -- at a join, for a tied asm
 operand -- before the data has landed, or reuse the register).  LDS operations return in order: a read has arrived once a wait with
