@@ -4,18 +4,23 @@
     python bench.py --gpus 1 --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
-A "step" is one pass of the hot path over one batch of synthetic input already resident in HBM:
-  N = 1 : one scene of 20 views -- encode 20, memory update with the demo schedule [2,1,...,1] (20-view memory),
-          render 20 against the final memory, fp32 activation (BASELINE.json configs[2]).
-  N > 1 : weak scaling of the same workload: every rank owns 20 views (20*N views per step); the memory is still
-          built from 20 keyframes (every N-th view), whose encoded tokens are all-gathered over RCCL/xGMI and the
-          sequential update is replicated on every rank; encode and render are view-sharded (must3r_amd/parallel.py).
-Prints ONE JSON line on rank 0.  Beside the headline it carries a ``configs`` array with the other BASELINE.json
-configurations measured in the same run (never part of ``value``):
+A "step" is one pass of the hot path over one batch of synthetic input already resident in HBM: S (``--scenes``, default 8)
+independent scenes of 20 views per rank -- every scene: encode 20, memory update with the demo schedule [2,1,...,1] (20-view
+memory), render 20 against its final memory, fp32 activation (BASELINE.json configs[2]).  The S scenes
+are IN FLIGHT TOGETHER: they ride the batch dimension of the reference's decoder API (decoder.py:170-186), one native call per
+schedule step, so the strictly sequential memory update runs its GEMMs on S x 768 rows instead of 768.
+  N = 1 : ``value`` = S x 20 views per step / time.  ``single_scene`` carries the S = 1 numbers (one scene at a time: the
+          figure of rounds 1-2) with its stage split and kernel classes.
+  N > 1 : REPLICAS -- every rank runs its own S scenes (the metric's whole-node definition, SURVEY.md section 8e: independent
+          scenes shard with no data-path collective); barrier + max over ranks around the timed region.  The view-SHARDED
+          forms of one scene (RCCL all-gather of the encoded keyframe tokens over xGMI, replicated sequential update:
+          must3r_amd/parallel.py) are timed in the same run and reported under ``configs``.
+Prints ONE JSON line on rank 0.  ``configs`` carries the other BASELINE.json configurations measured in the same run (never
+part of ``value``):
   configs[1]  MUSt3R_224 10-view 224x224 scene
   configs[3]  200-frame online streaming memory (N = 1: one GPU; N > 1: frames sharded, all-gather, replicated update)
-  configs[4]  mixed-resolution scene 512 x {384,336,288,256,160} x 4 views through forward_list
-  N > 1 only: the STRONG-scaling form of the headline scene (the same 20 views sharded over the ranks).
+  configs[4]  mixed-resolution scene 512 x {384,336,288,256,160} x 4 views through forward_list, 16-bit and fp8 (MX) attention
+  N > 1 only: the weak- and strong-scaling view-sharded forms of the 20-view scene.
 """
 import argparse
 import json
@@ -86,8 +91,8 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--views", type=int, default=20)
-    ap.add_argument("--scenes", type=int, default=4, help="S: independent 20-view scenes in flight together for the `scenes_in_flight` "
-                    "line (they ride the decoder's batch dimension: M = S x 768 rows in the sequential memory update); 0/1 skips it")
+    ap.add_argument("--scenes", type=int, default=8, help="S: independent 20-view scenes in flight together per rank (they ride the "
+                    "decoder's batch dimension: M = S x 768 rows in the sequential memory update); 1 = one scene at a time")
     ap.add_argument("--precision", default="fp16wa", choices=["bf16", "fp16", "fp16w2", "fp16wa"],
                     help="MFMA operand mode; fp16wa (fp16, split weights except in the Mlp Linears) and fp16w2 (all weights split) meet the "
                          "1e-3 parity target")
@@ -97,9 +102,6 @@ def main():
     ap.add_argument("--no-configs", action="store_true", help="skip the extra BASELINE.json configurations")
     ap.add_argument("--stream-frames", type=int, default=200)
     ap.add_argument("--cpu-timeout", type=float, default=420.0)
-    ap.add_argument("--overlap", action="store_true", help="encode views 2.. on a second stream under the memory update (was +3 %% with "
-                    "the 4-wave GEMMs; the 8-wave one-block-per-CU GEMM leaves no room for co-resident kernels: no gain)")
-    ap.add_argument("--enc-chunk", type=int, default=6, help="views per encoder call on the second stream")
     args = ap.parse_args()
 
     import torch.distributed as dist
@@ -128,23 +130,18 @@ def main():
 
     cfg, H, W, V = MUST3R_512, 384, 512, args.views
     N = (H // 16) * (W // 16)
+    Sn = max(1, args.scenes)
     enc, dec, sde, sdd = build_models(cfg, args.precision, device)
-    imgs, ts = S.make_images(V, H, W, seed=rank)           # each rank its own views, resident in HBM
-    imgs, ts = imgs.to(device), ts.to(device)
+    # scene 0 of rank 0 is the seed-0 scene the CPU oracle runs; every other (rank, scene) has its own seed.  All resident in HBM.
+    ts = S.make_images(V, H, W, seed=0)[1]
+    scenes = torch.stack([S.make_images(V, H, W, seed=(0 if (rank == 0 and b == 0) else 1000 + rank * 64 + b))[0] for b in range(Sn)]).to(device)
+    imgs = scenes[0]
     tdt = torch.bfloat16 if args.precision == "bf16" else torch.float16
     dtype_label = {"bf16": "bf16", "fp16": "fp16", "fp16w2": "fp16 (split weights)",
                    "fp16wa": "fp16 (split weights in the attention-side Linears, plain in the Mlp Linears)"}[args.precision]
-    if world > 1:
-        gidx = torch.arange(rank * V, (rank + 1) * V)
-        keyframes = (gidx % world == 0)                    # 20 keyframes spread over all ranks
-        # the schedule is static: every rank knows every rank's keyframe count (no count exchange, no read-back in the step)
-        kf_counts = [int((torch.arange(r * V, (r + 1) * V) % world == 0).sum()) for r in range(world)]
-    n_key = V
 
     def step():
-        if world > 1:
-            return run_scene_sharded(enc, dec, imgs, ts, keyframes, comm_dtype=tdt, keyframe_counts=kf_counts)
-        return run_scene(enc, dec, imgs, ts, overlap=args.overlap, enc_chunk=args.enc_chunk)
+        return run_scenes(enc, dec, scenes, ts) if Sn > 1 else run_scene(enc, dec, imgs, ts)
 
     def sync():
         torch.cuda.synchronize(device)
@@ -168,7 +165,7 @@ def main():
     for _ in range(max(args.warmup, 1)):
         step()
     dt = timed(step, args.steps)
-    views_per_step = V * world
+    views_per_step = Sn * V * world
     value = views_per_step * args.steps / dt
 
     def profile_classes(fn):
@@ -188,50 +185,54 @@ def main():
                    for k, v in prof.items()}
         return prof, classes
 
-    # ---- S scenes in flight (single GPU): the same 20-view scenes, S of them riding the decoder's batch dimension
-    flight = None
-    simgs_all = None
-    if world == 1 and args.scenes > 1:
-        Sn = args.scenes
-        simgs_all = torch.stack([imgs] + [S.make_images(V, H, W, seed=1000 + b)[0].to(device) for b in range(1, Sn)])   # scene 0 = the headline scene
-        fnS = lambda: run_scenes(enc, dec, simgs_all, ts)  # noqa: E731
-        for _ in range(max(args.warmup, 1)):
-            fnS()
-        stepsS = max(2, (args.steps + Sn - 1) // Sn)
-        dS = timed(fnS, stepsS)
-        _, clsS = profile_classes(fnS)
+    def stage_split(n_scenes):
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
         ts_host = ts.cpu()
         ev[0].record()
-        xS, posS = enc(simgs_all.reshape(Sn * V, 3, H, W), ts_host.repeat(Sn, 1))
+        x, pos = enc(scenes[:n_scenes].reshape(n_scenes * V, 3, H, W), ts_host.repeat(n_scenes, 1))
         ev[1].record()
-        outS = run_scenes(enc, dec, simgs_all, ts, encoder_tokens=(xS, posS), activate=False)
+        x, pos = x.view(n_scenes, V, *x.shape[1:]), pos.view(n_scenes, V, *pos.shape[1:])
+        tsb = ts_host.unsqueeze(0).expand(n_scenes, -1, -1)
+        mem, i = None, 0
+        for nb in demo_mem_batches(V):
+            mem, _ = dec(x[:, i:i + nb], pos[:, i:i + nb], tsb[:, i:i + nb], mem)
+            i += nb
         ev[2].record()
+        dec(x, pos, tsb, mem, render=True)
+        ev[3].record()
         torch.cuda.synchronize(device)
-        flight = {"scenes_in_flight": Sn, "value": round(Sn * V * stepsS / dS, 2), "unit": "views/s", "steps": stepsS,
-                  "ms_per_step": round(dS / stepsS * 1e3, 3), "ms_per_scene": round(dS / stepsS / Sn * 1e3, 3),
-                  "workload": f"{Sn} independent {V}-view 384x512 scenes in flight: one batched native call per schedule step "
-                              f"(encode {Sn * V}, update [2,1,...,1] with M = {Sn} x 768 rows per GEMM, render {Sn * V}, activation)",
-                  "stages_ms": {"encode": round(ev[0].elapsed_time(ev[1]), 2), "update+render": round(ev[1].elapsed_time(ev[2]), 2)},
-                  "kernel_classes": clsS,
-                  "end_to_end_mfma_frac": round(Sn * scene_flops(N, V, V) * stepsS / dS / 1e12 / PEAK_TFLOPS[args.precision], 4)}
-        del xS, posS, outS
+        return {"encode": round(ev[0].elapsed_time(ev[1]), 2), "update": round(ev[1].elapsed_time(ev[2]), 2),
+                "render": round(ev[2].elapsed_time(ev[3]), 2)}
 
-    # ---- per-kernel-class timing of the single-scene step
-    roofline, stages, classes = None, None, None
-    prof, classes = profile_classes((lambda: run_scene(enc, dec, imgs, ts, overlap=False)) if world == 1 else step)
+    # ---- per-kernel-class timing of the step (one extra, untimed step) and its stage split
+    prof, classes = profile_classes(step)
+    stages = stage_split(Sn) if world == 1 else None
+
+    # ---- one scene at a time (S = 1): the figure of rounds 1-2, kept beside the headline
+    single = None
+    if world == 1 and Sn > 1:
+        fn1 = lambda: run_scene(enc, dec, imgs, ts)  # noqa: E731
+        fn1()
+        d1 = timed(fn1, args.steps)
+        _, cls1 = profile_classes(fn1)
+        single = {"value": round(V * args.steps / d1, 2), "unit": "views/s", "ms_per_step": round(d1 / args.steps * 1e3, 3),
+                  "workload": f"ONE {V}-view 384x512 scene at a time (encode {V}, update [2,1,...,1] one view per call = M 768 GEMMs, render {V})",
+                  "stages_ms": stage_split(1), "kernel_classes": cls1,
+                  "end_to_end_mfma_frac": round(scene_flops(N, V, V) * args.steps / d1 / 1e12 / PEAK_TFLOPS[args.precision], 4)}
+
     # roofline of the dominant KERNEL = one symbol of the rocprofv3 trace.  attn3_kernel (self + cross launches) is the top
     # symbol in every precision; the GEMM template is spread over one symbol per epilogue, so its two tile classes are
     # reported next to it under "roofline_gemm".
-    kern = {"attn3_kernel": (["attn_self", "attn_cross"], ("attn3_kernel", "attn_kernel", "attn2_kernel")),
+    kern = {"attn3_kernel": (["attn_self", "attn_cross"], ("attn3_kernel", "attn4_kernel")),
             "gemm_kernel<big tile>": (["gemm128"], ("gemm256_kernel", "Li128ELi64E", "Li128ELi128E")),
             "gemm_kernel<small-M>": (["gemm64"], ("Li64ELi64E", "gemm48_kernel", "gemm96_kernel", "gemms_kernel"))}
     try:
         import glob
         pmc_file = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))[-1]
-        pmc = json.load(open(pmc_file))["kernels"]
+        pmc_doc = json.load(open(pmc_file))
+        pmc = pmc_doc["kernels"]
     except Exception:
-        pmc_file, pmc = None, {}
+        pmc_file, pmc, pmc_doc = None, {}, {}
     want = "DF16b" if args.precision == "bf16" else "DF16_"
 
     def roof(name):
@@ -249,36 +250,19 @@ def main():
             n = sum(x["launches"] for x in rows)
             r["traffic"] = int(sum(x["hbm_bytes_per_launch_corrected"] * x["launches"] for x in rows) / max(1, n))
             r["traffic_unit"] = "bytes/launch (PMC, corrected)"
-            r["traffic_source"] = os.path.relpath(pmc_file, ROOT) + " (separate --pmc passes of this command; not this run)"
+            r["traffic_source"] = (os.path.relpath(pmc_file, ROOT) + " (separate --pmc passes of this command, taken at commit "
+                                   + str(pmc_doc.get("commit", "?")) + "; not this run)")
         return r
 
     roofline = roof("attn3_kernel")
     roofline_gemm = [roof("gemm_kernel<big tile>"), roof("gemm_kernel<small-M>")]
-    # stage split (untimed extra step, single GPU only)
-    if world == 1:
-        ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
-        ts_host = ts.cpu()
-        ev[0].record()
-        x, pos = enc(imgs, ts)
-        ev[1].record()
-        mem, i = None, 0
-        for nb in demo_mem_batches(V):
-            mem, _ = dec(x[i:i + nb].unsqueeze(0), pos[i:i + nb].unsqueeze(0), ts_host[i:i + nb].unsqueeze(0), mem)
-            i += nb
-        ev[2].record()
-        dec(x.unsqueeze(0), pos.unsqueeze(0), ts_host.unsqueeze(0), mem, render=True)
-        ev[3].record()
-        torch.cuda.synchronize(device)
-        stages = {"encode": round(ev[0].elapsed_time(ev[1]), 2), "update": round(ev[1].elapsed_time(ev[2]), 2),
-                  "render": round(ev[2].elapsed_time(ev[3]), 2)}
-        del x, pos, mem
 
-    # postprocess(compute_cam=True) on the scene's 20 rendered pointmaps (HBM-bound:
+    # postprocess(compute_cam=True) on one scene's 20 rendered pointmaps (HBM-bound:
     # 28 B read + 28 B written per pixel; the focal iteration and the registration add no HBM pass)
     cam = None
     if rank == 0 and world == 1:
         from must3r_amd.engine import postprocess
-        pmaps = step()["render"]
+        pmaps = run_scene(enc, dec, imgs, ts)["render"]
         for _ in range(3):
             postprocess(pmaps, compute_cam=True)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -293,6 +277,7 @@ def main():
         cam = {"op": "postprocess(compute_cam=True): activation + Weiszfeld focal + weighted rigid registration",
                "views": V, "ms": round(ms, 4), "bound": "hbm", "achieved": round(nbytes / ms / 1e6, 1), "peak": 8000.0,
                "unit": "GB/s", "frac": round(nbytes / ms / 1e6 / 8000.0, 4), "algorithmic_bytes": nbytes}
+        del pmaps
 
     alt = None
     if not args.no_alt and world == 1:
@@ -302,8 +287,8 @@ def main():
                 continue
             enc.precision = dec.precision = other
             step()
-            dta = timed(step, args.steps)
-            alt.append({"dtype": other, "value": round(views_per_step * args.steps / dta, 2)})
+            dta = timed(step, max(2, args.steps // 2))
+            alt.append({"dtype": other, "value": round(views_per_step * max(2, args.steps // 2) / dta, 2)})
         enc.precision = dec.precision = args.precision
 
     # ---- the other BASELINE.json configurations, measured in the same run (reported beside the headline, never in it)
@@ -311,11 +296,11 @@ def main():
     if not args.no_configs:
         ksteps = max(2, min(10, args.steps))
         if world == 1:
-            # configs[4]: mixed resolution through forward_list
+            # configs[4]: mixed resolution through forward_list, 16-bit attention and the fp8 (MX-scaled Q K^T) attention path
             groups = [S.make_images(4, h, 512, seed=100 + gi)[0].to(device) for gi, h in enumerate(MIXED_H)]
             tokens = [(h // 16) * 32 for h in MIXED_H for _ in range(4)]
             fl = mixed_scene_flops(tokens)
-            mixed = {"config": "configs[4] MUSt3R_512 mixed-resolution scene 512x{384,336,288,256,160} x4 views (forward_list)",
+            mixed = {"config": "configs[4] MUSt3R_512 mixed-resolution scene 512x{384,336,288,256,160} x4 views (forward_list), one scene at a time",
                      "views_per_step": 20, "unit": "views/s", "scene_tflop": round(fl / 1e12, 2), "modes": []}
             ref_mixed = None
             for prec, fp8 in ((args.precision, False), (args.precision, True)):
@@ -324,8 +309,8 @@ def main():
                 fnm = lambda: run_scene_mixed(enc, dec, groups)  # noqa: E731
                 om = fnm()
                 d = timed(fnm, ksteps)
-                mode = {"dtype": prec + (" + fp8 (e4m3) attention operands, e4m3 K|V memory" if fp8 else ""), "value": round(20 * ksteps / d, 2),
-                        "ms_per_step": round(d / ksteps * 1e3, 3), "mfma_frac": round(fl * ksteps / d / 1e12 / 2500.0, 4)}
+                mode = {"dtype": prec + (" + fp8 attention (e4m3 Q / K through the MX-scaled 32x32x64 MFMA; [K e4m3 | V fp16] memory rows)" if fp8 else ""),
+                        "value": round(20 * ksteps / d, 2), "ms_per_step": round(d / ksteps * 1e3, 3), "mfma_frac": round(fl * ksteps / d / 1e12 / 2500.0, 4)}
                 if not fp8:
                     ref_mixed = [r.clone() for r in om["render"]]
                 else:   # the mode's distance from the 16-bit path on the same scene (the 16-bit path's own error vs the oracle: parity_vs_cpu_oracle)
@@ -333,9 +318,8 @@ def main():
                 mixed["modes"].append(mode)
             enc.precision = dec.precision = args.precision
             enc.attention_fp8 = dec.attention_fp8 = False
-            del ref_mixed, om
             configs.append(mixed)
-            del groups
+            del groups, ref_mixed, om
             # configs[3] on one GPU: online streaming memory, every frame updates the memory (engine.run_video)
             F = args.stream_frames
             vimgs, vts = S.make_images(F, H, W, seed=7)
@@ -348,30 +332,50 @@ def main():
                             "value": round(F / d, 2), "unit": "frames/s", "ms_per_step": round(d * 1e3, 2), "frames": F,
                             "keyframes": len(kfs), "final_memory_tokens": int(memv[0][0].shape[1]), "dtype": dtype_label})
             del vimgs, memv
-            # configs[1]: MUSt3R_224, 10 views of 224x224
+            # configs[1]: MUSt3R_224, 10 views of 224x224, one scene at a time and S scenes in flight
             e2, d2, _, _ = build_models(MUST3R_224, args.precision, device)
-            i2, t2 = S.make_images(10, 224, 224, seed=0)
-            i2, t2 = i2.to(device), t2.to(device)
-            fn2 = lambda: run_scene(e2, d2, i2, t2)  # noqa: E731
+            i2 = torch.stack([S.make_images(10, 224, 224, seed=b)[0] for b in range(Sn)]).to(device)
+            t2 = S.make_images(10, 224, 224, seed=0)[1]
+            fl2 = scene_flops(196, 10, 10)
+            fn2 = lambda: run_scene(e2, d2, i2[0], t2)  # noqa: E731
             fn2(); fn2()
             d = timed(fn2, 2 * ksteps)
-            fl2 = scene_flops(196, 10, 10)
-            configs.append({"config": "configs[1] MUSt3R_224 10-view 224x224 scene (encode + update[2,1..] + render + activation)",
-                            "value": round(10 * 2 * ksteps / d, 2), "unit": "views/s", "ms_per_step": round(d / (2 * ksteps) * 1e3, 3),
-                            "scene_tflop": round(fl2 / 1e12, 3), "mfma_frac": round(fl2 * 2 * ksteps / d / 1e12 / 2500.0, 4),
-                            "dtype": dtype_label, "note": "launch-latency-bound at this size (0.94 ms at MFMA peak)"})
-            del e2, d2
+            c1 = {"config": "configs[1] MUSt3R_224 10-view 224x224 scene (encode + update[2,1..] + render + activation)",
+                  "value": round(10 * 2 * ksteps / d, 2), "unit": "views/s", "ms_per_step": round(d / (2 * ksteps) * 1e3, 3),
+                  "scene_tflop": round(fl2 / 1e12, 3), "mfma_frac": round(fl2 * 2 * ksteps / d / 1e12 / 2500.0, 4),
+                  "dtype": dtype_label, "note": "one scene at a time: launch-latency-bound at this size (0.94 ms at MFMA peak)"}
+            if Sn > 1:
+                fn2s = lambda: run_scenes(e2, d2, i2, t2)  # noqa: E731
+                fn2s(); fn2s()
+                d = timed(fn2s, ksteps)
+                c1["scenes_in_flight"] = {"scenes": Sn, "value": round(Sn * 10 * ksteps / d, 2), "ms_per_step": round(d / ksteps * 1e3, 3),
+                                          "mfma_frac": round(Sn * fl2 * ksteps / d / 1e12 / 2500.0, 4)}
+            configs.append(c1)
+            del e2, d2, i2
         else:
-            # strong scaling of the headline scene: the SAME 20 views sharded over the ranks (all of them keyframes)
+            # the view-SHARDED forms of ONE 20-view scene (must3r_amd/parallel.py): RCCL all-gather of the encoded keyframe tokens over xGMI,
+            # sequential update replicated on every rank, encode and render view-sharded
+            gidx = torch.arange(rank * V, (rank + 1) * V)
+            keyframes = (gidx % world == 0)                    # weak form: every rank owns 20 views, 20 keyframes spread over all ranks
+            kf_counts = [int((torch.arange(r * V, (r + 1) * V) % world == 0).sum()) for r in range(world)]   # static: no count exchange
+            wimgs = S.make_images(V, H, W, seed=rank)[0].to(device)
+            fnw = lambda: run_scene_sharded(enc, dec, wimgs, ts, keyframes, comm_dtype=tdt, keyframe_counts=kf_counts)  # noqa: E731
+            fnw()
+            d = timed(fnw, ksteps)
+            configs.append({"config": f"configs[2] view-sharded, WEAK: every rank owns {V} views ({V * world} per scene), memory from {V} keyframes (every "
+                                      f"{world}-th view): all-gather of the keyframe tokens [{backend}], replicated update, sharded encode / render",
+                            "value": round(V * world * ksteps / d, 2), "unit": "views/s", "ms_per_step": round(d / ksteps * 1e3, 3),
+                            "scaling": "weak", "dtype": dtype_label})
+            del wimgs
             simgs, sts = S.make_images(V, H, W, seed=0)
             lo, hi = shard_range(V, rank, world)
-            simgs, sts = simgs[lo:hi].to(device), sts[lo:hi].to(device)
+            simgs, sts = simgs[lo:hi].to(device), sts[lo:hi]
             kf_all = torch.ones(hi - lo, dtype=torch.bool)
             kc_all = [shard_range(V, r, world)[1] - shard_range(V, r, world)[0] for r in range(world)]
             fns = lambda: run_scene_sharded(enc, dec, simgs, sts, kf_all, comm_dtype=tdt, keyframe_counts=kc_all)  # noqa: E731
             fns()
             d = timed(fns, ksteps)
-            configs.append({"config": f"configs[2] STRONG scaling: the same {V}-view 384x512 scene sharded over {world} ranks "
+            configs.append({"config": f"configs[2] view-sharded, STRONG: the same {V}-view 384x512 scene sharded over {world} ranks "
                                       "(encode + render view-sharded, all-gather of the encoded tokens, sequential update replicated)",
                             "value": round(V * ksteps / d, 2), "unit": "views/s", "ms_per_step": round(d / ksteps * 1e3, 3),
                             "scaling": "strong", "dtype": dtype_label})
@@ -379,7 +383,7 @@ def main():
             F = args.stream_frames
             vimgs, vts = S.make_images(F, H, W, seed=7)
             lo, hi = shard_range(F, rank, world)
-            vimgs, vts = vimgs[lo:hi].to(device), vts[lo:hi].to(device)
+            vimgs, vts = vimgs[lo:hi].to(device), vts[lo:hi]
             fc_all = [shard_range(F, r, world)[1] - shard_range(F, r, world)[0] for r in range(world)]
             fnv = lambda: run_video_sharded(enc, dec, vimgs, vts, comm_dtype=tdt, render=False, frame_counts=fc_all)  # noqa: E731
             fnv()
@@ -389,21 +393,10 @@ def main():
                             "value": round(F / d, 2), "unit": "frames/s", "ms_per_step": round(d * 1e3, 2), "frames": F,
                             "scaling": "strong", "dtype": dtype_label})
             del vimgs
-            # REPLICAS: independent scenes per rank -- the metric's whole-node definition ("independent scenes ->
-            # pure replicas"): every rank runs its own S scenes in flight, no data-path collective; whole-node views/s = sum over ranks
-            Sn = max(1, args.scenes)
-            rimgs = torch.stack([S.make_images(V, H, W, seed=5000 + rank * 64 + b)[0].to(device) for b in range(Sn)])
-            fnr = (lambda: run_scenes(enc, dec, rimgs, ts)) if Sn > 1 else (lambda: run_scene(enc, dec, rimgs[0], ts))  # noqa: E731
-            fnr()
-            d = timed(fnr, ksteps)
-            configs.append({"config": f"configs[2] REPLICAS: {world} ranks x {Sn} independent {V}-view 384x512 scenes in flight per rank "
-                                      "(no data-path collective; barrier + max over ranks around the timed region)",
-                            "value": round(world * Sn * V * ksteps / d, 2), "unit": "views/s", "ms_per_step": round(d / ksteps * 1e3, 3),
-                            "scaling": "weak", "dtype": dtype_label})
 
     cpu_baseline, parity = None, None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        # the oracle (a port of the reference's CPU path) on the metric's OWN workload -- the full 20-view scene: encode 20,
+        # the oracle (a port of the reference's CPU path) on the metric's OWN unit of work -- one full 20-view scene: encode 20,
         # memory update [2,1,...,1], render 20 -- in its own process, <= 32 threads, hard time limit.  It is pinned on the
         # committed real-reference fixture in the same pass (oracle_vs_reference_fixture), and the HIP pointmaps of ALL
         # views (update and render) are compared with it.
@@ -424,8 +417,8 @@ def main():
                 ren_o, upd_o = torch.from_numpy(z["render"]), torch.from_numpy(z["update"])
                 cpu_baseline = {"value": round(nv / info["seconds"], 4), "unit": "views/s", "cores": info["threads"],
                                 "host_cores": ncores, "kind": "port",
-                                "sample": f"the {nv}-view 384x512 scene itself: encode {nv} + memory update [2,1,...,1] + render {nv} "
-                                          "(fp32, torch CPU, SDPA attention)",
+                                "sample": f"one {nv}-view 384x512 scene (the unit the step runs S of): encode {nv} + memory update [2,1,...,1] + "
+                                          f"render {nv} (fp32, torch CPU, SDPA attention)",
                                 "seconds": round(info["seconds"], 2), "stages_s": {k: round(v, 2) for k, v in info["stages_s"].items()},
                                 "oracle_vs_reference_fixture": info.get("oracle_vs_reference_fixture")}
                 parity = {"views": nv, "reference": "CPU oracle (fp32) on the same seeded inputs; per-view = max over views of "
@@ -433,6 +426,7 @@ def main():
 
                 def rel(a, b):
                     return float((a - b).abs().max() / b.abs().max())
+
                 def cmp(ren, upd):
                     d = ren - ren_o
                     return {"pointmap_max_abs_err": float(d.abs().max()), "rel_inf": rel(ren, ren_o),
@@ -447,39 +441,42 @@ def main():
                     parity[prec] = cmp(out["render"].cpu(), out["update"].cpu())
                 enc.precision = dec.precision = args.precision
                 enc.attention_fp8 = dec.attention_fp8 = False
-                if simgs_all is not None and nv == V:
-                    # S scenes in flight: scene 0 of the batch IS the headline scene -> all its views against the oracle; every other
-                    # scene against its own single-scene HIP run (tests/test_zz_batch_gpu.py checks every scene against the oracle at
-                    # sizes the oracle finishes in seconds)
-                    outS = run_scenes(enc, dec, simgs_all, ts)
+                if Sn > 1 and nv == V:
+                    # the step itself: scene 0 of the batch IS the oracle's scene -> all its views against the oracle; every other scene
+                    # against its own single-scene HIP run (tests/test_zz_batch_gpu.py checks every scene of a batch against the oracle
+                    # at sizes the oracle finishes in seconds)
+                    outS = step()
                     pf = cmp(outS["render"][0].cpu(), outS["update"][0].cpu())
                     others = []
-                    for b in range(1, simgs_all.shape[0]):
-                        one = run_scene(enc, dec, simgs_all[b], ts)
+                    for b in range(1, Sn):
+                        one = run_scene(enc, dec, scenes[b], ts)
                         others.append(max(rel(outS["render"][b].cpu(), one["render"].cpu()), rel(outS["update"][b].cpu(), one["update"].cpu())))
-                    pf["other_scenes_vs_their_single_scene_run_rel_inf"] = others
-                    parity["scenes_in_flight"] = pf
+                    pf["other_scenes_vs_their_single_scene_run_rel_inf"] = [round(o, 7) for o in others]
+                    parity["step_scene0_of_" + str(Sn)] = pf
                     del outS
             except Exception as e:  # timeout or failure: report, never hang the bench
                 cpu_baseline = {"value": None, "error": repr(e)[:300], "kind": "port"}
 
     if rank == 0:
-        flops = scene_flops(N, V * world, n_key) if world == 1 else None
+        flops = Sn * world * scene_flops(N, V, V)
         line = {
             "metric": "views/sec (whole node) MUSt3R_512 20-view 512x384; pointmap max-abs-err vs ref",
             "value": round(value, 2), "unit": "views/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": dtype_label, "data": "synthetic",
-            "config": {"workload": f"MUSt3R_512 ViT-L/ViT-B random-init, {V}-view memory, {V * world} views/step 384x512 "
-                                   f"(encode+update[2,1..]+render+activation)", "views_per_step": V * world, "keyframes": n_key,
-                       "H": H, "W": W, "parallelism": "single" if world == 1 else f"view-sharded x{world} + all-gather(keyframe tokens) [{backend}]"},
+            "config": {"workload": f"MUSt3R_512 ViT-L/ViT-B random-init, {V}-view 384x512 scenes with a {V}-view memory each (encode {V} + update[2,1..] + "
+                                   f"render {V} + activation); {Sn} independent scene(s) in flight per GPU = {views_per_step} views per step",
+                       "views_per_step": views_per_step, "scenes_in_flight_per_gpu": Sn, "views_per_scene": V, "keyframes_per_scene": V,
+                       "H": H, "W": W, "ms_per_scene": round(dt / args.steps / Sn * 1e3, 3),
+                       "parallelism": "single GPU" if world == 1 else f"{world} replicas (independent scenes per rank, no data-path collective; "
+                                                                       f"barrier + max over ranks) [{backend}]"},
             "roofline": roofline, "roofline_gemm": roofline_gemm, "cpu_baseline": cpu_baseline, "parity_vs_cpu_oracle": parity,
-            "kernel_classes": classes, "stages_ms": stages, "scenes_in_flight": flight, "alt": alt, "configs": configs, "postprocess_cam": cam,
-            "multi_gpu": ("this line is a 1-GPU run; no RCCL run of the N > 1 path has happened in the build environment (one GPU per box): the "
-                          "sharded path is covered by world-size-2 gloo tests and a 2-rank gloo dry run of this script" if world == 1 else
+            "kernel_classes": classes, "stages_ms": stages, "single_scene": single, "alt": alt, "configs": configs, "postprocess_cam": cam,
+            "multi_gpu": ("this line is a 1-GPU run; no RCCL run of the N > 1 paths has happened in the build environment (one GPU per box): the "
+                          "view-sharded path is covered by world-size-2 gloo tests and a 2-rank gloo dry run of this script" if world == 1 else
                           f"{world} ranks, backend {backend}"),
-            "scene_tflop": round(flops / 1e12, 2) if flops else None,
-            "end_to_end_mfma_frac": round(flops * args.steps / dt / 1e12 / PEAK_TFLOPS[args.precision], 4) if flops else None,
+            "scene_tflop": round(scene_flops(N, V, V) / 1e12, 2),
+            "end_to_end_mfma_frac": round(flops * args.steps / dt / 1e12 / PEAK_TFLOPS[args.precision], 4),
         }
         print(json.dumps(line), flush=True)
     if world > 1:

@@ -200,12 +200,6 @@ int must3r_hip_op_gemm_lnfold(int dtype, int epi, const void* A, const void* W2,
                               int lda, int ldc, void* x16_out, float* copy32_out, float* stats_out, const float* ln_stats,
                               const float* ln_s, float ln_eps, float* ln_shift, int ln_shift_init, const int64_t* pos,
                               const float* rope_tab, int rope_cols, int rope_npos, float out_scale, int scale_cols, void* stream);
-/* split-K form of the Linear above (fp16 activations, split fp16 weights W2 = [W_hi | W_lo], no bias): K is cut into `ksplit`
- * equal ranges and range z stores its fp32 partial product into slabs + z * slab_stride (elements, >= M * ldc).  The consumer adds
- * the slabs in a fixed order (must3r_hip_op_layernorm_slabs): deterministic, no atomics.  N % 96 == 0, (K / 64) % ksplit == 0.
- * Used for the K = 3072 Mlp.fc2 of the one-view memory update (croco Mlp; must3r/model/blocks/layers.py:98). */
-int must3r_hip_op_gemm_splitk(int dtype, const void* A, const void* W2, float* slabs, int M, int N, int K, int lda, int ldc,
-                              int ksplit, long long slab_stride, void* stream);
 /* cos/sin table fp32 [npos][16][2] for RoPE2D(freq, F0) with head dim 64 (host pointer) */
 int must3r_hip_rope_table(float freq, float f0, int npos, float* out_host);
 
@@ -220,11 +214,6 @@ int must3r_hip_op_attention(int dtype, const void* Q, const void* K, const void*
                             const int32_t* views_dev, int n_views, int max_nq,
                             int nsplit, void* scratch, int total_q_rows, void* stream);
 
-/* LayerNorm fused with the deferred residual update of a split-K Linear: x += slab_bias + slabs[0] + ... + slabs[nslabs-1] (fixed
- * order, fp32, written back to x), then out16 = LN(x) and optionally copy32 = x.  must3r/model/blocks/layers.py:91-99 (x = x + ...;
- * norm(x)) with the addition moved into the normalisation pass. */
-int must3r_hip_op_layernorm_slabs(int dtype, float* x, const float* slabs, int nslabs, long long slab_stride, const float* slab_bias,
-                                  const float* w, const float* b, void* out16, float* copy32, int M, int C, float eps, void* stream);
 /* y = LN(x (+ add)) * w + b over rows of C; optional outputs may be NULL */
 int must3r_hip_op_layernorm(int dtype, const float* x, const float* add, const float* w, const float* b,
                             void* out16, void* out16_lo, float* out32, float* copy32, int M, int C, float eps,

@@ -27,7 +27,7 @@ EXPORTS = (
     "must3r_hip_postprocess_cam", "must3r_hip_postprocess_cam_scratch_bytes",
     "must3r_hip_nn_query", "must3r_hip_quadrant_ids",
     "must3r_hip_affine", "must3r_hip_row_norm", "must3r_hip_l2_normalize", "must3r_hip_layernorm_act_f32", "must3r_hip_topk_gather", "must3r_hip_weighted_spoc",
-    "must3r_hip_op_gemm_splitk", "must3r_hip_op_layernorm_slabs", "must3r_hip_op_gemm_lnfold",
+    "must3r_hip_op_gemm_lnfold",
 )
 
 
@@ -91,8 +91,6 @@ def load():
     lib.must3r_hip_attention_scratch_bytes.restype = C.c_size_t
     lib.must3r_hip_op_layernorm.argtypes = [i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, fp, vp]
     lib.must3r_hip_op_gemm_lnfold.argtypes = [i32, i32, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, fp, vp, i32, vp, vp, i32, i32, fp, i32, vp]
-    lib.must3r_hip_op_gemm_splitk.argtypes = [i32, vp, vp, vp, i32, i32, i32, i32, i32, i32, C.c_int64, vp]
-    lib.must3r_hip_op_layernorm_slabs.argtypes = [i32, vp, vp, i32, C.c_int64, vp, vp, vp, vp, vp, i32, i32, fp, vp]
     lib.must3r_hip_op_im2col.argtypes = [i32, vp, vp, i32, i32, i32, vp]
     lib.must3r_hip_op_cast.argtypes = [i32, vp, vp, vp, C.c_size_t, vp]
     lib.must3r_hip_debug_tr_probe.argtypes = [vp, vp]

@@ -907,8 +907,7 @@ int launch_attention_phase(DType dt, const AttnArgs& a_in, int phase, hipStream_
     AttnArgs a = a_in;
     if (a.nviews <= 0 || a.max_nq <= 0) return 0;
     {   // split-KV partials of the fp16 paths are written normalised, in fp16 (bf16 keeps fp32)
-        static const bool p16 = !(getenv("M3R_ATTN_PART16") && atoi(getenv("M3R_ATTN_PART16")) == 0);
-        a.part16 = (p16 && dt == DT_F16 && a.nsplit > 1) ? 1 : 0;
+        a.part16 = (dt == DT_F16 && a.nsplit > 1) ? 1 : 0;
     }
     if ((a.ldq % (a.fp8 ? 16 : 8)) || (a.ldk % (a.fp8 ? 16 : 8)) || (a.ldv % (a.fp8 ? 16 : 8)) || (a.ldo % 4)) { *err = "attention: row strides must be 16-byte aligned"; return 1; }
     const int nsplit = a.nsplit > 1 ? a.nsplit : 1;
@@ -947,8 +946,7 @@ int launch_attention_phase(DType dt, const AttnArgs& a_in, int phase, hipStream_
     const int nqb_abs = (a.max_nq + qb_rows - 1) / qb_rows;
     const int npairs = ngrp * nsplit;
     // pairs dealt over the 8 XCDs; per-block round robin when that would leave the XCDs more than 10 % apart (see attn_block_coords)
-    static const bool old_map = getenv("M3R_ATTN_OLDMAP") != nullptr;   // experiments: never use the per-block map
-    const bool per_block = !old_map && ((npairs + 7) / 8) * 8 * 10 > npairs * 11;
+    const bool per_block = ((npairs + 7) / 8) * 8 * 10 > npairs * 11;
     const int nqb = per_block ? -nqb_abs : nqb_abs;
     const int grid = per_block ? npairs * nqb_abs : ((npairs + 7) / 8) * 8 * nqb_abs;
     if (phase == 0) {

@@ -875,8 +875,8 @@ static int launch_48(const GemmArgs& a, hipStream_t s) {
 // per tile.  The fragment reads of tile kt are issued BEFORE the DMA of tile kt+3 so that they are in flight while the
 // DMA instructions issue.  Accumulation order per output (k ascending, hi before lo per 32-deep step) as everywhere else:
 // same bits as the other tile shapes.
-// gridDim.z > 1: split-K.  Block z multiplies K-tiles [z nk, (z+1) nk) and stores its fp32 partial tile, without bias, into
-// slab z (out + z * slab_stride); the consumer (LayerNorm with LnArgs::slabs) adds the slabs in a fixed order.
+// (A split-K form -- gridDim.z K ranges, fp32 partial slabs, the residual update folded into the next LayerNorm -- was built in r02 for
+// the K = 3072 fc2 of the one-view update and removed in r03: in the scene it was a wash, the slabs cost the LayerNorm what the GEMM saved.)
 template <class T, int EPI, int NST, int PF>
 __global__ void __launch_bounds__(576) gemm96_kernel(const GemmArgs p) {
     typedef typename Vec<T>::v8 v8;
@@ -905,14 +905,12 @@ __global__ void __launch_bounds__(576) gemm96_kernel(const GemmArgs p) {
     const int m0 = (bid % nbm) * BM;                    // row-block fastest: the blocks of an XCD share weight panels
     const int n0 = (bid / nbm) * BN;
     const int grp = blockIdx.y;
-    const int nk = p.K / BK / (int)gridDim.z;           // K-tiles of this block
-    const int kt0 = blockIdx.z * nk;
-    const T* __restrict__ A = reinterpret_cast<const T*>(p.A) + (size_t)grp * p.strideA + (size_t)kt0 * BK;
+    const int nk = p.K / BK;
+    const T* __restrict__ A = reinterpret_cast<const T*>(p.A) + (size_t)grp * p.strideA;
     const int wgrp = p.wdiv > 1 ? grp / p.wdiv : grp;
-    const T* __restrict__ W = reinterpret_cast<const T*>(p.W) + (size_t)wgrp * p.strideW + (size_t)kt0 * BK;
+    const T* __restrict__ W = reinterpret_cast<const T*>(p.W) + (size_t)wgrp * p.strideW;
     const float* __restrict__ bias = p.bias ? p.bias + (size_t)wgrp * p.strideB : nullptr;
-    void* outp = p.out_table ? p.out_table[grp] : p.out;
-    if (gridDim.z > 1) outp = reinterpret_cast<float*>(outp) + (size_t)blockIdx.z * p.slab_stride;
+    void* const outp = p.out_table ? p.out_table[grp] : p.out;
 
     // pieces dealt round-robin: piece = t * NW + wave; rows [0,96) = A, [96,192) = W_hi, [192,288) = W_lo
     const int srow = lane >> 3, pch = lane & 7;
@@ -1109,13 +1107,12 @@ static int launch_96pf(const GemmArgs& a, hipStream_t s) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm96_kernel<T, EPI, NST, PF>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm96_kernel<T, EPI, NST, PF>), dim3(nbm * nbn, a.batch > 1 ? a.batch : 1, a.ksplit > 1 ? a.ksplit : 1), dim3(576), lds, s, a);
+    hipLaunchKernelGGL((gemm96_kernel<T, EPI, NST, PF>), dim3(nbm * nbn, a.batch > 1 ? a.batch : 1), dim3(576), lds, s, a);
     return hipGetLastError() == hipSuccess ? 0 : 1;
 }
 template <class T, int EPI>
 static int launch_96(const GemmArgs& a, hipStream_t s) {
-    static const int pf = getenv("M3R_GEMM96_PF") ? atoi(getenv("M3R_GEMM96_PF")) : 1;   // 0: the lock-step loop (experiments)
-    return pf ? launch_96pf<T, EPI, 1>(a, s) : launch_96pf<T, EPI, 0>(a, s);
+    return launch_96pf<T, EPI, 1>(a, s);   // the software-pipelined K loop (the lock-step form measured 3 % slower: profiles/r02_gemm96_ab.txt)
 }
 
 // Tile selection (measured on MI355X, scripts/bench_gemm.py): two resident blocks per CU beat every larger tile that
@@ -1125,14 +1122,7 @@ static int launch_96(const GemmArgs& a, hipStream_t s) {
 // K-tile depth 32 (the BK template parameter; 3-5 resident blocks per CU) was also measured: 605-626 TF/s plain,
 // 397-419 vs 409 TF/s split -- no gain, so only BK = 64 is instantiated.
 // minimum number of big tiles for the big-tile kernel (tunable for experiments: M3R_GEMM_MIN_BIG / _MIN_BIG_SPLIT)
-static long min_big(bool split) {
-    static long v[2] = {-1, -1};
-    if (v[split] < 0) {
-        const char* e = getenv(split ? "M3R_GEMM_MIN_BIG_SPLIT" : "M3R_GEMM_MIN_BIG");
-        v[split] = e ? atol(e) : (split ? 384 : 192);
-    }
-    return v[split];
-}
+static long min_big(bool split) { return split ? 384 : 192; }
 
 // Launches of at most one 64 x 64 tile per CU (M = 768: proj, fc2, projq) run it with 8 waves (4 x 2, wave tile 16 x 32), a
 // 6-8 slot LDS ring (one block per CU: the whole LDS can be prefetch depth) and the fragment reads of tile kt+1 issued
@@ -1157,27 +1147,14 @@ static bool small8(long tiles64) { return tiles64 <= 256; }
 #endif
 
 static bool use_48(const GemmArgs& a, long nb) {
-    static int v = -1;
-    if (v < 0) {
-        const char* e = getenv("M3R_GEMM48");
-        v = e ? atoi(e) : 1;
-    }
-    if (!v || a.N % 48 || a.K % 64 || a.rope_tab != nullptr) return false;
+    if (a.N % 48 || a.K % 64 || a.rope_tab != nullptr) return false;
     const long tiles = (long)((a.M + 47) / 48) * (a.N / 48) * nb;
     return tiles <= 256 && tiles >= 192;
 }
 
 // 96 x 96 tiles: split weights, one round of 224..256 tiles (M = 768: fc1 / feedback fc1 = 256 tiles; measured 17.8 -> 13.3 us);
-// explicit split-K launches (ksplit > 1) always run here.  M3R_GEMM96=0 disables it (experiments).
 static bool use_96(const GemmArgs& a, long nb) {
-    static int v = -1;
-    if (v < 0) {
-        const char* e = getenv("M3R_GEMM96");
-        v = e ? atoi(e) : 1;
-    }
     if (a.N % 96 || a.K % 64) return false;
-    if (a.ksplit > 1) return true;
-    if (!v) return false;
     const long tiles = (long)((a.M + 95) / 96) * (a.N / 96) * nb;
     return tiles <= 256 && tiles >= 224;   // (qkv at M = 768 is 192 tiles = 75 % of the CUs: measured 12.3 us vs 11.2 us on 64 x 64 tiles)
 }
@@ -1196,15 +1173,6 @@ static int fill256(long tiles) {   // percentage of the CU slots of its rounds t
     const long rounds = (tiles + 255) / 256;
     return (int)(tiles * 100 / (rounds * 256));
 }
-static int g256_bn_override() {    // experiments: M3R_G256_BN = 128 / 256 forces the split-mode tile width
-    static int v = -1;
-    if (v < 0) {
-        const char* e = getenv("M3R_G256_BN");
-        v = e ? atoi(e) : 0;
-    }
-    return v;
-}
-
 template <class T, int EPI>
 static int launch_epi(const GemmArgs& a, hipStream_t s, const char** err) {
     const long nb = a.batch > 1 ? a.batch : 1;
@@ -1219,10 +1187,9 @@ static int launch_epi(const GemmArgs& a, hipStream_t s, const char** err) {
             // 192-column tiles (wave tile 128 x 48): N = 768 at M = 15360 is 240 tiles = ONE round at 94 % fill, where 256 columns
             // give 180 tiles (70 %) and 128 columns two rounds.  Not for the RoPE epilogue (its rotate-half pairs need 32-column
             // aligned wave tiles).
-            static const bool no192 = getenv("M3R_G256_NO192") != nullptr;   // experiments: the round-1 selection
-            const bool ok192 = a.N % 192 == 0 && a.K % 32 == 0 && EPI != EPI_QKV_ROPE && !no192;
+            const bool ok192 = a.N % 192 == 0 && a.K % 32 == 0 && EPI != EPI_QKV_ROPE;
             int pick = 0;
-            if (mode == 2) pick = (g256_bn_override() == 128 || !ok256) ? (ok128 ? 128 : 0) : 256;
+            if (mode == 2) pick = !ok256 ? (ok128 ? 128 : 0) : 256;
             else if (mode == 1) {
                 // cost ~ rounds over the 256 CUs x tile width; eligible when its rounds are reasonably full; ties -> wider tile
                 long best = -1;
@@ -1238,7 +1205,7 @@ static int launch_epi(const GemmArgs& a, hipStream_t s, const char** err) {
             // fc1 (exact-erf GELU epilogue, ~17 VALU per output) of the chip-filling batches: two 256 x 128 blocks per CU, so that one block's
             // epilogue runs under the other's K loop.  Measured (r02, M = 15360): N = 3072, K = 768: 157 -> 143 us; N = 4096, K = 1024: 270 -> 265 us;
             // every other epilogue is faster with one block per CU and the deeper ring (qkv 186 vs 199-209 us, fc2 210 vs 228 us).
-            static const bool gelu_occ2 = !(getenv("M3R_G256_GELU_OCC2") && atoi(getenv("M3R_G256_GELU_OCC2")) == 0);
+            constexpr bool gelu_occ2 = true;
             if (a.ln_stats != nullptr) {
                 // LN-fold consumers: the kernels that carry the row-statistics prologue, whatever the tile count
                 if constexpr (EPI == EPI_STORE16_GELU) rc = a.N % 96 == 0 ? launch_96<T, EPI>(a, s) : 1;
@@ -1250,10 +1217,7 @@ static int launch_epi(const GemmArgs& a, hipStream_t s, const char** err) {
             else if (EPI != EPI_QKV_ROPE && EPI != EPI_HEAD && use_48(a, nb)) rc = launch_48<T, EPI == EPI_QKV_ROPE || EPI == EPI_HEAD ? EPI_STORE16 : EPI, 2>(a, s);
             else if (pick == 256) rc = launch_256<T, EPI, 2, 256>(a, s);
             else if (pick == 192) rc = launch_256<T, EPI == EPI_QKV_ROPE ? EPI_STORE16 : EPI, 2, 192>(a, s);
-            else if (pick == 128) {
-                static const bool occ2 = getenv("M3R_G256_OCC2") && atoi(getenv("M3R_G256_OCC2")) != 0;   // experiments: every 128-column launch
-                rc = occ2 ? launch_256<T, EPI, 2, 128, 2>(a, s) : launch_256<T, EPI, 2, 128>(a, s);
-            }
+            else if (pick == 128) rc = launch_256<T, EPI, 2, 128>(a, s);   // (two blocks per CU measured slower for every epilogue but the GELU one)
             else if (tiles >= min_big(true)) rc = launch_cfg<T, 128, 64, 2, 2, EPI, 2, 2>(a, s);
             else if (small8((long)((a.M + 63) / 64) * (a.N / 64) * nb)) rc = launch_cfg<T, 64, 64, SMALL_WGM, 2, EPI, SMALL8_NST_SPLIT, 2, 64, 1>(a, s);
             else rc = launch_cfg<T, 64, 64, 2, 2, EPI, 3, 2>(a, s);
@@ -1315,13 +1279,6 @@ int launch_gemm(DType dt, Epi epi, const GemmArgs& a, hipStream_t s, const char*
     }
     // the consumer of the statistics reads LNF_SLOTS fragments per row (its K = 768): a producer of another width would pair with misaligned rows
     if (a.stats_out && a.N != 16 * LNF_SLOTS) { *err = "gemm: stats_out (LN-fold producer) needs N = 768"; return 1; }
-    if (a.ksplit > 1) {   // split-K: fp32 partial slabs, no bias, 96 x 96 tiles with split weights only
-        if (epi != EPI_F32 || a.bias != nullptr || a.bias2 != nullptr || a.accumulate || a.wsplit != 2 || dt != DT_F16 || a.N % 96 ||
-            (a.K / 64) % a.ksplit || a.slab_stride < (long long)a.M * a.ldc) {
-            *err = "gemm: split-K needs EPI_F32 without bias, split fp16 weights, N % 96 == 0, K-tiles divisible by ksplit, slab_stride >= M*ldc";
-            return 1;
-        }
-    }
     return dt == DT_BF16 ? launch_t<bf16_t>(epi, a, s, err) : launch_t<f16_t>(epi, a, s, err);
 }
 

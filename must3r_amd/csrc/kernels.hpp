@@ -71,10 +71,6 @@ struct GemmArgs {
     //     column-0 blocks leave shift += mean(y) (= the current row mean) for the next producer.  ln_shift_init: the buffer holds nothing yet.
     float* ln_shift;
     int ln_shift_init;
-    // split-K (EPI_F32, bias == nullptr): ksplit > 1 cuts K into ksplit equal ranges, range z stores its fp32 partial product into
-    // out + z * slab_stride (elements).  The consumer adds the slabs in a fixed order (LnArgs::slabs): deterministic, no atomics.
-    int ksplit;
-    long long slab_stride;
 };
 
 // returns 0 on success, non-zero (and sets *err) on an unsupported shape
@@ -149,13 +145,6 @@ struct LnArgs {
     // [rows_per_group, C]) is applied to groups < add_groups only (feedback offset: all layers but the last)
     int rows_per_group;      // 0 = ungrouped
     int add_groups;
-    // deferred residual update of a split-K GEMM (GemmArgs::ksplit): x += slab_bias + slabs[0] + ... + slabs[nslabs-1] (this
-    // order, fp32) before anything else; the updated row is written back to x (xw) -- the fused form of EPI_RESID_F32.
-    const float* slabs;      // [nslabs][slab_stride] fp32, row r at r*C
-    const float* slab_bias;  // [C] or nullptr
-    int nslabs;              // 0 = none
-    long long slab_stride;   // elements
-    float* xw;               // where the updated fp32 row goes (the residual stream itself)
 };
 int launch_layernorm(DType dt, const LnArgs& a, hipStream_t s, const char** err);
 

@@ -33,13 +33,6 @@ __global__ void __launch_bounds__(256) ln_kernel(const LnArgs p) {
         if (c < p.C) {
             if (p.x) v[i] = *reinterpret_cast<const f32x4*>(p.x + (size_t)row * p.C + c);
             else v[i] = __builtin_convertvector(*reinterpret_cast<const v4*>(reinterpret_cast<const T*>(p.x16) + (size_t)row * p.C + c), f32x4);
-            if (p.nslabs > 0) {   // deferred x += bias + sum of split-K partials (fixed order)
-                f32x4 u = *reinterpret_cast<const f32x4*>(p.slabs + (size_t)row * p.C + c);
-                for (int z = 1; z < p.nslabs; ++z) u += *reinterpret_cast<const f32x4*>(p.slabs + (size_t)z * p.slab_stride + (size_t)row * p.C + c);
-                if (p.slab_bias) u += *reinterpret_cast<const f32x4*>(p.slab_bias + c);
-                v[i] += u;
-                *reinterpret_cast<f32x4*>(p.xw + (size_t)row * p.C + c) = v[i];
-            }
             if (addp) v[i] += *reinterpret_cast<const f32x4*>(addp + c);
             if (p.copy32) *reinterpret_cast<f32x4*>(p.copy32 + (size_t)row * p.C + c) = v[i];
             if (p.raw16) *reinterpret_cast<v4*>(reinterpret_cast<T*>(p.raw16) + (size_t)row * p.C + c) = cvt4<T>(v[i]);
@@ -82,7 +75,6 @@ __global__ void __launch_bounds__(256) ln_kernel(const LnArgs p) {
 int launch_layernorm(DType dt, const LnArgs& a, hipStream_t s, const char** err) {
     if (a.M <= 0) return 0;
     if (a.C > 1024 || a.C % 4) { *err = "layernorm: C must be <= 1024 and a multiple of 4"; return 1; }
-    if (a.nslabs > 0 && (!a.slabs || !a.xw || !a.x || a.rows_per_group > 0)) { *err = "layernorm: slabs need fp32 x, xw and ungrouped rows"; return 1; }
     const int grid = (a.M + 3) / 4;
     if (dt == DT_BF16) hipLaunchKernelGGL(ln_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, a);
     else hipLaunchKernelGGL(ln_kernel<f16_t>, dim3(grid), dim3(256), 0, s, a);

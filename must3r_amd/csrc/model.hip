@@ -802,16 +802,6 @@ static int decode_impl(must3r_hip_ctx* c, const must3r_hip_decode_args* A, void*
     need = ws_need(need, lnf ? (size_t)R * D : 0, 2);                 // x16: the residual stream rounded to fp16
     need = ws_need(need, lnf ? (size_t)R * (D / 16) * 2 : 0, 4);      // per row and 16-column fragment (sum, sum of squares)
     need = ws_need(need, lnf ? (size_t)R : 0, 4);                     // per row: the mean the last consumer measured (shift of the next rows)
-    // One-view update calls: the K = 4 D fc2 of every block runs as a split-K GEMM on 96 x 96 tiles (64 tiles x 4 K-ranges = one
-    // block per CU instead of 256 blocks of 48 x 48 over the whole K) that leaves fp32 partial slabs; the residual update
-    // x += b + slabs is done by the LayerNorm that reads x next (norm1 of the next block / norm_dec), in a fixed order.
-    const int KS = 4;
-    // Measured in the scene (r02, same box, interleaved): the GEMM class loses 0.9 ms and the LayerNorm class gains 0.9 ms (the four
-    // 2.4 MB slabs per launch) -- a wash, so the route is OFF by default (M3R_FC2_SPLITK=1 enables it; operator-level tests cover it).
-    static const bool fc2_splitk_on = getenv("M3R_FC2_SPLITK") && atoi(getenv("M3R_FC2_SPLITK")) != 0;
-    const bool fc2_splitk = !lnf && fc2_splitk_on && c->wsplit == 2 && !c->mlp_plain && dt == DT_F16 && !need_pre_kv && !A->feats && D % 96 == 0 &&
-                            (F / 64) % KS == 0 && (long)((R + 95) / 96) * (D / 96) * KS <= 256;
-    need = ws_need(need, fc2_splitk ? (size_t)KS * R * D : 0, 4);   // slabs
     // split-KV cross attention when the launch cannot fill the chip (sequential memory update: one view per call)
     const int max_nk_ca = A->render ? Nm : Nm + (lone_view ? 0 : Rs);
     const int ca_split = attention_pick_split(total_views, Hh, max_n, max_nk_ca);
@@ -849,7 +839,6 @@ static int decode_impl(must3r_hip_ctx* c, const must3r_hip_decode_args* A, void*
     float* lnstats = lnf ? ws_take<float>(c, (size_t)R * (D / 16) * 2) : nullptr;
     float* lnshift = lnf ? ws_take<float>(c, (size_t)R) : nullptr;
     bool lnshift_fresh = true;   // nothing measured yet in this call: the first consumer starts the estimate
-    float* slabs = fc2_splitk ? ws_take<float>(c, (size_t)KS * R * D) : nullptr;
     char* split_ws = split_bytes ? ws_take<char>(c, split_bytes) : nullptr;
     uint16_t* kvs = kvs_rows ? ws_take<uint16_t>(c, kvs_rows * 2 * D) : nullptr;
     uint16_t* ytmp = (mode == MUST3R_MEM_RAW && kvs_rows) ? ws_take<uint16_t>(c, kvs_rows * D) : nullptr;
@@ -990,14 +979,6 @@ static int decode_impl(must3r_hip_ctx* c, const must3r_hip_decode_args* A, void*
         return 0;
     };
 
-    const float* pending_bias = nullptr;   // fc2 bias of the previous block while its split-K slabs await the next LayerNorm of x
-    auto with_slabs = [&](LnArgs la) {
-        if (pending_bias) {
-            la.slabs = slabs; la.nslabs = KS; la.slab_stride = (long long)R * D; la.slab_bias = pending_bias; la.xw = x;
-            pending_bias = nullptr;
-        }
-        return la;
-    };
     for (int l = 0; l < L; ++l) {
         const std::vector<Param*>& LP = c->dec_tab[l];
         if (need_pre_kv) M3R_OK(kv_project(l, x, nullptr, nullptr, s));
@@ -1011,8 +992,8 @@ static int decode_impl(must3r_hip_ctx* c, const must3r_hip_decode_args* A, void*
         // ... and a residual GEMM leaves them for the next consumer (copy: the memorised input of the next block, decoder.py:304-305)
         auto fold_out = [&](GemmArgs& g_, float* copy) { g_.x16_out = x16; g_.stats_out = lnstats; g_.copy32_out = copy; g_.ln_shift = lnshift; };
         if (!lnf)
-            M3R_OK(layernorm_a(c, dt, with_slabs(lnargs(x, nullptr, LP[LF_N1W]->d, LP[LF_N1B]->d, h16, nullptr, nullptr,
-                                                       update ? newmem + (size_t)l * R * D : nullptr, R, D, 1e-6f)), s));
+            M3R_OK(layernorm_a(c, dt, lnargs(x, nullptr, LP[LF_N1W]->d, LP[LF_N1B]->d, h16, nullptr, nullptr,
+                                            update ? newmem + (size_t)l * R * D : nullptr, R, D, 1e-6f), s));
         M3R_OK(w16p(c, *LP[lnf ? LF_QKVLN_W : LF_QKVW], dt, &w, s));
         GemmArgs ga = gargs(h16, w, LP[LF_QKVB]->d, qkv, R, 3 * D, D, D, 3 * D);
         if (lnf) fold_in(ga, LF_QKVLN_S);
@@ -1086,12 +1067,7 @@ static int decode_impl(must3r_hip_ctx* c, const must3r_hip_decode_args* A, void*
             M3R_OK(gemm(c, dt, EPI_STORE16_GELU, g1, s, ws_mlp));
         }
         M3R_OK(wmlp(c, *LP[LF_FC2W], dt, &w, &ws_mlp, s));
-        if (fc2_splitk) {
-            GemmArgs gs = gargs(g16, w, nullptr, slabs, R, D, F, F, D);
-            gs.ksplit = KS; gs.slab_stride = (long long)R * D;
-            M3R_OK(gemm(c, dt, EPI_F32, gs, s));
-            pending_bias = LP[LF_FC2B]->d;
-        } else {
+        {
             GemmArgs g2 = gargs(g16, w, LP[LF_FC2B]->d, x, R, D, F, F, D);
             if (lnf && l + 1 < L) fold_out(g2, newmem + (size_t)(l + 1) * R * D);   // the next block's norm1 input
             M3R_OK(gemm(c, dt, EPI_RESID_F32, g2, s, ws_mlp));
@@ -1108,8 +1084,8 @@ static int decode_impl(must3r_hip_ctx* c, const must3r_hip_decode_args* A, void*
     // --- prediction head in split precision (fp32-equivalent; decoder.py:149-156 runs it in fp32):
         //     y = LN(x); out = y_hi W_hi + y_lo W_hi + y_hi W_lo + b, pixel-shuffled to [n,H,W,7]
         {
-            LnArgs la = with_slabs(lnargs(x, nullptr, p32(c, "decoder.norm_dec.weight"), p32(c, "decoder.norm_dec.bias"), hcat, hcat + D,
-                                          A->feats ? A->feats + (size_t)(L - 1) * R * D : nullptr, nullptr, R, D, 1e-6f));
+            LnArgs la = lnargs(x, nullptr, p32(c, "decoder.norm_dec.weight"), p32(c, "decoder.norm_dec.bias"), hcat, hcat + D,
+                               A->feats ? A->feats + (size_t)(L - 1) * R * D : nullptr, nullptr, R, D, 1e-6f);
             la.out16_dup = hcat + 2 * D;
             la.ld16 = 3 * D;
             M3R_OK(layernorm_a(c, dt, la, hs_));
@@ -1397,17 +1373,6 @@ extern "C" int must3r_hip_op_gemm_lnfold(int dtype, int epi, const void* A, cons
     return 0;
 }
 
-extern "C" int must3r_hip_op_gemm_splitk(int dtype, const void* A, const void* W2, float* slabs, int M, int N, int K, int lda, int ldc,
-                                         int ksplit, long long slab_stride, void* stream) {
-    if (dtype != MUST3R_F16) return fail("op_gemm_splitk: fp16 operands with split weights only");
-    if (ksplit < 2 || ksplit > 16) return fail("op_gemm_splitk: ksplit must be 2..16");
-    GemmArgs a = gargs(A, W2, nullptr, slabs, M, N, K, lda, ldc);
-    a.wsplit = 2; a.ksplit = ksplit; a.slab_stride = slab_stride;
-    const char* err = "";
-    if (launch_gemm(DT_F16, EPI_F32, a, reinterpret_cast<hipStream_t>(stream), &err)) return fail("%s", err);
-    return 0;
-}
-
 extern "C" size_t must3r_hip_attention_scratch_bytes(int nsplit, int total_q_rows, int heads) {
     return attention_split_scratch_bytes(nsplit, total_q_rows, heads);
 }
@@ -1438,18 +1403,6 @@ extern "C" int must3r_hip_op_layernorm(int dtype, const float* x, const float* a
                                        void* out16_lo, float* out32, float* copy32, int M, int C, float eps, void* stream) {
     if (dtype != MUST3R_BF16 && dtype != MUST3R_F16) return fail("op_layernorm: bad dtype");
     LnArgs a = lnargs(x, add, w, b, out16, out16_lo, out32, copy32, M, C, eps);
-    const char* err = "";
-    if (launch_layernorm((DType)dtype, a, reinterpret_cast<hipStream_t>(stream), &err)) return fail("%s", err);
-    return 0;
-}
-
-extern "C" int must3r_hip_op_layernorm_slabs(int dtype, float* x, const float* slabs, int nslabs, long long slab_stride,
-                                             const float* slab_bias, const float* w, const float* b, void* out16, float* copy32, int M,
-                                             int C, float eps, void* stream) {
-    if (dtype != MUST3R_BF16 && dtype != MUST3R_F16) return fail("op_layernorm_slabs: bad dtype");
-    if (nslabs < 1 || !slabs || !x) return fail("op_layernorm_slabs: needs x and at least one slab");
-    LnArgs a = lnargs(x, nullptr, w, b, out16, nullptr, nullptr, copy32, M, C, eps);
-    a.slabs = slabs; a.nslabs = nslabs; a.slab_stride = slab_stride; a.slab_bias = slab_bias; a.xw = x;
     const char* err = "";
     if (launch_layernorm((DType)dtype, a, reinterpret_cast<hipStream_t>(stream), &err)) return fail("%s", err);
     return 0;

@@ -67,25 +67,12 @@ def demo_mem_batches(n_views, init_num_images=2, batch_num_views=1):
     return out
 
 
-_side_streams = {}
-
-
-def _side_stream(device):
-    key = (device.type, device.index)
-    if key not in _side_streams:
-        _side_streams[key] = torch.cuda.Stream(device=device)
-    return _side_streams[key]
-
-
 @torch.no_grad()
-def run_scene(encoder, decoder, imgs, true_shape, mem_batches=None, render_bs=None, activate=True, encoder_tokens=None,
-              overlap=False, enc_chunk=6):
+def run_scene(encoder, decoder, imgs, true_shape, mem_batches=None, render_bs=None, activate=True, encoder_tokens=None):
     """One scene with a single aspect ratio.  imgs fp32 [V,3,H,W] (cuda), true_shape int64 [V,2].
 
-    ``overlap`` (off by default): only the views of the first memory batch are encoded up front, the rest in chunks on a
-    second HIP stream *while* the memory update of the earlier views runs, each decoder call waiting on the event of the
-    chunk that holds its view.  Worth +3 % with the 4-wave GEMM kernels; the 8-wave one-block-per-CU GEMM the batched
-    encoder now uses leaves no room for co-resident kernels, and chunking costs it its fill: no gain.
+    (Rounds 1-2 carried an ``overlap`` option -- the encoder of the later views on a second stream under the memory update of the
+    earlier ones: +3 % with the 4-wave GEMMs, nothing with the 8-wave one-block-per-CU GEMM; removed in r03)
 
     Returns dict(update=[V,H,W,7], render=[V,H,W,7], mem=mem_tuple, x, pos[, pts3d, pts3d_local, conf of the render])."""
     V = imgs.shape[0]
@@ -95,61 +82,16 @@ def run_scene(encoder, decoder, imgs, true_shape, mem_batches=None, render_bs=No
     # stops the host from queueing ahead of the GPU (the reference does the same: head.py:33 `.cpu().tolist()`); one copy
     # per scene instead.
     true_shape = true_shape.cpu() if true_shape.is_cuda else true_shape
-    ready = None   # per view: event to wait for before the decoder may read its tokens
-    if encoder_tokens is not None:
-        x, pos = encoder_tokens
-        xs = poss = None
-    elif overlap and imgs.is_cuda and V > mem_batches[0] + 2:
-        dev = imgs.device
-        main = torch.cuda.current_stream(dev)
-        side = _side_stream(dev)
-        n0 = mem_batches[0]
-        x0, p0 = encoder(imgs[:n0], true_shape[:n0])
-        xs, poss, ready = [x0], [p0], [None] * n0
-        side.wait_stream(main)              # images resident + first encode done (one encoder forward in flight at a time)
-        with torch.cuda.stream(side):
-            for a in range(n0, V, enc_chunk):
-                b = min(V, a + enc_chunk)
-                xc, pc = encoder(imgs[a:b], true_shape[a:b])
-                ev = torch.cuda.Event()
-                ev.record(side)
-                xs.append(xc)
-                poss.append(pc)
-                ready += [ev] * (b - a)
-        x = pos = None
-    else:
-        x, pos = encoder(imgs, true_shape)
-        xs = poss = None
-
-    def tokens(a, b):
-        if xs is None:
-            return x[a:b], pos[a:b]
-        # views a..b-1 live in one chunk by construction of the schedule below, or are gathered
-        bounds, o = [], 0
-        for t in xs:
-            bounds.append((o, o + t.shape[0]))
-            o += t.shape[0]
-        for (lo, hi), tx, tp in zip(bounds, xs, poss):
-            if a >= lo and b <= hi:
-                return tx[a - lo:b - lo], tp[a - lo:b - lo]
-        return torch.cat(xs, 0)[a:b], torch.cat(poss, 0)[a:b]
-
+    x, pos = encoder_tokens if encoder_tokens is not None else encoder(imgs, true_shape)
     mem = None
     upd = []
     i = 0
     if imgs.is_cuda and hasattr(decoder, "reserve_memory_tokens"):
         decoder.reserve_memory_tokens = sum(mem_batches) * ((imgs.shape[-2] // 16) * (imgs.shape[-1] // 16))   # final memory size
     for nb in mem_batches:
-        if ready is not None:
-            for ev in {ready[j] for j in range(i, i + nb)} - {None}:
-                torch.cuda.current_stream(imgs.device).wait_event(ev)
-        xi, pi = tokens(i, i + nb)
-        mem, pm = decoder(xi.unsqueeze(0), pi.unsqueeze(0), true_shape[i:i + nb].unsqueeze(0), mem)
+        mem, pm = decoder(x[i:i + nb].unsqueeze(0), pos[i:i + nb].unsqueeze(0), true_shape[i:i + nb].unsqueeze(0), mem)
         upd.append(pm[0])
         i += nb
-    if xs is not None:
-        torch.cuda.current_stream(imgs.device).wait_stream(side)
-        x, pos = torch.cat(xs, 0), torch.cat(poss, 0)
     ren = []
     bs = render_bs or V
     for v0 in range(0, V, bs):

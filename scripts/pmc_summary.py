@@ -6,6 +6,7 @@ reports exactly half the bytes of a wide coalesced streaming read (16 B/lane glo
 so it is doubled; WRITE_SIZE is taken as is (uncalibrated).  bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024."""
 import json
 import re
+import subprocess
 import sys
 
 out = sys.argv[1] if len(sys.argv) > 1 else "profiles/r01_pmc_traffic.json"
@@ -20,8 +21,14 @@ for k in sorted(set(f) | set(w)):
     short = re.sub(r"^_ZN3m3r\d+", "", k)
     res[k] = {"launches": fk.get("launches", wk.get("launches")), "FETCH_SIZE_KiB_mean": round(fetch, 1),
               "WRITE_SIZE_KiB_mean": round(write, 1), "hbm_bytes_per_launch_corrected": int((2 * fetch + write) * 1024)}
+try:   # the commit the counters were taken at (gpurun ships no .git: scripts/gpu_pmc.sh passes it through M3R_COMMIT)
+    import os
+    commit = os.environ.get("M3R_COMMIT") or subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip() or "?"
+except Exception:
+    commit = "?"
 json.dump({"command": "rocprofv3 --kernel-trace --pmc <FETCH_SIZE|WRITE_SIZE> -- python bench.py --gpus 1 --steps 1 --warmup 1 "
-                      "--no-cpu-baseline --no-alt --no-overlap  (two separate passes)",
+                      "--no-cpu-baseline --no-alt --no-configs  (two separate passes)",
+           "commit": commit,
            "correction": "bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950 FETCH_SIZE halves wide coalesced reads; WRITE_SIZE uncalibrated)",
            "kernels": res}, open(out, "w"), indent=1)
 for k, v in sorted(res.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch_corrected"] * (kv[1]["launches"] or 0))[:8]:

@@ -168,46 +168,6 @@ def test_gemm96_tiles_same_bits_as_small_tiles(lib, shape):
     record("gemm96", shape=shape, err_f32=rel_inf(full, ref))
 
 
-def test_gemm_splitk_slabs_and_fused_layernorm(lib):
-    """fc2 of the one-view update: K = 3072 cut into 4 ranges on 96 x 96 tiles, fp32 partial slabs, and the LayerNorm that follows
-    does x += (s0 + s1 + s2 + s3) + b before normalising (must3r_hip_op_layernorm_slabs).  Checked against fp64, against the
-    unsplit residual GEMM + LayerNorm (close, not bitwise: different summation order) and for run-to-run determinism."""
-    M, N, K, KS = 768, 768, 3072, 4
-    g = torch.Generator(device="cuda").manual_seed(3)
-    A = torch.randn((M, K), device="cuda", generator=g).half()
-    Wf = torch.randn((N, K), device="cuda", generator=g) / math.sqrt(K)
-    W2 = _split_w(Wf)
-    bias = torch.randn((N,), device="cuda", generator=g)
-    x0 = torch.randn((M, N), device="cuda", generator=g)
-    lw, lb = torch.randn((N,), device="cuda", generator=g), torch.randn((N,), device="cuda", generator=g)
-    L = lib.load()
-    outs = []
-    for _ in range(2):
-        slabs = torch.full((KS, M, N), float("nan"), device="cuda")
-        lib.check(L.must3r_hip_op_gemm_splitk(1, P(A), P(W2), P(slabs), M, N, K, K, N, KS, M * N, stream()))
-        x = x0.clone()
-        h = torch.empty((M, N), device="cuda", dtype=torch.float16)
-        cp = torch.empty((M, N), device="cuda")
-        lib.check(L.must3r_hip_op_layernorm_slabs(1, P(x), P(slabs), KS, M * N, P(bias), P(lw), P(lb), P(h), P(cp), M, N, 1e-6, stream()))
-        torch.cuda.synchronize()
-        outs.append((x, h, cp, slabs))
-    x, h, cp, slabs = outs[0]
-    assert all(torch.equal(a, b) for a, b in zip(outs[0], outs[1])), "split-K path is not deterministic"
-    for z in range(KS):   # each slab is the product over its own K range
-        kz = slice(z * K // KS, (z + 1) * K // KS)
-        assert torch.allclose(slabs[z].double(), A[:, kz].double() @ Wf[:, kz].double().t(), rtol=1e-5, atol=1e-4)
-    want = x0.double() + A.double() @ Wf.double().t() + bias.double()
-    assert torch.equal(x, cp) and torch.allclose(x.double(), want, rtol=1e-5, atol=1e-4), rel_inf(x, want)
-    ln = torch.nn.functional.layer_norm(want, (N,), lw.double(), lb.double(), 1e-6)
-    assert torch.allclose(h.double(), ln, rtol=2 * 2.0 ** -11, atol=4 * 2.0 ** -11), rel_inf(h, ln)
-    # the unsplit route
-    x2 = x0.clone()
-    lib.check(L.must3r_hip_op_gemm(1, lib.EPI_RESID_F32, P(A), P(W2), P(bias), P(x2), M, N, K, K, N, None, None, 0, 0, None, 0, 0,
-                                   0, 0, 0, 0, 2, stream()))
-    torch.cuda.synchronize()
-    record("gemm_splitk", err=rel_inf(x, want), vs_unsplit=rel_inf(x, x2))
-    assert rel_inf(x, x2) < 1e-5
-
 
 @pytest.mark.parametrize("dt", ["bf16", "fp16"])
 @pytest.mark.parametrize("geom", [(2, 14, 14, 128), (1, 24, 32, 768), (3, 3, 4, 1024), (4, 24, 32, 256)])
