@@ -114,6 +114,11 @@ def split(V=3):
         "all but MLPs and feedback MLP": lambda n: ".mlp." not in n and "feedback" not in n,
         "all but fc1 (enc+dec)": lambda n: "fc1" not in n,
         "all but fc2 (enc+dec)": lambda n: "fc2" not in n,
+        "plain: enc fc2 + dec MLP": lambda n: not ((n.startswith("e.") and "fc2" in n) or (n.startswith("d.") and (".mlp." in n or "feedback" in n))),
+        "plain: enc fc1 + dec MLP": lambda n: not ((n.startswith("e.") and "fc1" in n) or (n.startswith("d.") and (".mlp." in n or "feedback" in n))),
+        "plain: enc MLP + dec fc2": lambda n: not ((n.startswith("e.") and ".mlp." in n) or (n.startswith("d.") and "fc2" in n)),
+        "plain: enc MLP of blocks 12-23 + dec MLP": lambda n: not ((n.startswith("e.") and ".mlp." in n and int(n.split(".")[2]) >= 12) or (n.startswith("d.") and (".mlp." in n or "feedback" in n))),
+        "plain: enc MLP of blocks 0-11 + dec MLP": lambda n: not ((n.startswith("e.") and ".mlp." in n and int(n.split(".")[2]) < 12) or (n.startswith("d.") and (".mlp." in n or "feedback" in n))),
     }
     if len(sys.argv) > 3:
         sets = {k: v for k, v in sets.items() if any(o in k for o in sys.argv[3:])}
