@@ -58,7 +58,7 @@ class MUSt3R(HipModule):
     def __init__(self, img_size=(224, 224), enc_embed_dim=1024, patch_size=16, embed_dim=768, output_dim=1792,
                  depth=12, num_heads=12, mlp_ratio=4, norm_layer=partial(nn.LayerNorm, eps=1e-6), act_layer=nn.GELU,
                  pos_embed="RoPE100", landscape_only=True, head="Linear", feedback_type=None, memory_mode="norm_y",
-                 pointmaps_activation=ActivationType.NORM_EXP, block_type=None, precision="fp16w2", **kv):
+                 pointmaps_activation=ActivationType.NORM_EXP, block_type=None, precision="fp16wa", **kv):
         super().__init__()
         if isinstance(img_size, int):
             img_size = (img_size, img_size)

@@ -8,7 +8,8 @@ LN -> fc1 GEMM with fused GELU -> fc2 GEMM with fused residual], final LN.
 
 Precision: the reference disables autocast here (encoder.py:46) and runs fp32 (TF32 on NVIDIA,
 demo.py:12).  gfx950 has no TF32; this module feeds the MFMAs with ``precision`` operands
-('fp16w2' default: fp16 with split weights; 'fp16': 10-bit mantissa like TF32; 'bf16') and keeps the residual stream, LayerNorm, softmax
+('fp16wa' default: fp16, split weights in the attention-side Linears, plain in the Mlp Linears; 'fp16w2': every weight split;
+'fp16': 10-bit mantissa like TF32; 'bf16') and keeps the residual stream, LayerNorm, softmax
 and accumulators in fp32.  Autocast state is ignored, as in the reference.
 """
 from functools import partial
@@ -28,7 +29,7 @@ class Dust3rEncoder(HipModule):
 
     def __init__(self, img_size=(224, 224), patch_size=16, embed_dim=1024, depth=24, num_heads=16, mlp_ratio=4,
                  norm_layer=partial(nn.LayerNorm, eps=1e-6), patch_embed="PatchEmbedDust3R", pos_embed="RoPE100",
-                 precision="fp16w2", **kv):
+                 precision="fp16wa", **kv):
         super().__init__()
         if isinstance(img_size, int):
             img_size = (img_size, img_size)
