@@ -56,6 +56,7 @@ template <class T> __device__ __forceinline__ typename Vec<T>::v8 cvt8(f32x8 v) 
 // s_waitcnt vmcnt(0) before it), which would drain the next tile's prefetch in the middle of the current tile; the
 // asm form is invisible to that bookkeeping.  The reads only touch the tile buffer whose DMA was already waited for.
 typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 template <class T>
 __device__ __forceinline__ void lds_read_tr4_x8(const T* p0, const T* p1, const T* p2, const T* p3, const T* p4, const T* p5,
                                                 const T* p6, const T* p7, typename Vec<T>::v4 (&out)[8]) {

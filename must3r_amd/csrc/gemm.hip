@@ -31,9 +31,20 @@ __device__ unsigned long long g_gemm256_trace[2][64 * 8];   // scripts/probes/ge
 // Shared by every tile geometry so that all of them round identically (built with -ffp-contract=off).
 // The small-M kernels load the bias fragments (and, for the residual epilogue, the old x values) BEFORE their K loop: after the loop
 // they would be one or two dependent L2 round trips (~0.5-1 us) at the end of a 7-14 us launch.
+// out / out_table[g] are global memory; telling the compiler so keeps the epilogue's accesses global_* instead of flat_* (a pointer read from
+// out_table has no address space the compiler can see)
+template <class V> __device__ __forceinline__ void st_global(void* ptr, const V v) {
+    *reinterpret_cast<__attribute__((address_space(1))) V*>((unsigned long long)ptr) = v;
+}
+template <class V> __device__ __forceinline__ V ld_global(const void* ptr) {
+    return *reinterpret_cast<const __attribute__((address_space(1))) V*>((unsigned long long)ptr);
+}
 template <int NF> struct EpiPre {
     f32x4 b[NF];   // bias columns of this lane (zero when the epilogue adds none)
     f32x4 x[NF];   // old residual values (EPI_RESID_F32 only)
+};
+template <int NF> struct RopePre {
+    f32x4 t0[NF / 2 > 0 ? NF / 2 : 1], t1[NF / 2 > 0 ? NF / 2 : 1];   // the (cos, sin) table entries of the row's position, per 32-column half
 };
 template <class T, int EPI, int NF>
 __device__ __forceinline__ void epilogue_prefetch(const GemmArgs& p, void* const outp, const float* __restrict__ bias, const int m,
@@ -116,17 +127,21 @@ __device__ __forceinline__ void ln_fold_rows(const GemmArgs& p, const int m0, fl
 }
 template <int BM, int NT> constexpr size_t ln_fold_lds_bytes() { return (size_t)(BM * (NT / BM) * 2 + BM * 2) * sizeof(float); }
 
-template <class T, int EPI, int NF>
+// LN = false: the LN-fold paths (consumer: ln_stats / ln_s; producer: x16_out / copy32_out / stats_out / ln_shift) are compiled out -- the
+// chip-filling tile shapes never run them (launch_epi routes such calls to the small-tile kernels), and a load under a branch in front of
+// every row fragment's stores makes the compiler wait for vmcnt(0) at the join, i.e. for the previous fragment's stores.
+template <class T, int EPI, int NF, bool LN = true>
 __device__ __forceinline__ void epilogue_row(const GemmArgs& p, void* const outp, const float* __restrict__ bias, const int m,
                                              const int nw0, const int fg, f32x4 (&v)[NF], const EpiPre<NF>* pre = nullptr,
-                                             const float ln_mu = 0.f, const float ln_rstd = 0.f) {
+                                             const float ln_mu = 0.f, const float ln_rstd = 0.f, const f32x4* b2pre = nullptr,
+                                             const RopePre<NF>* rp = nullptr) {
     typedef typename Vec<T>::v4 v4;
     const int nb = nw0 + fg * 4;
     float ln_shift = 0.f;
-    if constexpr (EPI == EPI_RESID_F32 || EPI == EPI_F32) {
+    if constexpr (LN && (EPI == EPI_RESID_F32 || EPI == EPI_F32)) {
         if (p.ln_shift != nullptr && (p.x16_out != nullptr || p.stats_out != nullptr)) ln_shift = p.ln_shift[m];
     }
-    if constexpr (EPI == EPI_STORE16 || EPI == EPI_STORE16_GELU || EPI == EPI_QKV_ROPE) {
+    if constexpr (LN && (EPI == EPI_STORE16 || EPI == EPI_STORE16_GELU || EPI == EPI_QKV_ROPE)) {
         if (p.ln_stats != nullptr) {   // LN fold: acc = sum_k x_k W'_nk  ->  rstd (acc - mu s_n); c_n comes in as the bias
 #pragma unroll
             for (int j = 0; j < NF; ++j) {
@@ -149,16 +164,16 @@ __device__ __forceinline__ void epilogue_row(const GemmArgs& p, void* const outp
         // wave tile is 32- or 64-column aligned inside a 64-wide head: fragments (2q, 2q+1) are the
         // rotate-half pair of one 32-wide half; even halves rotate by y, odd halves by x.
         if (nw0 < p.rope_cols) {
-            const long long py = p.pos[(size_t)m * 2 + 0];
-            const long long px = p.pos[(size_t)m * 2 + 1];
+            const long long py = rp ? 0 : p.pos[(size_t)m * 2 + 0];
+            const long long px = rp ? 0 : p.pos[(size_t)m * 2 + 1];
 #pragma unroll
             for (int q = 0; q < NF / 2; ++q) {
                 const int nh = nw0 + q * 32;
                 int pp = (int)(((nh >> 5) & 1) ? px : py);
                 pp = pp < 0 ? 0 : (pp >= p.rope_npos ? p.rope_npos - 1 : pp);
                 const float* tb = p.rope_tab + ((size_t)pp * 16 + fg * 4) * 2;
-                const f32x4 t0 = *reinterpret_cast<const f32x4*>(tb);      // cos0 sin0 cos1 sin1
-                const f32x4 t1 = *reinterpret_cast<const f32x4*>(tb + 4);  // cos2 sin2 cos3 sin3
+                const f32x4 t0 = rp ? rp->t0[q] : *reinterpret_cast<const f32x4*>(tb);      // cos0 sin0 cos1 sin1
+                const f32x4 t1 = rp ? rp->t1[q] : *reinterpret_cast<const f32x4*>(tb + 4);  // cos2 sin2 cos3 sin3
                 const float cs[4] = {t0[0], t0[2], t1[0], t1[2]};
                 const float sn[4] = {t0[1], t0[3], t1[1], t1[3]};
                 const f32x4 x0 = v[2 * q], x1 = v[2 * q + 1];
@@ -176,6 +191,57 @@ __device__ __forceinline__ void epilogue_row(const GemmArgs& p, void* const outp
             for (int j = 0; j < NF; ++j) v[j] *= p.out_scale;
         }
     }
+    if constexpr ((EPI == EPI_STORE16 || EPI == EPI_QKV_ROPE || EPI == EPI_STORE16_GELU) && NF % 2 == 0) {
+        // 16-bit outputs: a lane's fragment is 4 columns = 8 bytes, the four lanes of a row cover 32 contiguous bytes per store -- a quarter
+        // of a cache line, and the memory system takes such stores at ~2 TB/s (a 256 x 256 x 64 GEMM launch of 94 MB: 56 us against 11 us
+        // without its stores, profiles/r03_gemm256k_fixed.txt).  Two cross-lane swaps per dword rotate (fragment parity j0, lane bit 5, lane bit 4)
+        // so that a lane holds 8 consecutive columns of fragments (2q, 2q+1) and a row's four lanes 64 contiguous bytes: half as many stores,
+        // 16 bytes per lane.  Values are untouched (the same bits land in the same places).
+        const int lane = (int)__lane_id();
+        u32x4 o[NF / 2];
+#pragma unroll
+        for (int q = 0; q < NF / 2; ++q) {
+            f32x4 g0 = v[2 * q], g1 = v[2 * q + 1];
+            if constexpr (EPI == EPI_STORE16_GELU) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { g0[r] = gelu_erf(g0[r]); g1[r] = gelu_erf(g1[r]); }
+            }
+            const v4 h0 = cvt4_sat<T>(g0), h1 = cvt4_sat<T>(g1);
+            unsigned a[2], b[2];
+            __builtin_memcpy(a, &h0, 8);
+            __builtin_memcpy(b, &h1, 8);
+#pragma unroll
+            for (int d = 0; d < 2; ++d) {
+                auto s1 = __builtin_amdgcn_permlane32_swap(a[d], b[d], false, false);   // fragment parity <-> lane bit 5
+                auto s2 = __builtin_amdgcn_permlane16_swap(s1[0], s1[1], false, false); // (old lane bit 5) <-> lane bit 4
+                o[q][d] = s2[0];
+                o[q][2 + d] = s2[1];
+            }
+        }
+        const int nq = nw0 + ((lane >> 5) & 1) * 16 + ((lane >> 4) & 1) * 8;
+        bool done = false;
+        if constexpr (NF == 4) {
+            // 64-column wave tiles: one more exchange (32-column half q <-> lane bit 3, a DPP row rotation by 8 under a bank mask) gives
+            // every store 8 rows x 128 contiguous bytes -- whole cache lines.  Needs all 16 rows of the fragment (the lanes trade rows).
+            const int row0 = m - (lane & 15);
+            if (row0 + 15 < p.M) {
+                u32x4 x, y;
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    x[d] = (unsigned)__builtin_amdgcn_update_dpp((int)o[0][d], (int)o[1][d], 0x128, 0xf, 0xc, false);   // lanes 8-15: half 1 of rows 0-7
+                    y[d] = (unsigned)__builtin_amdgcn_update_dpp((int)o[1][d], (int)o[0][d], 0x128, 0xf, 0x3, false);   // lanes 0-7: half 0 of rows 8-15
+                }
+                T* const dst = reinterpret_cast<T*>(outp) + (size_t)(row0 + (lane & 7)) * p.ldc + nq + ((lane >> 3) & 1) * 32;
+                st_global<u32x4>(dst, x);
+                st_global<u32x4>(dst + (size_t)8 * p.ldc, y);
+                done = true;
+            }
+        }
+        if (!done) {
+#pragma unroll
+            for (int q = 0; q < NF / 2; ++q) st_global<u32x4>(reinterpret_cast<T*>(outp) + (size_t)m * p.ldc + nq + q * 32, o[q]);
+        }
+    } else
 #pragma unroll
     for (int j = 0; j < NF; ++j) {
         const int n = nb + j * 16;
@@ -188,19 +254,19 @@ __device__ __forceinline__ void epilogue_row(const GemmArgs& p, void* const outp
             *reinterpret_cast<v4*>(reinterpret_cast<T*>(outp) + (size_t)m * p.ldc + n) = cvt4_sat<T>(g);
         } else if constexpr (EPI == EPI_RESID_F32) {
             f32x4* o = reinterpret_cast<f32x4*>(reinterpret_cast<float*>(outp) + (size_t)m * p.ldc + n);
-            const f32x4 xn = (pre != nullptr ? pre->x[j] : *o) + v[j];
-            *o = xn;
-            ln_fold_emit<T>(p, m, n, fg, xn, ln_shift);
+            const f32x4 xn = (pre != nullptr ? pre->x[j] : ld_global<f32x4>(o)) + v[j];
+            st_global<f32x4>(o, xn);
+            if constexpr (LN) ln_fold_emit<T>(p, m, n, fg, xn, ln_shift);
         } else if constexpr (EPI == EPI_F32) {
             f32x4* o = reinterpret_cast<f32x4*>(reinterpret_cast<float*>(outp) + (size_t)m * p.ldc + n);
             f32x4 x = v[j];
             if (p.accumulate) {
-                x += *o;
+                x += pre != nullptr && b2pre != nullptr ? pre->x[j] : ld_global<f32x4>(o);
             } else if (p.bias2 != nullptr && (p.row_period2 > 0 ? m % p.row_period2 : m) >= p.row_start2) {
-                x += *reinterpret_cast<const f32x4*>(p.bias2 + n);
+                x += b2pre != nullptr ? b2pre[j] : *reinterpret_cast<const f32x4*>(p.bias2 + n);
             }
-            *o = x;
-            ln_fold_emit<T>(p, m, n, fg, x, ln_shift);
+            st_global<f32x4>(o, x);
+            if constexpr (LN) ln_fold_emit<T>(p, m, n, fg, x, ln_shift);
         } else if constexpr (EPI == EPI_HEAD) {
             // permuted feature n = (i*16 + jj)*7 + c ; token t of view vv at grid (gy, gx)
             const int vv = m / p.ntok, t = m - vv * p.ntok;
@@ -214,6 +280,89 @@ __device__ __forceinline__ void epilogue_row(const GemmArgs& p, void* const outp
         }
     }
 }
+
+// The whole wave tile (MF row fragments).  vmcnt counts loads AND stores in order, so a load issued behind a store cannot be waited for
+// without waiting for the store's acknowledgement (~1 us under load): an epilogue that loads its bias / old residual / RoPE entries per row
+// fragment pays one such round trip per fragment -- 8 per 128-row wave tile, ~10 us of a 256 x 256 tile whose K loop (K = 1024) takes 16 us
+// (profiles/r03_gemm256k_fixed.txt: a K = 64 launch 56 us with its epilogue, 11 us without).  Here everything that depends only on the column
+// (bias, bias2) is loaded once, and the row-dependent operands (old fp32 rows, positions -> table entries) BI fragments at a time, all in front
+// of that batch's stores.  Values and rounding are those of epilogue_row.
+template <class T, int EPI, int NF, int MF, int BI, bool LN, class LnF>
+__device__ __forceinline__ void epilogue_tile(const GemmArgs& p, void* const outp, const float* __restrict__ bias, const int m_first,
+                                              const int nw0, const int fg, f32x4 (&acc)[MF][NF], LnF lnf) {
+    static_assert(MF % BI == 0, "batches of BI row fragments");
+    const int nb = nw0 + fg * 4;
+    const bool nobias = (EPI == EPI_F32 || EPI == EPI_HEAD) && p.accumulate;
+    f32x4 b[NF], b2[NF];
+#pragma unroll
+    for (int j = 0; j < NF; ++j) {
+        b[j] = (bias != nullptr && !nobias) ? *reinterpret_cast<const f32x4*>(bias + nb + j * 16) : f32x4{0.f, 0.f, 0.f, 0.f};
+        b2[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if constexpr (EPI == EPI_F32) {
+            if (!p.accumulate && p.bias2 != nullptr) b2[j] = *reinterpret_cast<const f32x4*>(p.bias2 + nb + j * 16);
+        }
+    }
+#pragma unroll
+    for (int i0 = 0; i0 < MF; i0 += BI) {
+        EpiPre<NF> pre[BI];
+        RopePre<NF> rp[BI];
+        long long py[BI], px[BI];
+#pragma unroll
+        for (int ii = 0; ii < BI; ++ii) {
+            const int m = m_first + (i0 + ii) * 16;
+            const int mm = m < p.M ? m : p.M - 1;
+#pragma unroll
+            for (int j = 0; j < NF; ++j) {
+                pre[ii].b[j] = b[j];
+                if constexpr (EPI == EPI_RESID_F32) {
+                    pre[ii].x[j] = ld_global<f32x4>(reinterpret_cast<const float*>(outp) + (size_t)mm * p.ldc + nb + j * 16);
+                } else if constexpr (EPI == EPI_F32) {
+                    if (p.accumulate) pre[ii].x[j] = ld_global<f32x4>(reinterpret_cast<const float*>(outp) + (size_t)mm * p.ldc + nb + j * 16);
+                }
+            }
+            if constexpr (EPI == EPI_QKV_ROPE) {
+                if (nw0 < p.rope_cols) {
+                    py[ii] = p.pos[(size_t)mm * 2 + 0];
+                    px[ii] = p.pos[(size_t)mm * 2 + 1];
+                }
+            }
+        }
+        // Explicit waits (the compiler's own would sit behind each fragment's row-validity branch, where only vmcnt(0) can express "the
+        // loads of this batch" -- and that also waits for the previous fragment's stores): ONE wait per batch, in front of its stores.
+        constexpr bool row_loads = EPI == EPI_RESID_F32 || EPI == EPI_F32 || EPI == EPI_QKV_ROPE;
+        if (i0 == 0 || row_loads) __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0)
+        if constexpr (EPI == EPI_QKV_ROPE) {
+            if (nw0 < p.rope_cols) {
+#pragma unroll
+                for (int ii = 0; ii < BI; ++ii)
+#pragma unroll
+                    for (int q = 0; q < NF / 2; ++q) {
+                        const int nh = nw0 + q * 32;
+                        int pp = (int)(((nh >> 5) & 1) ? px[ii] : py[ii]);
+                        pp = pp < 0 ? 0 : (pp >= p.rope_npos ? p.rope_npos - 1 : pp);
+                        const float* tb = p.rope_tab + ((size_t)pp * 16 + fg * 4) * 2;
+                        rp[ii].t0[q] = *reinterpret_cast<const f32x4*>(tb);
+                        rp[ii].t1[q] = *reinterpret_cast<const f32x4*>(tb + 4);
+                    }
+                __builtin_amdgcn_s_waitcnt(0x0f70);
+            }
+        }
+#pragma unroll
+        for (int ii = 0; ii < BI; ++ii) {
+            const int m = m_first + (i0 + ii) * 16;
+            if (m >= p.M) continue;
+            f32x4 v[NF];
+#pragma unroll
+            for (int j = 0; j < NF; ++j) v[j] = acc[i0 + ii][j];
+            float mu = 0.f, rstd = 0.f;
+            lnf(i0 + ii, mu, rstd);
+            epilogue_row<T, EPI, NF, LN>(p, outp, bias, m, nw0, fg, v, &pre[ii], mu, rstd, b2, &rp[ii]);
+        }
+    }
+}
+struct NoLnFold {
+    __device__ __forceinline__ void operator()(int, float&, float&) const {}
+};
 
 // WS = 2: split-weight mode, W is [N, 2K] = [W_hi | W_lo]; every K-tile stages the activation tile once plus BOTH weight
 // tiles, and each activation fragment feeds two MFMAs (acc += W_hi.a ; acc += W_lo.a).
@@ -308,7 +457,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN) gemm_kernel(const GemmArgs p) 
     const int fg = lane >> 4;   // k-group (16-byte chunk) supplied by this lane
     const int nk = nka;
     // LN fold (consumer): row statistics of this block's BM rows, kept behind the ring
-    constexpr bool LNF = EPI == EPI_STORE16 || EPI == EPI_STORE16_GELU || EPI == EPI_QKV_ROPE;
+    constexpr bool LNF = BM == 64 && (EPI == EPI_STORE16 || EPI == EPI_STORE16_GELU || EPI == EPI_QKV_ROPE);   // LN-fold consumers run on the 64 x 64 tiles only
     float* const sm_ln = reinterpret_cast<float*>(smem + (size_t)NST * (BM + WS * BN) * BK * sizeof(T));
     if constexpr (LNF) {
         if (p.ln_stats != nullptr) ln_fold_rows<BM, 64 * NW>(p, m0, sm_ln, tid, n0 == 0);
@@ -478,14 +627,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN) gemm_kernel(const GemmArgs p) 
     }
 
     // ---- epilogue: acc[i][j][r] = C[m = m0 + wm*WM + i*16 + fr][n = n0 + wn*WN + j*16 + fg*4 + r]
-#pragma unroll
-    for (int i = 0; i < MF; ++i) {
-        const int m = m0 + wm * WM + i * 16 + fr;
-        if (m >= p.M) continue;
-        f32x4 v[NF];
-#pragma unroll
-        for (int j = 0; j < NF; ++j) v[j] = acc[i][j];
-        float mu = 0.f, rstd = 0.f;
+    auto lnf = [&](int i, float& mu, float& rstd) {
         if constexpr (LNF) {
             if (p.ln_stats != nullptr) {
                 constexpr int TPR = 64 * NW / BM;
@@ -493,8 +635,8 @@ __global__ void __launch_bounds__(64 * WGM * WGN) gemm_kernel(const GemmArgs p) 
                 rstd = sm_ln[BM * TPR * 2 + (wm * WM + i * 16 + fr) * 2 + 1];
             }
         }
-        epilogue_row<T, EPI, NF>(p, outp, bias, m, n0 + wn * WN, fg, v, nullptr, mu, rstd);
-    }
+    };
+    epilogue_tile<T, EPI, NF, MF, (MF % 4 == 0 ? 4 : (MF % 2 == 0 ? 2 : 1)), BM == 64>(p, outp, bias, m0 + wm * WM + fr, n0 + wn * WN, fg, acc, lnf);
 }
 
 template <class T, int BM, int BN, int WGM, int WGN, int EPI, int NST, int WS, int BK = 64, int PIPE = 0>
@@ -684,15 +826,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(OCC ==
     }
     if (wr == 0) __builtin_amdgcn_s_barrier();
 
-#pragma unroll
-    for (int i = 0; i < MF; ++i) {
-        const int m = m0 + wr * 128 + i * 16 + fr;
-        if (m >= p.M) continue;
-        f32x4 v[NF];
-#pragma unroll
-        for (int j = 0; j < NF; ++j) v[j] = acc[i][j];
-        epilogue_row<T, EPI, NF>(p, outp, bias, m, n0 + wc * WN, fg, v);
-    }
+    epilogue_tile<T, EPI, NF, MF, 4, false>(p, outp, bias, m0 + wr * 128 + fr, n0 + wc * WN, fg, acc, NoLnFold{});
 }
 
 // (r03, built / measured / removed: `gemm256s_kernel` -- the same tile, ring and epilogues with ALL EIGHT waves multiplying all the time,
@@ -715,6 +849,293 @@ static int launch_256(const GemmArgs& a, hipStream_t s) {
     }
     hipLaunchKernelGGL((gemm256_kernel<T, EPI, WS, BN, OCC>), dim3(nbm * nbn, a.batch > 1 ? a.batch : 1), dim3(512), lds, s, a);
     return hipGetLastError() == hipSuccess ? 0 : 1;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// gemm256k_kernel (r03): 256 x BN tile, 8 waves, K staged in CHUNKS of 64 (128-byte operand rows), two 64 KB buffers, ONE barrier per chunk.
+//   Why (profiles/r03_pipe_rates.txt): an LDS-DMA instruction that gathers 16 rows x 64 B (the K-tile of 32 of gemm256_kernel) touches 16
+//   cache lines for 1 KB; the CU's vector-memory front end delivers such pieces at 30 B/clk -- 1070 cycles for the 32 KB of a 256 x 256 x 32
+//   K-tile, as long as the tile's 1024 cycles of MFMA work, and a wave that cannot issue its DMA cannot issue its MFMAs either.  Pieces of
+//   8 rows x 128 B (whole lines) go at 59 B/clk.  A chunk is two 32-deep sub-tiles: 16 phases of NF x WS MFMAs per wave; the fragments
+//   are streamed from inline-asm ds_reads with hand-counted lgkmcnt (activation fragments two phases ahead in a ring of four register
+//   sets, the weight fragments of the next sub-tile behind the last two phases of the current one).
+//   The chunk barrier sits in front of phase 14: it publishes chunk c+1 (every wave has waited for ITS pieces: vmcnt 0) and, because
+//   every wave has also retired its last read of chunk c (lgkmcnt 0 on the two fragments still in flight), frees the buffer of chunk c for
+//   chunk c+2, whose DMA pieces are issued one per phase over the next SPREAD phases (SPREAD = 16: even / odd waves alternate).
+//   WARM: one dword per lane touches the 512 cache lines of chunk c+3 a chunk ahead of its DMA (HBM latency off the DMA's path).
+// Same accumulation order per output as every other tile shape (k ascending, hi before lo in each 32-deep step): identical bits.
+template <class T, int EPI, int WS, int BN, int SPREAD, int WARM, int ABL = 0>
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) gemm256k_kernel(const GemmArgs p) {
+    typedef typename Vec<T>::v8 v8;
+    constexpr int BM = 256, CK = 64;
+    constexpr int WR = WS * BN;                 // rows of the staged weight region
+    static_assert(WR == 256 || WR == 128, "two chunk buffers must fit the LDS");
+    constexpr int WN = BN / 4;
+    constexpr int MF = 8, NF = WN / 16;
+    constexpr int NW = NF * WS, NW2 = NW / 2;   // weight fragments per sub-tile
+    static_assert(NW >= 2 && NW % 2 == 0, "weight fragments are read in two halves");
+    constexpr int PW = WR / 64;                 // weight DMA pieces (8 rows x 128 B) per wave and chunk; activations: 4
+    constexpr int NP = 4 + PW;
+    static_assert(SPREAD == 16 || SPREAD == NP, "one piece per wave and phase");
+    constexpr int STAGE = (BM + WR) * CK;       // elements per buffer
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    T* const lds = reinterpret_cast<T*>(smem);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+
+    const int nbn = p.N / BN;
+    const int nbm = (p.M + BM - 1) / BM;
+    const int nwg = nbm * nbn;
+    int bid = blockIdx.x;
+    {
+        const int xcd = bid & 7, slot = bid >> 3;
+        const int q = nwg >> 3, r = nwg & 7;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+    }
+    constexpr int GM = 4;
+    const int tpg = GM * nbn;
+    const int gidx = bid / tpg;
+    const int gfirst = gidx * GM;
+    const int gsz = (nbm - gfirst < GM) ? nbm - gfirst : GM;
+    const int gin = bid - gidx * tpg;
+    const int m0 = (gfirst + gin % gsz) * BM;
+    const int n0 = (gin / gsz) * BN;
+
+    const int grp = blockIdx.y;
+    const T* __restrict__ A = reinterpret_cast<const T*>(p.A) + (size_t)grp * p.strideA;
+    const int wgrp = p.wdiv > 1 ? grp / p.wdiv : grp;
+    const T* __restrict__ W = reinterpret_cast<const T*>(p.W) + (size_t)wgrp * p.strideW;
+    const float* __restrict__ bias = p.bias ? p.bias + (size_t)wgrp * p.strideB : nullptr;
+    void* const outp = p.out_table ? p.out_table[grp] : p.out;
+
+    // ---- staging: one wave instruction moves 8 rows x 128 B
+    const int srow = lane >> 3, pch = lane & 7;
+    const T* a_src[4];
+    const T* w_src[PW];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int r = (wave * 4 + t) * 8 + srow;
+        int gr = m0 + r;
+        gr = gr < p.M ? gr : p.M - 1;
+        a_src[t] = A + (size_t)gr * p.lda + swz(r, pch) * 8;
+    }
+#pragma unroll
+    for (int t = 0; t < PW; ++t) {
+        const int r = (wave * PW + t) * 8 + srow;            // weight region row: [hi BN rows | lo BN rows] when split
+        const int part = r / BN, wrow = r - part * BN;
+        w_src[t] = W + (size_t)(n0 + wrow) * (size_t)(p.K * WS) + (size_t)part * p.K + swz(r, pch) * 8;
+    }
+    auto piece = [&](int q, int c, int buf) {   // q: compile-time constant at every call site
+        T* base = lds + buf * STAGE;
+        if (q < 4) glds16(a_src[q < 4 ? q : 0] + c * CK, base + (wave * 4 + q) * 8 * CK);
+        else glds16(w_src[q >= 4 ? q - 4 : 0] + c * CK, base + BM * CK + (wave * PW + (q - 4)) * 8 * CK);
+    };
+    const char* warm_ptr = nullptr;
+    if constexpr (WARM != 0) {
+        const int q = lane >> 3, sr = lane & 7;
+        if (q < 4 || PW < 4) {
+            const int qa = q & 3;
+            int gr = m0 + (wave * 4 + qa) * 8 + sr;
+            gr = gr < p.M ? gr : p.M - 1;
+            warm_ptr = reinterpret_cast<const char*>(A + (size_t)gr * p.lda);
+        }
+        if (q >= 4 && (q - 4) < PW) {
+            const int r = (wave * PW + (q - 4)) * 8 + sr;
+            const int part = r / BN, wrow = r - part * BN;
+            warm_ptr = reinterpret_cast<const char*>(W + (size_t)(n0 + wrow) * (size_t)(p.K * WS) + (size_t)part * p.K);
+        }
+    }
+
+    f32x4 acc[MF][NF];
+#pragma unroll
+    for (int i = 0; i < MF; ++i)
+#pragma unroll
+        for (int j = 0; j < NF; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int fr = lane & 15, fg = lane >> 4;
+    const int nc = p.K / CK;
+    // LDS byte addresses of this lane's fragments in buffer 0, sub-tile h: row-fragment i / weight fragment (part, j) are immediates on top
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) const char*)smem;
+    unsigned a_lane[2], w_lane[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int ra = wr * 128 + fr, rw = wc * WN + fr;
+        a_lane[h] = lds0 + (unsigned)(ra * 128 + swz(ra, h * 4 + fg) * 16);
+        w_lane[h] = lds0 + (unsigned)(BM * 128 + rw * 128 + swz(rw, h * 4 + fg) * 16);
+    }
+    constexpr unsigned STAGEB = STAGE * 2;
+
+#pragma unroll
+    for (int q = 0; q < NP; ++q) piece(q, 0, 0);
+    if (nc > 1) {
+#pragma unroll
+        for (int q = 0; q < NP; ++q) piece(q, 1, 1);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NP) : "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+
+    v8 wf[2][WS][NF], af[4];
+    unsigned warm = 0;
+#define M3R_DSR0(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
+#define M3R_DSR(dst, addr, off) do { if constexpr (!(ABL & 2)) M3R_DSR0(dst, addr, off); else asm volatile("" : "+v"(dst)); } while (0)
+#define M3R_LGKM(n, x) do { if constexpr (!(ABL & 2)) asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(x) : "n"(n)); } while (0)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // scalar loads share the counter: none may be in flight under the counted waits
+#pragma unroll
+    for (int part = 0; part < WS; ++part)
+#pragma unroll
+        for (int j = 0; j < NF; ++j) M3R_DSR0(wf[0][part][j], w_lane[0], (part * BN + j * 16) * 128);
+    M3R_DSR0(af[0], a_lane[0], 0);
+    M3R_DSR0(af[1], a_lane[0], 16 * 128);
+    if constexpr ((ABL & 2) != 0) {   // timing ablation: fragments read once
+        M3R_DSR0(af[2], a_lane[0], 32 * 128);
+        M3R_DSR0(af[3], a_lane[0], 48 * 128);
+#pragma unroll
+        for (int part = 0; part < WS; ++part)
+#pragma unroll
+            for (int j = 0; j < NF; ++j) M3R_DSR0(wf[1][part][j], w_lane[1], (part * BN + j * 16) * 128);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+
+    for (int c = 0; c < nc; ++c) {
+        const int buf = c & 1;
+        const unsigned cur = buf ? STAGEB : 0u, nxt = buf ? 0u : STAGEB;
+        const unsigned a_cur0 = a_lane[0] + cur, a_cur1 = a_lane[1] + cur, a_nxt0 = a_lane[0] + nxt;
+        const unsigned w_cur1 = w_lane[1] + cur, w_nxt0 = w_lane[0] + nxt;
+        const bool dma_next = c >= 1 && c + 1 < nc;   // the rest of chunk c+1 (its first pieces went out behind the barrier of chunk c-1)
+        const bool dma_next2 = c + 2 < nc;            // chunk c+2, behind this chunk's barrier
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+            const int h = g >> 3, i = g & 7;
+            if (g == 14) {
+                // last reads of this chunk (fragments 14, 15) retired; own pieces of chunk c+1 landed; then: chunk c+1 visible, this buffer free
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(af[2]), "+v"(af[3]));
+                if constexpr (!(ABL & 16)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if constexpr (!(ABL & 4)) __builtin_amdgcn_s_barrier();
+                if constexpr (WARM != 0) {
+                    if (c + 3 < nc) asm volatile("global_load_dword %0, %1, off" : "=v"(warm) : "v"(warm_ptr + (size_t)(c + 3) * CK * sizeof(T)) : "memory");
+                }
+            }
+            // ---- reads: activation fragment g+2 (phases 14 / 15: fragments 0 / 1 of chunk c+1 -- the last chunk reads stale ring contents
+            // nobody uses, so that the counted waits are the same in every chunk and no branch surrounds a statement with an in-flight register)
+            {
+                const int g2 = g + 2;
+                if (g2 < 8) M3R_DSR(af[g2 & 3], a_cur0, g2 * 16 * 128);
+                else if (g2 < 16) M3R_DSR(af[g2 & 3], a_cur1, (g2 - 8) * 16 * 128);
+                else M3R_DSR(af[g2 & 3], a_nxt0, (g2 - 16) * 16 * 128);
+            }
+            if (i >= 6) {   // the next sub-tile's weight fragments: half of them behind each of the last two phases
+#pragma unroll
+                for (int part = 0; part < WS; ++part)
+#pragma unroll
+                    for (int j = 0; j < NF; ++j)
+                        if ((part * NF + j) / NW2 == i - 6) {
+                            if (h == 0) M3R_DSR(wf[1][part][j], w_cur1, (part * BN + j * 16) * 128);
+                            else M3R_DSR(wf[0][part][j], w_nxt0, (part * BN + j * 16) * 128);
+                        }
+            }
+            // ---- DMA: phase offset o behind the barrier -> piece o (SPREAD = NP) or piece o / 2 of the waves of parity o & 1 (SPREAD = 16)
+            {
+                const int o = (g + 2) & 15;
+                const bool on = (ABL & 1) ? false : (g >= 14 ? dma_next2 : dma_next);
+                const int tc = g >= 14 ? c + 2 : c + 1, tb = g >= 14 ? buf : (buf ^ 1);
+                if constexpr (SPREAD == 16) {
+                    if ((o >> 1) < NP && on && (wave & 1) == (o & 1)) piece(o >> 1, tc, tb);
+                } else {
+                    if (o < NP && on) piece(o < NP ? o : 0, tc, tb);
+                }
+            }
+            // ---- wait for fragment g (phase 0 of a sub-tile: and for its weight fragments)
+            if (g >= 14) {
+            } else if (i == 0) {
+                M3R_LGKM(1, af[g & 3]);
+#pragma unroll
+                for (int part = 0; part < WS; ++part)
+#pragma unroll
+                    for (int j = 0; j < NF; ++j) asm volatile("" : "+v"(wf[h][part][j]));
+            } else if (i < 6) {
+                M3R_LGKM(2, af[g & 3]);
+            } else if (i == 6) {
+                M3R_LGKM(2 + NW2, af[g & 3]);
+            } else {
+                M3R_LGKM(2 + 2 * NW2, af[g & 3]);
+            }
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int part = 0; part < WS; ++part)
+#pragma unroll
+                for (int j = 0; j < NF; ++j) {
+                    if constexpr (!(ABL & 8)) acc[i][j] = mfma16(wf[h][part][j], af[g & 3], acc[i][j]);
+                    else asm volatile("" : "+v"(acc[i][j]) : "v"(wf[h][part][j]), "v"(af[g & 3]));
+                }
+            __builtin_amdgcn_s_setprio(0);
+        }
+    }
+    // the last chunk's "next chunk" reads are still in flight: their destination registers stay LIVE up to this wait, or the epilogue
+    // would reuse them under the landing data (scripts/checks/asm_inflight_regs.py walks the generated code for exactly that)
+    if constexpr (NW == 4 && WS == 1)
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+v"(af[0]), "+v"(af[1]), "+v"(wf[0][0][0]), "+v"(wf[0][0][1]), "+v"(wf[0][0][2]), "+v"(wf[0][0][3]), "+v"(warm) : : "memory");
+    else if constexpr (NW == 4 && WS == 2)
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+v"(af[0]), "+v"(af[1]), "+v"(wf[0][0][0]), "+v"(wf[0][0][1]), "+v"(wf[0][1][0]), "+v"(wf[0][1][1]), "+v"(warm) : : "memory");
+    else {
+        static_assert(NW == 2 && WS == 1, "gemm256k: add the drain statement for this geometry");
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+v"(af[0]), "+v"(af[1]), "+v"(wf[0][0][0]), "+v"(wf[0][0][1]), "+v"(warm) : : "memory");
+    }
+#undef M3R_DSR
+#undef M3R_DSR0
+#undef M3R_LGKM
+
+    if constexpr ((ABL & 32) != 0) {   // timing ablation: no epilogue
+        if (acc[0][0][0] != 12345.678f) return;
+    }
+    epilogue_tile<T, EPI, NF, MF, 4, false>(p, outp, bias, m0 + wr * 128 + fr, n0 + wc * WN, fg, acc, NoLnFold{});
+}
+
+template <class T, int EPI, int WS, int BN, int SPREAD, int WARM, int ABL = 0>
+static int launch_256k_v(const GemmArgs& a, hipStream_t s) {
+    const int nbn = a.N / BN, nbm = (a.M + 255) / 256;
+    const size_t lds = (size_t)2 * (256 + WS * BN) * 64 * sizeof(T);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256k_kernel<T, EPI, WS, BN, SPREAD, WARM, ABL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((gemm256k_kernel<T, EPI, WS, BN, SPREAD, WARM, ABL>), dim3(nbm * nbn, a.batch > 1 ? a.batch : 1), dim3(512), lds, s, a);
+    return hipGetLastError() == hipSuccess ? 0 : 1;
+}
+// experiment switch M3R_G256K_VAR: 0 = 8 phases, 1 = 16 phases (alternating waves), +2 = with the L2 warm-up loads
+template <class T, int EPI, int WS, int BN>
+static int launch_256k(const GemmArgs& a, hipStream_t s) {
+    static int var = -1;
+    if (var < 0) {
+        const char* e = getenv("M3R_G256K_VAR");
+        var = e ? atoi(e) : 0;
+    }
+    constexpr int NP = 4 + WS * BN / 64;
+    if constexpr (EPI == EPI_STORE16 && WS == 1) {   // timing ablations (wrong results): M3R_G256K_ABL bit 0 no DMA, 1 no fragment reads, 2 no barrier, 3 no MFMA, 4 no vmcnt wait
+        static int abl = -1;
+        if (abl < 0) {
+            const char* e = getenv("M3R_G256K_ABL");
+            abl = e ? atoi(e) : 0;
+        }
+        switch (abl) {
+            case 0: break;
+#define M3R_ABL(n) case n: return launch_256k_v<T, EPI, WS, BN, NP, 0, n>(a, s);
+            M3R_ABL(1) M3R_ABL(2) M3R_ABL(3) M3R_ABL(4) M3R_ABL(5) M3R_ABL(6) M3R_ABL(7) M3R_ABL(8) M3R_ABL(9) M3R_ABL(10) M3R_ABL(12) M3R_ABL(20) M3R_ABL(21) M3R_ABL(23) M3R_ABL(32) M3R_ABL(39)
+#undef M3R_ABL
+            default: return 1;
+        }
+    }
+    switch (var) {
+        case 1: return launch_256k_v<T, EPI, WS, BN, 16, 0>(a, s);
+        case 2: return launch_256k_v<T, EPI, WS, BN, NP, 1>(a, s);
+        case 3: return launch_256k_v<T, EPI, WS, BN, 16, 1>(a, s);
+        default: return launch_256k_v<T, EPI, WS, BN, NP, 0>(a, s);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -1173,10 +1594,20 @@ static int fill256(long tiles) {   // percentage of the CU slots of its rounds t
     const long rounds = (tiles + 255) / 256;
     return (int)(tiles * 100 / (rounds * 256));
 }
+static int g256k_mode() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("M3R_G256K");
+        v = e ? atoi(e) : 0;
+    }
+    return v;
+}
 template <class T, int EPI>
 static int launch_epi(const GemmArgs& a, hipStream_t s, const char** err) {
     const long nb = a.batch > 1 ? a.batch : 1;
-    const int mode = gemm256_mode();
+    // LN-fold producers (x16_out / copy32_out / stats_out) need a kernel whose epilogue carries the LN paths: the 64 x 64 / 96 / 48 tiles
+    const bool lnp = a.x16_out != nullptr || a.copy32_out != nullptr || a.stats_out != nullptr;
+    const int mode = lnp ? 0 : gemm256_mode();
     const long rb256 = (long)((a.M + 255) / 256) * nb;
     int rc;
     if (a.wsplit == 2) {
@@ -1218,7 +1649,7 @@ static int launch_epi(const GemmArgs& a, hipStream_t s, const char** err) {
             else if (pick == 256) rc = launch_256<T, EPI, 2, 256>(a, s);
             else if (pick == 192) rc = launch_256<T, EPI == EPI_QKV_ROPE ? EPI_STORE16 : EPI, 2, 192>(a, s);
             else if (pick == 128) rc = launch_256<T, EPI, 2, 128>(a, s);   // (two blocks per CU measured slower for every epilogue but the GELU one)
-            else if (tiles >= min_big(true)) rc = launch_cfg<T, 128, 64, 2, 2, EPI, 2, 2>(a, s);
+            else if (tiles >= min_big(true) && !lnp) rc = launch_cfg<T, 128, 64, 2, 2, EPI, 2, 2>(a, s);
             else if (small8((long)((a.M + 63) / 64) * (a.N / 64) * nb)) rc = launch_cfg<T, 64, 64, SMALL_WGM, 2, EPI, SMALL8_NST_SPLIT, 2, 64, 1>(a, s);
             else rc = launch_cfg<T, 64, 64, 2, 2, EPI, 3, 2>(a, s);
         } else {
@@ -1236,8 +1667,8 @@ static int launch_epi(const GemmArgs& a, hipStream_t s, const char** err) {
             else rc = 1;
         } else if (EPI != EPI_QKV_ROPE && EPI != EPI_HEAD && sizeof(T) == 2 && use_48(a, nb)) {
             rc = launch_48<T, EPI == EPI_QKV_ROPE || EPI == EPI_HEAD ? EPI_STORE16 : EPI, 1>(a, s);   // N = 768 one-view launches: 256 tiles of 48 x 48
-        } else if (ok256 && (mode == 2 || (mode == 1 && t256 >= 200 && fill256(t256) >= 80))) rc = launch_256<T, EPI, 1, 256>(a, s);
-        else if (n128 && tiles128 >= min_big(false)) rc = launch_cfg<T, 128, 128, 2, 2, EPI, 2, 1>(a, s);
+        } else if (ok256 && (mode == 2 || (mode == 1 && t256 >= 200 && fill256(t256) >= 80))) rc = g256k_mode() >= 1 ? launch_256k<T, EPI, 1, 256>(a, s) : launch_256<T, EPI, 1, 256>(a, s);
+        else if (n128 && tiles128 >= min_big(false) && !lnp) rc = launch_cfg<T, 128, 128, 2, 2, EPI, 2, 1>(a, s);
         else if (small8((long)((a.M + 63) / 64) * (a.N / 64) * nb)) rc = launch_cfg<T, 64, 64, SMALL_WGM, 2, EPI, SMALL8_NST_PLAIN, 1, 64, 1>(a, s);
         else rc = launch_cfg<T, 64, 64, 2, 2, EPI, 4, 1>(a, s);
     }

@@ -24,8 +24,14 @@ shapes = [("enc qkv", 15360, 3072, 1024, lib.EPI_STORE16), ("enc proj", 15360, 1
           ("dec fc1", 15360, 3072, 768, lib.EPI_STORE16_GELU), ("dec fc2", 15360, 768, 3072, lib.EPI_RESID_F32),
           ("dec kv", 15360, 1536, 768, lib.EPI_STORE16), ("tail M", 15360 - 100, 1024, 1024, lib.EPI_F32),
           ("enc18 fc1", 13824, 4096, 1024, lib.EPI_STORE16_GELU), ("k192", 4096, 1024, 192, lib.EPI_STORE16)]
+if os.environ.get("ONLY"):   # timing-experiment shapes (the fixed per-tile cost; a long K loop)
+    shapes += [("k64", 15360, 3072, 64, lib.EPI_STORE16), ("k128", 15360, 3072, 128, lib.EPI_STORE16), ("k4096", 15360, 3072, 4096, lib.EPI_STORE16),
+               ("k64 f32", 15360, 3072, 64, lib.EPI_RESID_F32), ("k16384", 15360, 1024, 16384, lib.EPI_STORE16)]
 tot_t = tot_f = 0.0
+only = os.environ.get("ONLY")   # comma-separated shape names
 for name, M, N, K, epi in shapes:
+    if only and name not in only.split(","):
+        continue
     g = torch.Generator(device="cuda").manual_seed(M + N + K)
     A = torch.randn((M, K), device="cuda", generator=g).to(tdt)
     Wf = torch.randn((N, K), device="cuda", generator=g) / math.sqrt(K)
@@ -59,7 +65,7 @@ for name, M, N, K, epi in shapes:
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / 10
     fl = 2.0 * M * N * K
-    if M >= 15000:
+    if M >= 15000 or only:
         tot_t += ms
         tot_f += fl
     print(f"{name:10s} M={M:6d} N={N:5d} K={K:5d} {ms * 1e3:8.1f} us {fl / ms / 1e9:7.1f} TF/s  err {err:.2e}  sha {digest}", flush=True)
