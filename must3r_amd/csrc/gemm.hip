@@ -861,10 +861,11 @@ static int launch_256(const GemmArgs& a, hipStream_t s) {
 //   sets, the weight fragments of the next sub-tile behind the last two phases of the current one).
 //   The chunk barrier sits in front of phase 14: it publishes chunk c+1 (every wave has waited for ITS pieces: vmcnt 0) and, because
 //   every wave has also retired its last read of chunk c (lgkmcnt 0 on the two fragments still in flight), frees the buffer of chunk c for
-//   chunk c+2, whose DMA pieces are issued one per phase over the next SPREAD phases (SPREAD = 16: even / odd waves alternate).
-//   WARM: one dword per lane touches the 512 cache lines of chunk c+3 a chunk ahead of its DMA (HBM latency off the DMA's path).
+//   chunk c+2, whose DMA pieces are issued one per phase over the next NP phases.  (Measured and dropped, profiles/r03_gemm256k_ab.txt:
+//   spreading them over all 16 phases, even / odd waves alternating: -9 %, the last pieces land too late; one dword per lane touching the
+//   cache lines of chunk c+3 a chunk ahead of its DMA: -12 %.)
 // Same accumulation order per output as every other tile shape (k ascending, hi before lo in each 32-deep step): identical bits.
-template <class T, int EPI, int WS, int BN, int SPREAD, int WARM, int ABL = 0>
+template <class T, int EPI, int WS, int BN, int ABL = 0>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) gemm256k_kernel(const GemmArgs p) {
     typedef typename Vec<T>::v8 v8;
     constexpr int BM = 256, CK = 64;
@@ -876,7 +877,6 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
     static_assert(NW >= 2 && NW % 2 == 0, "weight fragments are read in two halves");
     constexpr int PW = WR / 64;                 // weight DMA pieces (8 rows x 128 B) per wave and chunk; activations: 4
     constexpr int NP = 4 + PW;
-    static_assert(SPREAD == 16 || SPREAD == NP, "one piece per wave and phase");
     constexpr int STAGE = (BM + WR) * CK;       // elements per buffer
     extern __shared__ __attribute__((aligned(16))) char smem[];
     T* const lds = reinterpret_cast<T*>(smem);
@@ -933,22 +933,6 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
         if (q < 4) glds16(a_src[q < 4 ? q : 0] + c * CK, base + (wave * 4 + q) * 8 * CK);
         else glds16(w_src[q >= 4 ? q - 4 : 0] + c * CK, base + BM * CK + (wave * PW + (q - 4)) * 8 * CK);
     };
-    const char* warm_ptr = nullptr;
-    if constexpr (WARM != 0) {
-        const int q = lane >> 3, sr = lane & 7;
-        if (q < 4 || PW < 4) {
-            const int qa = q & 3;
-            int gr = m0 + (wave * 4 + qa) * 8 + sr;
-            gr = gr < p.M ? gr : p.M - 1;
-            warm_ptr = reinterpret_cast<const char*>(A + (size_t)gr * p.lda);
-        }
-        if (q >= 4 && (q - 4) < PW) {
-            const int r = (wave * PW + (q - 4)) * 8 + sr;
-            const int part = r / BN, wrow = r - part * BN;
-            warm_ptr = reinterpret_cast<const char*>(W + (size_t)(n0 + wrow) * (size_t)(p.K * WS) + (size_t)part * p.K);
-        }
-    }
-
     f32x4 acc[MF][NF];
 #pragma unroll
     for (int i = 0; i < MF; ++i)
@@ -980,7 +964,6 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
     __builtin_amdgcn_s_barrier();
 
     v8 wf[2][WS][NF], af[4];
-    unsigned warm = 0;
 #define M3R_DSR0(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
 #define M3R_DSR(dst, addr, off) do { if constexpr (!(ABL & 2)) M3R_DSR0(dst, addr, off); else asm volatile("" : "+v"(dst)); } while (0)
 #define M3R_LGKM(n, x) do { if constexpr (!(ABL & 2)) asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(x) : "n"(n)); } while (0)
@@ -1016,9 +999,6 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
                 asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(af[2]), "+v"(af[3]));
                 if constexpr (!(ABL & 16)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 if constexpr (!(ABL & 4)) __builtin_amdgcn_s_barrier();
-                if constexpr (WARM != 0) {
-                    if (c + 3 < nc) asm volatile("global_load_dword %0, %1, off" : "=v"(warm) : "v"(warm_ptr + (size_t)(c + 3) * CK * sizeof(T)) : "memory");
-                }
             }
             // ---- reads: activation fragment g+2 (phases 14 / 15: fragments 0 / 1 of chunk c+1 -- the last chunk reads stale ring contents
             // nobody uses, so that the counted waits are the same in every chunk and no branch surrounds a statement with an in-flight register)
@@ -1038,16 +1018,12 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
                             else M3R_DSR(wf[0][part][j], w_nxt0, (part * BN + j * 16) * 128);
                         }
             }
-            // ---- DMA: phase offset o behind the barrier -> piece o (SPREAD = NP) or piece o / 2 of the waves of parity o & 1 (SPREAD = 16)
+            // ---- DMA: phase offset o behind the barrier -> piece o
             {
                 const int o = (g + 2) & 15;
                 const bool on = (ABL & 1) ? false : (g >= 14 ? dma_next2 : dma_next);
                 const int tc = g >= 14 ? c + 2 : c + 1, tb = g >= 14 ? buf : (buf ^ 1);
-                if constexpr (SPREAD == 16) {
-                    if ((o >> 1) < NP && on && (wave & 1) == (o & 1)) piece(o >> 1, tc, tb);
-                } else {
-                    if (o < NP && on) piece(o < NP ? o : 0, tc, tb);
-                }
+                if (o < NP && on) piece(o < NP ? o : 0, tc, tb);
             }
             // ---- wait for fragment g (phase 0 of a sub-tile: and for its weight fragments)
             if (g >= 14) {
@@ -1078,12 +1054,12 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
     // the last chunk's "next chunk" reads are still in flight: their destination registers stay LIVE up to this wait, or the epilogue
     // would reuse them under the landing data (scripts/checks/asm_inflight_regs.py walks the generated code for exactly that)
     if constexpr (NW == 4 && WS == 1)
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+v"(af[0]), "+v"(af[1]), "+v"(wf[0][0][0]), "+v"(wf[0][0][1]), "+v"(wf[0][0][2]), "+v"(wf[0][0][3]), "+v"(warm) : : "memory");
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+v"(af[0]), "+v"(af[1]), "+v"(wf[0][0][0]), "+v"(wf[0][0][1]), "+v"(wf[0][0][2]), "+v"(wf[0][0][3]) : : "memory");
     else if constexpr (NW == 4 && WS == 2)
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+v"(af[0]), "+v"(af[1]), "+v"(wf[0][0][0]), "+v"(wf[0][0][1]), "+v"(wf[0][1][0]), "+v"(wf[0][1][1]), "+v"(warm) : : "memory");
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+v"(af[0]), "+v"(af[1]), "+v"(wf[0][0][0]), "+v"(wf[0][0][1]), "+v"(wf[0][1][0]), "+v"(wf[0][1][1]) : : "memory");
     else {
         static_assert(NW == 2 && WS == 1, "gemm256k: add the drain statement for this geometry");
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+v"(af[0]), "+v"(af[1]), "+v"(wf[0][0][0]), "+v"(wf[0][0][1]), "+v"(warm) : : "memory");
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+v"(af[0]), "+v"(af[1]), "+v"(wf[0][0][0]), "+v"(wf[0][0][1]) : : "memory");
     }
 #undef M3R_DSR
 #undef M3R_DSR0
@@ -1095,28 +1071,23 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
     epilogue_tile<T, EPI, NF, MF, 4, false>(p, outp, bias, m0 + wr * 128 + fr, n0 + wc * WN, fg, acc, NoLnFold{});
 }
 
-template <class T, int EPI, int WS, int BN, int SPREAD, int WARM, int ABL = 0>
+template <class T, int EPI, int WS, int BN, int ABL = 0>
 static int launch_256k_v(const GemmArgs& a, hipStream_t s) {
     const int nbn = a.N / BN, nbm = (a.M + 255) / 256;
     const size_t lds = (size_t)2 * (256 + WS * BN) * 64 * sizeof(T);
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256k_kernel<T, EPI, WS, BN, SPREAD, WARM, ABL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256k_kernel<T, EPI, WS, BN, ABL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm256k_kernel<T, EPI, WS, BN, SPREAD, WARM, ABL>), dim3(nbm * nbn, a.batch > 1 ? a.batch : 1), dim3(512), lds, s, a);
+    hipLaunchKernelGGL((gemm256k_kernel<T, EPI, WS, BN, ABL>), dim3(nbm * nbn, a.batch > 1 ? a.batch : 1), dim3(512), lds, s, a);
     return hipGetLastError() == hipSuccess ? 0 : 1;
 }
-// experiment switch M3R_G256K_VAR: 0 = 8 phases, 1 = 16 phases (alternating waves), +2 = with the L2 warm-up loads
 template <class T, int EPI, int WS, int BN>
 static int launch_256k(const GemmArgs& a, hipStream_t s) {
-    static int var = -1;
-    if (var < 0) {
-        const char* e = getenv("M3R_G256K_VAR");
-        var = e ? atoi(e) : 0;
-    }
-    constexpr int NP = 4 + WS * BN / 64;
-    if constexpr (EPI == EPI_STORE16 && WS == 1) {   // timing ablations (wrong results): M3R_G256K_ABL bit 0 no DMA, 1 no fragment reads, 2 no barrier, 3 no MFMA, 4 no vmcnt wait
+#ifdef M3R_GEMM_EXPERIMENTS
+    // timing ablations (wrong results by construction): M3R_G256K_ABL bit 0 no DMA, 1 no fragment reads, 2 no barrier, 3 no MFMA, 4 no vmcnt wait, 5 no epilogue
+    if constexpr (EPI == EPI_STORE16 && WS == 1) {
         static int abl = -1;
         if (abl < 0) {
             const char* e = getenv("M3R_G256K_ABL");
@@ -1124,18 +1095,14 @@ static int launch_256k(const GemmArgs& a, hipStream_t s) {
         }
         switch (abl) {
             case 0: break;
-#define M3R_ABL(n) case n: return launch_256k_v<T, EPI, WS, BN, NP, 0, n>(a, s);
-            M3R_ABL(1) M3R_ABL(2) M3R_ABL(3) M3R_ABL(4) M3R_ABL(5) M3R_ABL(6) M3R_ABL(7) M3R_ABL(8) M3R_ABL(9) M3R_ABL(10) M3R_ABL(12) M3R_ABL(20) M3R_ABL(21) M3R_ABL(23) M3R_ABL(32) M3R_ABL(39)
+#define M3R_ABL(n) case n: return launch_256k_v<T, EPI, WS, BN, n>(a, s);
+            M3R_ABL(1) M3R_ABL(2) M3R_ABL(3) M3R_ABL(4) M3R_ABL(5) M3R_ABL(7) M3R_ABL(8) M3R_ABL(9) M3R_ABL(12) M3R_ABL(20) M3R_ABL(32) M3R_ABL(39)
 #undef M3R_ABL
             default: return 1;
         }
     }
-    switch (var) {
-        case 1: return launch_256k_v<T, EPI, WS, BN, 16, 0>(a, s);
-        case 2: return launch_256k_v<T, EPI, WS, BN, NP, 1>(a, s);
-        case 3: return launch_256k_v<T, EPI, WS, BN, 16, 1>(a, s);
-        default: return launch_256k_v<T, EPI, WS, BN, NP, 0>(a, s);
-    }
+#endif
+    return launch_256k_v<T, EPI, WS, BN>(a, s);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -1598,7 +1565,7 @@ static int g256k_mode() {
     static int v = -1;
     if (v < 0) {
         const char* e = getenv("M3R_G256K");
-        v = e ? atoi(e) : 0;
+        v = e ? atoi(e) : 1;
     }
     return v;
 }
@@ -1646,6 +1613,7 @@ static int launch_epi(const GemmArgs& a, hipStream_t s, const char** err) {
             } else if (EPI == EPI_STORE16_GELU && gelu_occ2 && mode != 0 && ok128 && t128 >= 1024) rc = launch_256<T, EPI, 2, 128, 2>(a, s);
             else if (EPI != EPI_HEAD && use_96(a, nb)) rc = launch_96<T, EPI == EPI_HEAD ? EPI_STORE16 : EPI>(a, s);
             else if (EPI != EPI_QKV_ROPE && EPI != EPI_HEAD && use_48(a, nb)) rc = launch_48<T, EPI == EPI_QKV_ROPE || EPI == EPI_HEAD ? EPI_STORE16 : EPI, 2>(a, s);
+            else if (pick != 0 && g256k_mode() >= 2 && ok128) rc = launch_256k<T, EPI, 2, 128>(a, s);
             else if (pick == 256) rc = launch_256<T, EPI, 2, 256>(a, s);
             else if (pick == 192) rc = launch_256<T, EPI == EPI_QKV_ROPE ? EPI_STORE16 : EPI, 2, 192>(a, s);
             else if (pick == 128) rc = launch_256<T, EPI, 2, 128>(a, s);   // (two blocks per CU measured slower for every epilogue but the GELU one)
