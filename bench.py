@@ -34,6 +34,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_TFLOPS = {"bf16": 2500.0, "fp16": 2500.0, "fp16w2": 2500.0, "fp16wa": 2500.0}   # dense MFMA peak, MI355X_MICROARCH.md "Peak BF16/FP16 MFMA"
+SUSTAINED_TFLOPS = 1750.0   # measured: MFMA-only loop, random fp16 operands, 10 ms (profiles/r03_pipe_rates.txt)
 MIXED_H = (384, 336, 288, 256, 160)                                 # BASELINE.json configs[4], W = 512, 4 views each
 
 
@@ -224,7 +225,7 @@ def main():
     # symbol in every precision; the GEMM template is spread over one symbol per epilogue, so its two tile classes are
     # reported next to it under "roofline_gemm".
     kern = {"attn3_kernel": (["attn_self", "attn_cross"], ("attn3_kernel", "attn4_kernel")),
-            "gemm_kernel<big tile>": (["gemm128"], ("gemm256_kernel", "Li128ELi64E", "Li128ELi128E")),
+            "gemm_kernel<big tile>": (["gemm128"], ("gemm256_kernel", "gemm256k_kernel", "Li128ELi64E", "Li128ELi128E")),
             "gemm_kernel<small-M>": (["gemm64"], ("Li64ELi64E", "gemm48_kernel", "gemm96_kernel", "gemms_kernel"))}
     try:
         import glob
@@ -242,7 +243,10 @@ def main():
         r = {"bound": "mfma", "kernel": name, "achieved": round(ach, 1), "peak": PEAK_TFLOPS[args.precision], "unit": "TFLOP/s",
              "frac": round(ach / PEAK_TFLOPS[args.precision], 4), "traffic": None,
              "avg_launch_us": round(a["ms"] * 1e3 / max(1, a["calls"]), 2), "launches": int(a["calls"]),
-             "algorithmic_flops_per_launch": round(a["flops"] / max(1, a["calls"]) / 1e9, 3), "flops_unit": "GFLOP"}
+             "algorithmic_flops_per_launch": round(a["flops"] / max(1, a["calls"]) / 1e9, 3), "flops_unit": "GFLOP",
+             # what the matrix pipe sustains on THIS chip with random 16-bit operands in an MFMA-only loop (power-limited clock;
+             # all-ones operands: 2190-2260): profiles/r03_pipe_rates.txt, scripts/probes/pipe_rates.hip
+             "sustained_mfma_only": SUSTAINED_TFLOPS, "frac_of_sustained": round(ach / SUSTAINED_TFLOPS, 4)}
         # HBM bytes per launch: FETCH_SIZE / WRITE_SIZE cannot be read from inside the process; they come from the committed
         # PMC passes of this same command (scripts/gpu_pmc.sh + scripts/pmc_summary.py -> profiles/rNN_pmc_traffic.json)
         rows = [v for k, v in pmc.items() if any(t in k for t in sym) and want in k]

@@ -99,7 +99,8 @@ __device__ __forceinline__ float max16f(const f32x4& a, const f32x4& b, const f3
     return r;
 }
 
-template <class T, int QW, int ABL = 0>   // ABL: timing ablations for experiments (1 no exp2, 2 no max / slow path, 3 no P.V MFMAs, 4 no cvt)
+template <class T, int QW, int ABL = 0>   // ABL: timing ablations for experiments (1 no exp2, 2 no max / slow path, 3 no P.V MFMAs, 4 no cvt, 5 no DMA in the loop,
+                                         // 6 no barrier / vmcnt wait, 7 = 5 + 6, 8 = 7 + no LDS reads, 9 = 8 + no softmax VALU: MFMAs only)
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(QW == 32 ? 3 : 2))) attn3_kernel(const AttnArgs p, const int nqb, const int ngrp, const int nsplit) {
     typedef typename Vec<T>::v8 v8;
     typedef typename Vec<T>::v4 v4;
@@ -221,13 +222,13 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(QW == 
         f32x4 s_[4][QF];
 #pragma unroll
         for (int kf = 0; kf < 4; ++kf) {
-            const v8 kfrag = *reinterpret_cast<const v8*>(k_ + koff[0] + kf * 16 * 64);
+            const v8 kfrag = ABL >= 8 ? qf_[0][1] : *reinterpret_cast<const v8*>(k_ + koff[0] + kf * 16 * 64);
 #pragma unroll
             for (int f = 0; f < QF; ++f) s_[kf][f] = mfma16(kfrag, qf_[f][0], nm_[f]);
         }
 #pragma unroll
         for (int kf = 0; kf < 4; ++kf) {
-            const v8 kfrag = *reinterpret_cast<const v8*>(k_ + koff[1] + kf * 16 * 64);
+            const v8 kfrag = ABL >= 8 ? qf_[0][0] : *reinterpret_cast<const v8*>(k_ + koff[1] + kf * 16 * 64);
 #pragma unroll
             for (int f = 0; f < QF; ++f) s_[kf][f] = mfma16(kfrag, qf_[f][1], s_[kf][f]);
         }
@@ -253,14 +254,14 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(QW == 
         }
         // ---- does any reference have to move?  decided from ONE per-lane maximum over all the lane's scores
         float mxa = -INFINITY;
-        if (ABL != 2) {
+        if (ABL != 2 && ABL != 9) {
 #pragma unroll
             for (int f = 0; f < QF; ++f) {
                 const float mf = max16f(s_[0][f], s_[1][f], s_[2][f], s_[3][f]);
                 mxa = f == 0 ? mf : fmaxf(mxa, mf);
             }
         }
-        if (ABL != 2 && (any_first || __any(mxa > ATT_THR))) {   // wave-uniform, rare after the first tile: everything updated in place
+        if (ABL != 2 && ABL != 9 && (any_first || __any(mxa > ATT_THR))) {   // wave-uniform, rare after the first tile: everything updated in place
             bool fst = false;
 #pragma unroll
             for (int f = 0; f < QF; ++f) {
@@ -291,7 +292,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(QW == 
 #pragma unroll
             for (int f = 0; f < QF; ++f)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) s_[kf][f][r] = ABL == 1 ? s_[kf][f][r] * 0.001f : __builtin_amdgcn_exp2f(s_[kf][f][r]);
+                for (int r = 0; r < 4; ++r) s_[kf][f][r] = ABL == 9 ? s_[kf][f][r] : (ABL == 1 ? s_[kf][f][r] * 0.001f : __builtin_amdgcn_exp2f(s_[kf][f][r]));
         // ---- O^T += V^T P^T ; k-slot e of lane group g <-> keys {4g+e (e<4), 16+4g+e-4 (e>=4)} of the 32-key slot
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
@@ -304,14 +305,17 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(QW == 
                     pv[r] = s_[2 * ks][f][r];
                     pv[4 + r] = s_[2 * ks + 1][f][r];
                 }
-                if (ABL == 4) __builtin_memcpy(&pb[f], &pv, 16);   // first four fp32 words as the fragment: no conversion
+                if (ABL == 4 || ABL == 9) __builtin_memcpy(&pb[f], &pv, 16);   // first four fp32 words as the fragment: no conversion
                 else pb[f] = cvt8<T>(pv);
                 if (ABL == 3) { asm volatile("" ::"v"(pb[f])); continue; }
                 ol_[f] = mfma16(ones, pb[f], ol_[f]);
             }
             if (ABL == 3) continue;
             u32x2 tr[8];
-            if (ks == 0) lds_tr_x8_imm<buf * 4 * TILE, buf * 4 * TILE + 16 * 128>(vaddr[0], vaddr[1], vaddr[2], vaddr[3], tr);
+            if (ABL >= 8) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) __builtin_memcpy(&tr[e], &qf_[0][e & 1], 8);
+            } else if (ks == 0) lds_tr_x8_imm<buf * 4 * TILE, buf * 4 * TILE + 16 * 128>(vaddr[0], vaddr[1], vaddr[2], vaddr[3], tr);
             else lds_tr_x8_imm<buf * 4 * TILE + 32 * 128, buf * 4 * TILE + 48 * 128>(vaddr[0], vaddr[1], vaddr[2], vaddr[3], tr);
 #pragma unroll
             for (int d = 0; d < 4; ++d) {
@@ -328,20 +332,25 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(QW == 
     int t = advance(t_begin - 1);
     if (t < t_end) stage(t, std::integral_constant<int, 0>{});
     while (t < t_end) {
+        constexpr bool no_dma = ABL == 5 || ABL >= 7, no_bar = ABL >= 6;
         {
-            __builtin_amdgcn_s_waitcnt(0x0f70);
-            __syncthreads();
+            if (!no_bar) {
+                __builtin_amdgcn_s_waitcnt(0x0f70);
+                __syncthreads();
+            }
             const int tn = advance(t);
-            if (tn < t_end) stage(tn, std::integral_constant<int, 1>{});
+            if (tn < t_end && !no_dma) stage(tn, std::integral_constant<int, 1>{});
             compute(t, std::integral_constant<int, 0>{});
             t = tn;
         }
         if (t >= t_end) break;
         {
-            __builtin_amdgcn_s_waitcnt(0x0f70);
-            __syncthreads();
+            if (!no_bar) {
+                __builtin_amdgcn_s_waitcnt(0x0f70);
+                __syncthreads();
+            }
             const int tn = advance(t);
-            if (tn < t_end) stage(tn, std::integral_constant<int, 0>{});
+            if (tn < t_end && !no_dma) stage(tn, std::integral_constant<int, 0>{});
             compute(t, std::integral_constant<int, 1>{});
             t = tn;
         }
@@ -976,6 +985,11 @@ int launch_attention_phase(DType dt, const AttnArgs& a_in, int phase, hipStream_
             else if (!small && dt == DT_F16 && abl == 2) M3R_LAUNCH_ATTN((attn3_kernel<f16_t, 32, 2>));
             else if (!small && dt == DT_F16 && abl == 3) M3R_LAUNCH_ATTN((attn3_kernel<f16_t, 32, 3>));
             else if (!small && dt == DT_F16 && abl == 4) M3R_LAUNCH_ATTN((attn3_kernel<f16_t, 32, 4>));
+            else if (!small && dt == DT_F16 && abl == 5) M3R_LAUNCH_ATTN((attn3_kernel<f16_t, 32, 5>));
+            else if (!small && dt == DT_F16 && abl == 6) M3R_LAUNCH_ATTN((attn3_kernel<f16_t, 32, 6>));
+            else if (!small && dt == DT_F16 && abl == 7) M3R_LAUNCH_ATTN((attn3_kernel<f16_t, 32, 7>));
+            else if (!small && dt == DT_F16 && abl == 8) M3R_LAUNCH_ATTN((attn3_kernel<f16_t, 32, 8>));
+            else if (!small && dt == DT_F16 && abl == 9) M3R_LAUNCH_ATTN((attn3_kernel<f16_t, 32, 9>));
             else if (!small && dt == DT_F16 && qw_big == 48) M3R_LAUNCH_ATTN((attn3_kernel<f16_t, 48>));
             else if (!small && dt == DT_F16 && qw_big == 64) M3R_LAUNCH_ATTN((attn3_kernel<f16_t, 64>));
             else

@@ -863,7 +863,11 @@ static int launch_256(const GemmArgs& a, hipStream_t s) {
 //   every wave has also retired its last read of chunk c (lgkmcnt 0 on the two fragments still in flight), frees the buffer of chunk c for
 //   chunk c+2, whose DMA pieces are issued one per phase over the next NP phases.  (Measured and dropped, profiles/r03_gemm256k_ab.txt:
 //   spreading them over all 16 phases, even / odd waves alternating: -9 %, the last pieces land too late; one dword per lane touching the
-//   cache lines of chunk c+3 a chunk ahead of its DMA: -12 %.)
+//   cache lines of chunk c+3 a chunk ahead of its DMA: -12 %.  Staggering the two waves of a SIMD (w, w + 4) so that they never issue DMA in
+//   the same phase -- the ablations say the DMA issue costs 25 % of the loop, the waves blocked on the vector-memory front end together --
+//   as run-time phase tests: -55 % (128 scalar branches per chunk break the MFMA stream, profiles/r03_gemm256k_spread.txt); as two copies of
+//   the phase loop chosen per wave group: the register allocator copies in-flight fragments at the join (scripts/checks/asm_inflight_regs.py
+//   rejects the build).)
 // Same accumulation order per output as every other tile shape (k ascending, hi before lo in each 32-deep step): identical bits.
 template <class T, int EPI, int WS, int BN, int ABL = 0>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) gemm256k_kernel(const GemmArgs p) {

@@ -121,6 +121,55 @@ void run_rows(const char* buf, int nw, unsigned long long* cyc, float* sink, int
            ROWB, stride, nw, P * nw, R * nw, M, BAR, per, ms * 1e3 / iters, P * nw * 1024.0 / per, 100.0 * M * nw / 4.0 * 16 / per);
 }
 
+// r03: MFMA-only loop (2 waves per SIMD, 32 MFMAs per wave and iteration, 16 independent accumulators) on operands that are all ones,
+// random fp16 values held in a few registers, or random values in MANY registers (8 A x 4 B fragments cycling like a GEMM wave tile):
+// is the matrix pipe's sustained rate data dependent (power)?
+template <int MODE>
+__global__ void __launch_bounds__(512) probe_mfma(const _Float16* __restrict__ rnd, int iters, unsigned long long* cyc, float* sink) {
+    const int lane = threadIdx.x & 63;
+    f32x4 acc[16];
+    for (int i = 0; i < 16; ++i) acc[i] = f32x4{0, 0, 0, 0};
+    f16x8 a[8], b[4];
+    for (int i = 0; i < 8; ++i)
+        for (int e = 0; e < 8; ++e) a[i][e] = MODE == 0 ? (_Float16)1 : rnd[((MODE == 1 ? 0 : i) * 64 + lane) * 8 + e];
+    for (int i = 0; i < 4; ++i)
+        for (int e = 0; e < 8; ++e) b[i][e] = MODE == 0 ? (_Float16)1 : rnd[4096 + ((MODE == 1 ? 0 : i) * 64 + lane) * 8 + e];
+    unsigned long long t0 = 0;
+    for (int it = 0; it < iters; ++it) {
+        if (it == 8) t0 = __builtin_readcyclecounter();
+#pragma unroll
+        for (int m = 0; m < 32; ++m) acc[m & 15] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[m & 7], b[(m >> 3) & 3], acc[m & 15], 0, 0, 0);
+        // keep the accumulators bounded (random data would overflow to inf and the multipliers would see constant operands)
+        if ((it & 63) == 63)
+            for (int i = 0; i < 16; ++i) acc[i] *= 1e-3f;
+    }
+    const unsigned long long t1 = __builtin_readcyclecounter();
+    if (threadIdx.x == 0 && blockIdx.x == 0) cyc[0] = t1 - t0;
+    float s = 0;
+    for (int i = 0; i < 16; ++i) s += acc[i][0];
+    if (s == 12345.678f) sink[0] = s;
+}
+template <int MODE>
+void run_mfma(const _Float16* rnd, unsigned long long* cyc, float* sink) {
+    const int iters = 20008;   // ~10 ms: long enough for the power management to settle
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    probe_mfma<MODE><<<256, 512>>>(rnd, 64, cyc, sink);
+    hipDeviceSynchronize();
+    hipEventRecord(e0);
+    probe_mfma<MODE><<<256, 512>>>(rnd, iters, cyc, sink);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms = 0;
+    hipEventElapsedTime(&ms, e0, e1);
+    unsigned long long c = 0;
+    hipMemcpy(&c, cyc, 8, hipMemcpyDeviceToHost);
+    const double us = ms * 1e3 / iters;
+    printf("MFMA only, operands %-32s: %6.0f cycles/iter  %6.3f us/iter  = %6.0f TF/s on 256 CUs\n",
+           MODE == 0 ? "all ones" : MODE == 1 ? "random, one A / one B fragment" : "random, 8 A x 4 B fragments", (double)c / (iters - 8), us,
+           256.0 * 8 * 32 * 16384 / us * 1e-6);
+}
+
 template <int P, int R, int M, int BAR>
 void run(const char* buf, int nw, unsigned long long* cyc, float* sink, int stride = 0) {
     const int iters = 2008;
@@ -147,6 +196,13 @@ int main() {
     char* buf; float* sink; unsigned long long* cyc;
     hipMalloc(&buf, 256ull * (256 << 10)); hipMalloc(&sink, 64); hipMalloc(&cyc, 64);
     hipMemset(buf, 0x3c, 256ull * (256 << 10));
+    {
+        std::vector<_Float16> h(8192);
+        unsigned x = 12345;
+        for (auto& v : h) { x = x * 1664525u + 1013904223u; v = (_Float16)(((int)(x >> 8) % 2001 - 1000) * 1e-3f); }
+        _Float16* rnd; hipMalloc(&rnd, 8192 * 2); hipMemcpy(rnd, h.data(), 8192 * 2, hipMemcpyHostToDevice);
+        run_mfma<0>(rnd, cyc, sink); run_mfma<1>(rnd, cyc, sink); run_mfma<2>(rnd, cyc, sink); run_mfma<0>(rnd, cyc, sink);
+    }
     // r03: the chip-filling 256 x 256 x 32 K-tile (8 waves: 4 DMA pieces, 12 fragment reads, 32 (plain) / 64 (split: 6 pieces, 16 reads) MFMAs per wave)
     printf("-- gemm256 K-tile mix, 8 waves\n");
     run<0, 0, 32, 1>(buf, 8, cyc, sink, 2048);
