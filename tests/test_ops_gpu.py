@@ -60,7 +60,7 @@ def test_transposing_lds_read_mapping(lib):
 
 
 SHAPES = [(200, 128, 64), (768, 768, 768), (1000, 1024, 256), (3072, 1024, 512), (3000, 2304, 768), (196, 3072, 1024),
-          (12, 128, 128)]
+          (12, 128, 128), (15260, 1024, 128)]   # the last one fills the chip: 256-row tiles (gemm256k / gemm256), ragged last row block
 
 
 @pytest.mark.parametrize("dt", ["bf16", "fp16"])
@@ -106,7 +106,7 @@ def test_gemm_store_gelu_resid_f32(lib, dt, shape):
     record("gemm", dt=dt, shape=shape, store=e1, gelu=e2, resid=e3, f32=e4)
 
 
-@pytest.mark.parametrize("shape", [(768, 768, 768), (3072, 1024, 512), (200, 128, 64)])
+@pytest.mark.parametrize("shape", [(768, 768, 768), (3072, 1024, 512), (200, 128, 64), (15260, 1024, 128)])
 def test_gemm_split_weights(lib, shape):
     """W = W_hi + W_lo in fp16, two MFMA passes: the weight rounding term must vanish (error -> activation rounding
     + fp32 accumulation only) and the result must equal the explicit two-GEMM sum."""
@@ -168,9 +168,45 @@ def test_gemm96_tiles_same_bits_as_small_tiles(lib, shape):
     record("gemm96", shape=shape, err_f32=rel_inf(full, ref))
 
 
+@pytest.mark.parametrize("ws", [0, 2])
+def test_gemm256_tiles_same_bits_as_small_tiles(lib, ws):
+    """Chip-filling launches run on 256-row tiles (plain weights: gemm256k_kernel, 64-deep K chunks; split weights: gemm256_kernel) with the
+    batched epilogue (operands of four row fragments loaded in front of their stores, 16-byte full-line stores after two cross-lane
+    exchanges).  Every row must carry the bits of the same row computed by a 64-row launch (64 x 64 tiles, per-fragment epilogue
+    path for the ragged fragment), for all four epilogues, including the ragged last row block (M = 15260: 156 rows, last fragment 12)."""
+    M, N, K = 15260, 1024, 192
+    g = torch.Generator(device="cuda").manual_seed(77 + ws)
+    A = torch.randn((M, K), device="cuda", generator=g).half()
+    Wf = torch.randn((N, K), device="cuda", generator=g) / math.sqrt(K)
+    W = _split_w(Wf) if ws == 2 else Wf.half().contiguous()
+    bias = torch.randn((N,), device="cuda", generator=g)
+    x0 = torch.randn((M, N), device="cuda", generator=g)
+    ref = A.double() @ (Wf.double() if ws == 2 else W.double()).t() + bias.double()
+    L = lib.load()
+
+    def go(epi, a, out):
+        lib.check(L.must3r_hip_op_gemm(1, epi, P(a), P(W), P(bias), P(out), a.shape[0], N, K, K, N, None, None, 0, 0, None, 0, 0,
+                                       0, 0, 0, 0, ws, stream()))
+        torch.cuda.synchronize()
+    starts = [0, 64 * 117, 15104, 15232]   # 15232: the last 28 rows (one full fragment + the ragged one)
+    for epi, odt in ((lib.EPI_STORE16, torch.float16), (lib.EPI_STORE16_GELU, torch.float16), (lib.EPI_F32, torch.float32),
+                     (lib.EPI_RESID_F32, torch.float32)):
+        full = x0.clone() if epi == lib.EPI_RESID_F32 else torch.full((M, N), 7.0, device="cuda", dtype=odt)
+        go(epi, A, full)
+        want = torch.nn.functional.gelu(ref) if epi == lib.EPI_STORE16_GELU else (ref + x0.double() if epi == lib.EPI_RESID_F32 else ref)
+        tol = 2 * 2.0 ** -11 if odt == torch.float16 else 1e-5
+        assert torch.allclose(full.double(), want, rtol=tol, atol=tol * 4), (epi, rel_inf(full, want))
+        for r0 in starts:
+            r1 = min(r0 + 64, M)
+            part = x0[r0:r1].clone() if epi == lib.EPI_RESID_F32 else torch.empty((r1 - r0, N), device="cuda", dtype=odt)
+            go(epi, A[r0:r1], part)
+            assert torch.equal(part, full[r0:r1]), (epi, r0)
+    record("gemm256_bits", ws=ws)
+
+
 
 @pytest.mark.parametrize("dt", ["bf16", "fp16"])
-@pytest.mark.parametrize("geom", [(2, 14, 14, 128), (1, 24, 32, 768), (3, 3, 4, 1024), (4, 24, 32, 256)])
+@pytest.mark.parametrize("geom", [(2, 14, 14, 128), (1, 24, 32, 768), (3, 3, 4, 1024), (4, 24, 32, 256), (20, 24, 32, 512)])
 def test_gemm_qkv_rope(lib, dt, geom):
     from oracle import must3r_ref as R
     V, gh, gw, Cdim = geom
