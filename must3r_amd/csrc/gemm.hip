@@ -329,7 +329,7 @@ __device__ __forceinline__ void epilogue_tile(const GemmArgs& p, void* const out
         }
         // Explicit waits (the compiler's own would sit behind each fragment's row-validity branch, where only vmcnt(0) can express "the
         // loads of this batch" -- and that also waits for the previous fragment's stores): ONE wait per batch, in front of its stores.
-        constexpr bool row_loads = EPI == EPI_RESID_F32 || EPI == EPI_F32 || EPI == EPI_QKV_ROPE;
+        const bool row_loads = EPI == EPI_RESID_F32 || (EPI == EPI_F32 && p.accumulate) || EPI == EPI_QKV_ROPE;
         if (i0 == 0 || row_loads) __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0)
         if constexpr (EPI == EPI_QKV_ROPE) {
             if (nw0 < p.rope_cols) {
@@ -1665,6 +1665,9 @@ int launch_gemm(DType dt, Epi epi, const GemmArgs& a, hipStream_t s, const char*
     if (a.M <= 0) return 0;
     if (a.N % 64 != 0 || a.K % 64 != 0 || a.N <= 0 || a.K <= 0) { *err = "gemm: N and K must be multiples of 64"; return 1; }
     if (a.lda % 8 != 0 || (epi != EPI_HEAD && a.ldc % 4 != 0)) { *err = "gemm: lda%8 / ldc%4 alignment"; return 1; }
+    if ((epi == EPI_STORE16 || epi == EPI_STORE16_GELU || epi == EPI_QKV_ROPE) && a.ldc % 8 != 0) {   // 16-byte stores of 8 outputs
+        *err = "gemm: 16-bit outputs need ldc % 8 == 0"; return 1;
+    }
     if (epi == EPI_QKV_ROPE && (a.pos == nullptr || a.rope_tab == nullptr || a.rope_cols % 64 != 0)) {
         *err = "gemm: rope epilogue needs pos, table and 64-aligned rope_cols"; return 1;
     }

@@ -27,6 +27,9 @@ shapes = [("enc qkv", 15360, 3072, 1024, lib.EPI_STORE16), ("enc proj", 15360, 1
 if os.environ.get("ONLY"):   # timing-experiment shapes (the fixed per-tile cost; a long K loop)
     shapes += [("k64", 15360, 3072, 64, lib.EPI_STORE16), ("k128", 15360, 3072, 128, lib.EPI_STORE16), ("k4096", 15360, 3072, 4096, lib.EPI_STORE16),
                ("k64 f32", 15360, 3072, 64, lib.EPI_RESID_F32), ("k16384", 15360, 1024, 16384, lib.EPI_STORE16)]
+if os.environ.get("MROWS"):   # the decoder shapes at another row count (S scenes in flight: M = S * 768 in the batched update)
+    mr = int(os.environ["MROWS"])
+    shapes = [(n, mr, N, K, e) for n, M, N, K, e in shapes if n.startswith("dec")]
 tot_t = tot_f = 0.0
 only = os.environ.get("ONLY")   # comma-separated shape names
 for name, M, N, K, epi in shapes:
@@ -65,7 +68,7 @@ for name, M, N, K, epi in shapes:
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / 10
     fl = 2.0 * M * N * K
-    if M >= 15000 or only:
+    if M >= 15000 or only or os.environ.get("MROWS"):
         tot_t += ms
         tot_f += fl
     print(f"{name:10s} M={M:6d} N={N:5d} K={K:5d} {ms * 1e3:8.1f} us {fl / ms / 1e9:7.1f} TF/s  err {err:.2e}  sha {digest}", flush=True)
