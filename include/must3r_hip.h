@@ -180,7 +180,8 @@ int must3r_hip_quadrant_ids(const float* pts_xyz, int64_t n, const float* cam_ce
 enum { MUST3R_EPI_STORE16 = 0, MUST3R_EPI_STORE16_GELU = 1, MUST3R_EPI_QKV_ROPE = 2, MUST3R_EPI_RESID_F32 = 3,
        MUST3R_EPI_F32 = 4, MUST3R_EPI_HEAD = 5 };
 
-/* out[M,N] = epi(A[M,K] . W[N,K]^T + bias): nn.Linear (+ fused epilogue).  A, W 16-bit. */
+/* out[M,N] = epi(A[M,K] . W[N,K]^T + bias): nn.Linear (+ fused epilogue).  A, W 16-bit.  N, K multiples of 64; lda % 8 == 0; ldc % 4 == 0
+ * (16-bit outputs: ldc % 8 == 0 and a 16-byte aligned `out` -- the epilogue stores 16 bytes per lane). */
 int must3r_hip_op_gemm(int dtype, int epi, const void* A, const void* W, const float* bias, void* out,
                        int M, int N, int K, int lda, int ldc,
                        const int64_t* pos, const float* rope_tab, int rope_cols, int rope_npos, /* QKV_ROPE */
