@@ -1,6 +1,6 @@
 """Static check of hand-counted LDS waits in the generated assembly (build-time helper, not part of the product).
 
-Kernels that issue their fragment reads from inline asm (the r03 gemm256s_kernel experiment, attn4_kernel) count `lgkmcnt` by hand.  The property to hold on EVERY
+Kernels that issue their fragment reads from inline asm (gemm256k_kernel, attn4_kernel; first written for the r03 gemm256s_kernel experiment) count `lgkmcnt` by hand.  The property to hold on EVERY
 path through the kernel: between a `ds_read_b128 vDST, ...` and an `s_waitcnt lgkmcnt(N)` that guarantees its arrival, no
 instruction reads or writes a register of vDST (the register allocator may otherwise copy a fragment -- at a join, for a tied asm
 operand -- before the data has landed, or reuse the register).  LDS operations return in order: a read has arrived once a wait with
@@ -9,7 +9,7 @@ N <= (number of younger LDS reads in flight) has executed.
 The check is a forward dataflow walk over the kernel's control-flow graph (basic blocks from the labels and s_branch / s_cbranch
 instructions of the .s file); the state is the ordered list of in-flight destination register sets.  States are memoised per block.
 
-  python scripts/checks/asm_inflight_regs.py /tmp/gemm.s gemm256s_kernel
+  python scripts/checks/asm_inflight_regs.py /tmp/gemm.s gemm256k_kernel      (tests/test_asm_checks.py runs it on every build)
 """
 import re
 import sys
