@@ -120,6 +120,18 @@ def split(V=3):
         "plain: enc MLP of blocks 12-23 + dec MLP": lambda n: not ((n.startswith("e.") and ".mlp." in n and int(n.split(".")[2]) >= 12) or (n.startswith("d.") and (".mlp." in n or "feedback" in n))),
         "plain: enc MLP of blocks 0-11 + dec MLP": lambda n: not ((n.startswith("e.") and ".mlp." in n and int(n.split(".")[2]) < 12) or (n.startswith("d.") and (".mlp." in n or "feedback" in n))),
     }
+    att = lambda n: ".mlp." not in n   # the fp16wa set: everything but the Mlp Linears
+    sets.update({
+        "wa: all but MLPs (= fp16wa)": att,
+        "wa minus encoder qkv": lambda n: att(n) and not (n.startswith("e.") and "attn.qkv" in n),
+        "wa minus encoder proj": lambda n: att(n) and not (n.startswith("e.") and "attn.proj" in n),
+        "wa minus encoder attention (qkv + proj)": lambda n: att(n) and not (n.startswith("e.") and ".attn." in n),
+        "wa minus decoder self-attention qkv": lambda n: att(n) and not (n.startswith("d.") and ".attn.qkv" in n),
+        "wa minus decoder cross-attention projections": lambda n: att(n) and not (n.startswith("d.") and "cross_attn" in n),
+        "wa minus all proj (enc + dec output projections)": lambda n: att(n) and not n.endswith("proj.weight"),
+        "wa minus encoder attention of blocks 12-23": lambda n: att(n) and not (n.startswith("e.") and ".attn." in n and int(n.split(".")[2]) >= 12),
+        "wa minus encoder attention of blocks 0-11": lambda n: att(n) and not (n.startswith("e.") and ".attn." in n and int(n.split(".")[2]) < 12),
+    })
     if len(sys.argv) > 3:
         sets = {k: v for k, v in sets.items() if any(o in k for o in sys.argv[3:])}
     for label, fn in sets.items():
