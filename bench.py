@@ -4,7 +4,7 @@
     python bench.py --gpus 1 --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
-A "step" is one pass of the hot path over one batch of synthetic input already resident in HBM: S (``--scenes``, default 8)
+A "step" is one pass of the hot path over one batch of synthetic input already resident in HBM: S (``--scenes``, default 20)
 independent scenes of 20 views per rank -- every scene: encode 20, memory update with the demo schedule [2,1,...,1] (20-view
 memory), render 20 against its final memory, fp32 activation (BASELINE.json configs[2]).  The S scenes
 are IN FLIGHT TOGETHER: they ride the batch dimension of the reference's decoder API (decoder.py:170-186), one native call per
@@ -92,7 +92,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--views", type=int, default=20)
-    ap.add_argument("--scenes", type=int, default=8, help="S: independent 20-view scenes in flight together per rank (they ride the "
+    ap.add_argument("--scenes", type=int, default=20, help="S: independent 20-view scenes in flight together per rank (they ride the "
                     "decoder's batch dimension: M = S x 768 rows in the sequential memory update); 1 = one scene at a time")
     ap.add_argument("--precision", default="fp16wa", choices=["bf16", "fp16", "fp16w2", "fp16wa"],
                     help="MFMA operand mode; fp16wa (fp16, split weights except in the Mlp Linears) and fp16w2 (all weights split) meet the "
