@@ -58,6 +58,8 @@ __device__ __forceinline__ bool attn_block_coords(int nqb_signed, int ngrp, int 
 //   * LDS addresses: the swizzles are XORs with per-lane constants, so every fragment address is one of a few per-lane VGPRs
 //     plus an immediate (buffer, k-slot, row block): 2 VGPRs for the K fragments, 4 for the transposing V reads; the loop is
 //     unrolled over the two buffers so that the buffer is part of the immediate.
+//   * (r03, measured and dropped: the wave's four DMA pieces of the next tile issued between the MFMA groups of the tile instead of as a burst
+//     behind the barrier: render CA 905 vs 919 TF/s, one-view split launches -4 %.)
 //   * softmax fast path: the cross-lane row maximum is only needed when the reference moves.  Whether it has to move is decided
 //     from the PER-LANE maxima (`any lane above the threshold`, one compare per 16 queries), the permlane exchanges, the
 //     first-tile selects and the rescale live in one wave-uniform slow block that updates S, O, the row sums and m IN PLACE
