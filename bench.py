@@ -100,6 +100,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-views", type=int, default=20, help="views of the scene the CPU oracle runs (20 = the metric's own workload)")
     ap.add_argument("--no-alt", action="store_true")
+    ap.add_argument("--no-single", action="store_true", help="skip the one-scene-at-a-time leg (the PMC passes use this)")
     ap.add_argument("--no-configs", action="store_true", help="skip the extra BASELINE.json configurations")
     ap.add_argument("--stream-frames", type=int, default=200)
     ap.add_argument("--cpu-timeout", type=float, default=420.0)
@@ -211,7 +212,7 @@ def main():
 
     # ---- one scene at a time (S = 1): the figure of rounds 1-2, kept beside the headline
     single = None
-    if world == 1 and Sn > 1:
+    if world == 1 and Sn > 1 and not args.no_single:
         fn1 = lambda: run_scene(enc, dec, imgs, ts)  # noqa: E731
         fn1()
         d1 = timed(fn1, args.steps)
@@ -250,7 +251,9 @@ def main():
         # HBM bytes per launch: FETCH_SIZE / WRITE_SIZE cannot be read from inside the process; they come from the committed
         # PMC passes of this same command (scripts/gpu_pmc.sh + scripts/pmc_summary.py -> profiles/rNN_pmc_traffic.json)
         rows = [v for k, v in pmc.items() if any(t in k for t in sym) and want in k]
-        if rows:
+        if rows and pmc_doc.get("scenes", 8) != Sn:   # per-launch bytes of another step size do not belong to these launches
+            r["traffic_note"] = f"{os.path.relpath(pmc_file, ROOT)} was taken at {pmc_doc.get('scenes', 8)} scenes in flight, this run has {Sn}"
+        elif rows:
             n = sum(x["launches"] for x in rows)
             r["traffic"] = int(sum(x["hbm_bytes_per_launch_corrected"] * x["launches"] for x in rows) / max(1, n))
             r["traffic_unit"] = "bytes/launch (PMC, corrected)"

@@ -6,8 +6,8 @@ cd "${GRAFT_REPO_ROOT:-/root/repo}"
 export TMPDIR=/tmp PYTHONDONTWRITEBYTECODE=1
 for CTR in FETCH_SIZE WRITE_SIZE; do
   rm -rf gpurun_out/pmc_$CTR
-  timeout 900 rocprofv3 --kernel-trace --pmc $CTR --output-format csv -d gpurun_out/pmc_$CTR -o run -- \
-      python bench.py --gpus 1 --steps 1 --warmup 1 --no-cpu-baseline --no-alt --no-configs > gpurun_out/pmc_$CTR.log 2>&1
+  timeout 420 rocprofv3 --kernel-trace --pmc $CTR --output-format csv -d gpurun_out/pmc_$CTR -o run -- \
+      python bench.py --gpus 1 --steps 1 --warmup 1 --no-cpu-baseline --no-alt --no-configs --no-single > gpurun_out/pmc_$CTR.log 2>&1
   python - "$CTR" <<'PY'
 import sys, glob, json, csv, re, collections
 ctr = sys.argv[1]

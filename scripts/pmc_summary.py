@@ -21,14 +21,15 @@ for k in sorted(set(f) | set(w)):
     short = re.sub(r"^_ZN3m3r\d+", "", k)
     res[k] = {"launches": fk.get("launches", wk.get("launches")), "FETCH_SIZE_KiB_mean": round(fetch, 1),
               "WRITE_SIZE_KiB_mean": round(write, 1), "hbm_bytes_per_launch_corrected": int((2 * fetch + write) * 1024)}
+import os
 try:   # the commit the counters were taken at (gpurun ships no .git: scripts/gpu_pmc.sh passes it through M3R_COMMIT)
     import os
     commit = os.environ.get("M3R_COMMIT") or subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip() or "?"
 except Exception:
     commit = "?"
 json.dump({"command": "rocprofv3 --kernel-trace --pmc <FETCH_SIZE|WRITE_SIZE> -- python bench.py --gpus 1 --steps 1 --warmup 1 "
-                      "--no-cpu-baseline --no-alt --no-configs  (two separate passes)",
-           "commit": commit,
+                      "--no-cpu-baseline --no-alt --no-configs --no-single  (two separate passes)",
+           "commit": commit, "scenes": int(os.environ.get("M3R_PMC_SCENES", "20")),
            "correction": "bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950 FETCH_SIZE halves wide coalesced reads; WRITE_SIZE uncalibrated)",
            "kernels": res}, open(out, "w"), indent=1)
 for k, v in sorted(res.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch_corrected"] * (kv[1]["launches"] or 0))[:8]:
