@@ -191,4 +191,36 @@ __device__ __forceinline__ float gelu_erf(float x) {
     return 0.5f * x * (1.0f + erf_v);
 }
 
+// The same arithmetic on two values at once: clang maps the ext_vector float2 operations to the packed fp32 VALU instructions of gfx950
+// (v_pk_mul_f32 / v_pk_fma_f32 / v_pk_add_f32 -- IEEE per component, i.e. the bits of the scalar form) -- 10 instead of 18 VALU instructions
+// per output.  (Packed fp32 beside MFMAs is an anti-lever; in a GEMM epilogue no MFMA runs on the CU.)
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+__device__ __forceinline__ f32x2 gelu_erf2(const f32x2 x) {
+    f32x2 ax;
+    ax[0] = fabsf(x[0]);
+    ax[1] = fabsf(x[1]);
+    const f32x2 z = ax * 0.70710678118654752440f;
+    const f32x2 d = __builtin_elementwise_fma(f32x2{0.3275911f, 0.3275911f}, z, f32x2{1.0f, 1.0f});
+    f32x2 t;
+    t[0] = __builtin_amdgcn_rcpf(d[0]);
+    t[1] = __builtin_amdgcn_rcpf(d[1]);
+    f32x2 p = __builtin_elementwise_fma(f32x2{1.061405429f, 1.061405429f}, t, f32x2{-1.453152027f, -1.453152027f});
+    p = __builtin_elementwise_fma(p, t, f32x2{1.421413741f, 1.421413741f});
+    p = __builtin_elementwise_fma(p, t, f32x2{-0.284496736f, -0.284496736f});
+    p = __builtin_elementwise_fma(p, t, f32x2{0.254829592f, 0.254829592f});
+    const f32x2 a = -z * z * 1.44269504088896340736f;
+    f32x2 e;
+    e[0] = __builtin_amdgcn_exp2f(a[0]);
+    e[1] = __builtin_amdgcn_exp2f(a[1]);
+    const f32x2 erf_abs = __builtin_elementwise_fma(-p * t, e, f32x2{1.0f, 1.0f});
+    f32x2 erf_v;
+    erf_v[0] = __builtin_copysignf(erf_abs[0], x[0]);
+    erf_v[1] = __builtin_copysignf(erf_abs[1], x[1]);
+    return 0.5f * x * (1.0f + erf_v);
+}
+__device__ __forceinline__ f32x4 gelu_erf4(const f32x4 v) {
+    const f32x2 lo = gelu_erf2(f32x2{v[0], v[1]}), hi = gelu_erf2(f32x2{v[2], v[3]});
+    return f32x4{lo[0], lo[1], hi[0], hi[1]};
+}
+
 }  // namespace m3r

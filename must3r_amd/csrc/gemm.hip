@@ -203,8 +203,8 @@ __device__ __forceinline__ void epilogue_row(const GemmArgs& p, void* const outp
         for (int q = 0; q < NF / 2; ++q) {
             f32x4 g0 = v[2 * q], g1 = v[2 * q + 1];
             if constexpr (EPI == EPI_STORE16_GELU) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) { g0[r] = gelu_erf(g0[r]); g1[r] = gelu_erf(g1[r]); }
+                g0 = gelu_erf4(g0);
+                g1 = gelu_erf4(g1);
             }
             const v4 h0 = cvt4_sat<T>(g0), h1 = cvt4_sat<T>(g1);
             unsigned a[2], b[2];
@@ -248,9 +248,7 @@ __device__ __forceinline__ void epilogue_row(const GemmArgs& p, void* const outp
         if constexpr (EPI == EPI_STORE16 || EPI == EPI_QKV_ROPE) {
             *reinterpret_cast<v4*>(reinterpret_cast<T*>(outp) + (size_t)m * p.ldc + n) = cvt4_sat<T>(v[j]);
         } else if constexpr (EPI == EPI_STORE16_GELU) {
-            f32x4 g;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) g[r] = gelu_erf(v[j][r]);
+            const f32x4 g = gelu_erf4(v[j]);
             *reinterpret_cast<v4*>(reinterpret_cast<T*>(outp) + (size_t)m * p.ldc + n) = cvt4_sat<T>(g);
         } else if constexpr (EPI == EPI_RESID_F32) {
             f32x4* o = reinterpret_cast<f32x4*>(reinterpret_cast<float*>(outp) + (size_t)m * p.ldc + n);
