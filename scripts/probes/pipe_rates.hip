@@ -170,6 +170,66 @@ void run_mfma(const _Float16* rnd, unsigned long long* cyc, float* sink) {
            256.0 * 8 * 32 * 16384 / us * 1e-6);
 }
 
+// r03: a K-tile whose DMA pieces are a MIX of 64-byte-row and 128-byte-row gathers (the split-weight 256 x 256 x 32 K-tile: activations 2 pieces of
+// 16 rows x 64 B per wave; weights hi+lo either 4 more such pieces, or -- with hi and lo interleaved per 32 k in memory -- 4 pieces of 8 rows x 128 B)
+template <int P64, int P128, int R, int M, int BAR>
+__global__ void __launch_bounds__(1024) probe_mix(const char* __restrict__ src, int iters, unsigned long long* cyc, float* sink, int stride) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int nw = blockDim.x >> 6;
+    constexpr int P = P64 + P128;
+    const char* base64 = src + (size_t)(blockIdx.x & 7) * (1 << 20) + (size_t)(lane / 4) * stride + (lane % 4) * 16;
+    const char* base128 = src + (size_t)(blockIdx.x & 7) * (1 << 20) + (size_t)(lane / 8) * stride + (lane % 8) * 16;
+    f32x4 acc[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+    f16x8 a = {1, 1, 1, 1, 1, 1, 1, 1}, b = {1, 1, 1, 1, 1, 1, 1, 1};
+    f16x8 rd[4];
+    for (int i = 0; i < 4; ++i) rd[i] = a;
+    const unsigned lbase = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds + lane * 16;
+    for (int it = 0; it < iters; ++it) {
+        const int slot = it & 1;
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            const int piece = (slot * P + p) * nw + wave;
+            const char* g = p < P64 ? base64 + ((it * 64) & (stride - 1)) + (size_t)((wave * P + p) * 16 % 448) * stride
+                                    : base128 + ((it * 128) & (stride - 1)) + (size_t)((wave * P + p) * 8 % 448) * stride;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)(lds + piece * 1024), 16, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            f16x8 v;
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(lbase + (unsigned)(wave * 4096)), "n"((r & 3) * 1024));
+            rd[r & 3] = v;
+        }
+        if (R) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int m = 0; m < M; ++m) acc[m & 3] = __builtin_amdgcn_mfma_f32_16x16x32_f16(rd[m & 3], b, acc[m & 3], 0, 0, 0);
+        if (P) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(P) : "memory");
+        if (BAR) __builtin_amdgcn_s_barrier();
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    float s = 0;
+    for (int i = 0; i < 4; ++i) s += acc[i][0] + (float)rd[i][0];
+    if (s == 12345.678f) sink[0] = s;
+}
+template <int P64, int P128, int R, int M, int BAR>
+void run_mix(const char* buf, unsigned long long* cyc, float* sink) {
+    const int iters = 4000;
+    const size_t ldsb = 150 * 1024;
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&probe_mix<P64, P128, R, M, BAR>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    probe_mix<P64, P128, R, M, BAR><<<256, 512, ldsb>>>(buf, 64, cyc, sink, 2048);
+    hipDeviceSynchronize();
+    hipEventRecord(e0);
+    probe_mix<P64, P128, R, M, BAR><<<256, 512, ldsb>>>(buf, iters, cyc, sink, 2048);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms = 0;
+    hipEventElapsedTime(&ms, e0, e1);
+    printf("8 waves: %d pieces of 64 B rows + %d pieces of 128 B rows per wave (%2d KB), %2d reads, %2d MFMAs per wave, barrier %d : %6.3f us/iter\n", P64, P128,
+           (P64 + P128) * 8, R, M, BAR, ms * 1e3 / iters);
+}
+
 template <int P, int R, int M, int BAR>
 void run(const char* buf, int nw, unsigned long long* cyc, float* sink, int stride = 0) {
     const int iters = 2008;
@@ -203,6 +263,10 @@ int main() {
         _Float16* rnd; hipMalloc(&rnd, 8192 * 2); hipMemcpy(rnd, h.data(), 8192 * 2, hipMemcpyHostToDevice);
         run_mfma<0>(rnd, cyc, sink); run_mfma<1>(rnd, cyc, sink); run_mfma<2>(rnd, cyc, sink); run_mfma<0>(rnd, cyc, sink);
     }
+    printf("-- split-weight K-tile (256 x 256 x 32, hi + lo): weight pieces as 64 B rows (today) or as 128 B rows (hi / lo interleaved per 32 k)\n");
+    run_mix<6, 0, 0, 0, 1>(buf, cyc, sink); run_mix<2, 4, 0, 0, 1>(buf, cyc, sink);
+    run_mix<6, 0, 16, 64, 1>(buf, cyc, sink); run_mix<2, 4, 16, 64, 1>(buf, cyc, sink);
+    run_mix<6, 0, 16, 64, 0>(buf, cyc, sink); run_mix<2, 4, 16, 64, 0>(buf, cyc, sink);
     // r03: the chip-filling 256 x 256 x 32 K-tile (8 waves: 4 DMA pieces, 12 fragment reads, 32 (plain) / 64 (split: 6 pieces, 16 reads) MFMAs per wave)
     printf("-- gemm256 K-tile mix, 8 waves\n");
     run<0, 0, 32, 1>(buf, 8, cyc, sink, 2048);
