@@ -287,14 +287,15 @@ __device__ __forceinline__ void epilogue_row(const GemmArgs& p, void* const outp
 // of that batch's stores.  Values and rounding are those of epilogue_row.
 template <class T, int EPI, int NF, int MF, int BI, bool LN, class LnF>
 __device__ __forceinline__ void epilogue_tile(const GemmArgs& p, void* const outp, const float* __restrict__ bias, const int m_first,
-                                              const int nw0, const int fg, f32x4 (&acc)[MF][NF], LnF lnf) {
+                                              const int nw0, const int fg, f32x4 (&acc)[MF][NF], LnF lnf, const f32x4* bpre = nullptr) {
     static_assert(MF % BI == 0, "batches of BI row fragments");
     const int nb = nw0 + fg * 4;
     const bool nobias = (EPI == EPI_F32 || EPI == EPI_HEAD) && p.accumulate;
     f32x4 b[NF], b2[NF];
 #pragma unroll
     for (int j = 0; j < NF; ++j) {
-        b[j] = (bias != nullptr && !nobias) ? *reinterpret_cast<const f32x4*>(bias + nb + j * 16) : f32x4{0.f, 0.f, 0.f, 0.f};
+        if (bpre != nullptr) b[j] = bpre[j];   // loaded by the caller in front of its K loop (epilogue_bias): no round trip here
+        else b[j] = (bias != nullptr && !nobias) ? *reinterpret_cast<const f32x4*>(bias + nb + j * 16) : f32x4{0.f, 0.f, 0.f, 0.f};
         b2[j] = f32x4{0.f, 0.f, 0.f, 0.f};
         if constexpr (EPI == EPI_F32) {
             if (!p.accumulate && p.bias2 != nullptr) b2[j] = *reinterpret_cast<const f32x4*>(p.bias2 + nb + j * 16);
@@ -357,6 +358,14 @@ __device__ __forceinline__ void epilogue_tile(const GemmArgs& p, void* const out
             epilogue_row<T, EPI, NF, LN>(p, outp, bias, m, nw0, fg, v, &pre[ii], mu, rstd, b2, &rp[ii]);
         }
     }
+}
+// the bias columns of a lane, as epilogue_tile loads them -- for callers that can afford NF x 4 registers across their K loop
+template <int EPI, int NF>
+__device__ __forceinline__ void epilogue_bias(const GemmArgs& p, const float* __restrict__ bias, const int nw0, const int fg, f32x4 (&b)[NF]) {
+    const bool nobias = (EPI == EPI_F32 || EPI == EPI_HEAD) && p.accumulate;
+#pragma unroll
+    for (int j = 0; j < NF; ++j)
+        b[j] = (bias != nullptr && !nobias) ? *reinterpret_cast<const f32x4*>(bias + nw0 + fg * 4 + j * 16) : f32x4{0.f, 0.f, 0.f, 0.f};
 }
 struct NoLnFold {
     __device__ __forceinline__ void operator()(int, float&, float&) const {}
@@ -953,6 +962,8 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
         w_lane[h] = lds0 + (unsigned)(BM * 128 + rw * 128 + swz(rw, h * 4 + fg) * 16);
     }
     constexpr unsigned STAGEB = STAGE * 2;
+    f32x4 bpre[NF];   // bias columns: loaded here, in front of the first DMA, instead of as a round trip between the K loop and the stores
+    epilogue_bias<EPI, NF>(p, bias, n0 + wc * WN, fg, bpre);
 
 #pragma unroll
     for (int q = 0; q < NP; ++q) piece(q, 0, 0);
@@ -1070,7 +1081,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
     if constexpr ((ABL & 32) != 0) {   // timing ablation: no epilogue
         if (acc[0][0][0] != 12345.678f) return;
     }
-    epilogue_tile<T, EPI, NF, MF, 4, false>(p, outp, bias, m0 + wr * 128 + fr, n0 + wc * WN, fg, acc, NoLnFold{});
+    epilogue_tile<T, EPI, NF, MF, 4, false>(p, outp, bias, m0 + wr * 128 + fr, n0 + wc * WN, fg, acc, NoLnFold{}, bpre);
 }
 
 template <class T, int EPI, int WS, int BN, int ABL = 0>
