@@ -301,11 +301,23 @@ __device__ __forceinline__ void epilogue_tile(const GemmArgs& p, void* const out
             if (!p.accumulate && p.bias2 != nullptr) b2[j] = *reinterpret_cast<const f32x4*>(p.bias2 + nb + j * 16);
         }
     }
+    // RoPE: the positions of ALL the wave tile's rows in one go (16 bytes per row), so that a batch costs one round trip (its table entries), not two
+    long long py[MF], px[MF];
+    if constexpr (EPI == EPI_QKV_ROPE) {
+        if (nw0 < p.rope_cols) {
+#pragma unroll
+            for (int i = 0; i < MF; ++i) {
+                const int m = m_first + i * 16;
+                const int mm = m < p.M ? m : p.M - 1;
+                py[i] = p.pos[(size_t)mm * 2 + 0];
+                px[i] = p.pos[(size_t)mm * 2 + 1];
+            }
+        }
+    }
 #pragma unroll
     for (int i0 = 0; i0 < MF; i0 += BI) {
         EpiPre<NF> pre[BI];
         RopePre<NF> rp[BI];
-        long long py[BI], px[BI];
 #pragma unroll
         for (int ii = 0; ii < BI; ++ii) {
             const int m = m_first + (i0 + ii) * 16;
@@ -317,12 +329,6 @@ __device__ __forceinline__ void epilogue_tile(const GemmArgs& p, void* const out
                     pre[ii].x[j] = ld_global<f32x4>(reinterpret_cast<const float*>(outp) + (size_t)mm * p.ldc + nb + j * 16);
                 } else if constexpr (EPI == EPI_F32) {
                     if (p.accumulate) pre[ii].x[j] = ld_global<f32x4>(reinterpret_cast<const float*>(outp) + (size_t)mm * p.ldc + nb + j * 16);
-                }
-            }
-            if constexpr (EPI == EPI_QKV_ROPE) {
-                if (nw0 < p.rope_cols) {
-                    py[ii] = p.pos[(size_t)mm * 2 + 0];
-                    px[ii] = p.pos[(size_t)mm * 2 + 1];
                 }
             }
         }
@@ -337,7 +343,7 @@ __device__ __forceinline__ void epilogue_tile(const GemmArgs& p, void* const out
 #pragma unroll
                     for (int q = 0; q < NF / 2; ++q) {
                         const int nh = nw0 + q * 32;
-                        int pp = (int)(((nh >> 5) & 1) ? px[ii] : py[ii]);
+                        int pp = (int)(((nh >> 5) & 1) ? px[i0 + ii] : py[i0 + ii]);
                         pp = pp < 0 ? 0 : (pp >= p.rope_npos ? p.rope_npos - 1 : pp);
                         const float* tb = p.rope_tab + ((size_t)pp * 16 + fg * 4) * 2;
                         rp[ii].t0[q] = *reinterpret_cast<const f32x4*>(tb);
