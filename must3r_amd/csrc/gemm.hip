@@ -301,6 +301,37 @@ __device__ __forceinline__ void epilogue_tile(const GemmArgs& p, void* const out
             if (!p.accumulate && p.bias2 != nullptr) b2[j] = *reinterpret_cast<const f32x4*>(p.bias2 + nb + j * 16);
         }
     }
+    if constexpr (EPI == EPI_RESID_F32 && !LN && MF % 2 == 0) {
+        // Whole wave tile inside the matrix (wave-uniform): straight-line code, so the compiler counts vmcnt exactly -- the old fp32 rows of the NEXT
+        // pair of row fragments are requested in front of this pair's stores and waited for with those stores still in flight (vmcnt(N) waits for
+        // the older loads only).  One exposed round trip per tile instead of one per batch.  Same arithmetic as epilogue_row: x + (acc + bias).
+        const int lane16 = (int)__lane_id() & 15;
+        if (m_first - lane16 + MF * 16 - 1 < p.M) {
+            float* const o0 = reinterpret_cast<float*>(outp) + (size_t)m_first * p.ldc + nb;
+            f32x4 x[2][2][NF];
+            auto ld = [&](int pair, int slot) {
+#pragma unroll
+                for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+                    for (int j = 0; j < NF; ++j) x[slot][ii][j] = ld_global<f32x4>(o0 + (size_t)((2 * pair + ii) * 16) * p.ldc + j * 16);
+            };
+            ld(0, 0);
+#pragma unroll
+            for (int pair = 0; pair < MF / 2; ++pair) {
+                if (pair + 1 < MF / 2) ld(pair + 1, (pair + 1) & 1);
+#pragma unroll
+                for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+                    for (int j = 0; j < NF; ++j) {
+                        f32x4 v = acc[2 * pair + ii][j];
+                        v += b[j];
+                        const f32x4 xn = x[pair & 1][ii][j] + v;
+                        st_global<f32x4>(o0 + (size_t)((2 * pair + ii) * 16) * p.ldc + j * 16, xn);
+                    }
+            }
+            return;
+        }
+    }
     // RoPE: the positions of ALL the wave tile's rows in one go (16 bytes per row), so that a batch costs one round trip (its table entries), not two
     long long py[MF], px[MF];
     if constexpr (EPI == EPI_QKV_ROPE) {
