@@ -256,3 +256,49 @@ def test_label_run_mirror_is_dropped_when_the_labels_are_edited_in_place():
     assert l3.tolist() == [[0, 0, 1, 1]] and v3[0].flatten().tolist() == [0, 1, 2, 3]
     l4 = E.restore_label_in_mem(l2, 5, 2)         # the helper keeps its own mirror fresh
     assert l4.tolist() == [[0, 0, 5, 5]] and E._label_runs(l4) == [(0, 2), (5, 2)]
+
+
+def test_epilogue_lane_exchange_gives_whole_line_stores():
+    """Pure-numpy model of the 16-bit store path of epilogue_row (gemm.hip): after v_permlane32_swap, v_permlane16_swap and the DPP row rotation by 8
+    under bank masks, lane l stores 16 bytes = 8 consecutive columns, eight lanes cover one 128-byte row segment, and the 64 lanes together
+    cover every (row, column) of the 16 x 64 fragment block exactly once."""
+    import numpy as np
+    lanes = np.arange(64)
+    fr, fg = lanes & 15, lanes >> 4
+    # value held by lane l in fragment j, dword d (two 16-bit outputs): identify it by (row, col of its first output)
+    def src(j, d):
+        return np.stack((fr, j * 16 + fg * 4 + d * 2), -1)            # [64, 2]
+    def permlane32_swap(a, b):   # a' = {a.lo32, b.lo32}, b' = {a.hi32, b.hi32}
+        return np.concatenate((a[:32], b[:32])), np.concatenate((a[32:], b[32:]))
+    def permlane16_swap(a, b):   # odd 16-lane rows of a <-> even rows of b
+        a2, b2 = a.copy(), b.copy()
+        for r in (1, 3):
+            a2[r * 16:(r + 1) * 16] = b[(r - 1) * 16:r * 16]
+            b2[(r - 1) * 16:r * 16] = a[r * 16:(r + 1) * 16]
+        return a2, b2
+    def dpp_ror8(old, srcv, bank_mask):   # row_ror:8 within each 16-lane row, written only to lanes whose 4-lane bank is enabled
+        out = old.copy()
+        for l in range(64):
+            if bank_mask >> ((l & 15) >> 2) & 1:
+                out[l] = srcv[(l & ~15) | ((l + 8) & 15)]
+        return out
+    o = []
+    for q in range(2):
+        regs = [None] * 4
+        for d in range(2):
+            s0, s1 = permlane32_swap(src(2 * q, d), src(2 * q + 1, d))
+            t0, t1 = permlane16_swap(s0, s1)
+            regs[d], regs[2 + d] = t0, t1
+        o.append(regs)
+    x = [dpp_ror8(o[0][d], o[1][d], 0xC) for d in range(4)]
+    y = [dpp_ror8(o[1][d], o[0][d], 0x3) for d in range(4)]
+    seen = set()
+    for name, regs, row_add in (("x", x, 0), ("y", y, 8)):
+        for l in range(64):
+            row = (l & 7) + row_add
+            col0 = ((l >> 5) & 1) * 16 + ((l >> 4) & 1) * 8 + ((l >> 3) & 1) * 32
+            for d in range(4):
+                r, c = regs[d][l]
+                assert r == row and c == col0 + 2 * d, (name, l, d, (r, c), (row, col0 + 2 * d))
+                seen.add((r, c)); seen.add((r, c + 1))
+    assert len(seen) == 16 * 64
