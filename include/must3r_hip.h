@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MUST3R_HIP_ABI_VERSION 5
+#define MUST3R_HIP_ABI_VERSION 6
 
 typedef struct must3r_hip_ctx must3r_hip_ctx;
 
@@ -131,6 +131,11 @@ int must3r_hip_decode(must3r_hip_ctx* ctx, const must3r_hip_decode_args* args, v
  *   -> pts3d [npix,3], pts3d_local [npix,3], conf [npix] */
 int must3r_hip_postprocess(const float* pointmaps, float* pts3d, float* pts3d_local, float* conf, size_t npix,
                            void* stream);
+/* the same with the activation named (ABI 6): ActivationType of must3r/model/blocks/head.py:8-21 -- NORM_EXP as above, LINEAR leaves
+ * channels 0:3 / 3:6 as they are; conf = 1 + exp(ch 6) in both (engine/inference.py:26-27). */
+enum { MUST3R_ACT_NORM_EXP = 0, MUST3R_ACT_LINEAR = 1 };
+int must3r_hip_postprocess_act(const float* pointmaps, int activation, float* pts3d, float* pts3d_local, float* conf, size_t npix,
+                               void* stream);
 
 /* postprocess(..., compute_cam=True) (engine/inference.py:16-48), SURVEY.md section 8f rank 1: the activation above
  * plus, per view, focal = dust3r estimate_focal_knowing_depth(pts3d_local, pp=(W/2,H/2), 'weiszfeld')
@@ -141,6 +146,8 @@ int must3r_hip_postprocess(const float* pointmaps, float* pts3d, float* pts3d_lo
 size_t must3r_hip_postprocess_cam_scratch_bytes(int n_views, int H, int W);
 int must3r_hip_postprocess_cam(const float* pointmaps, int n_views, int H, int W, float* pts3d, float* pts3d_local,
                                float* conf, float* focal, float* c2w, void* scratch, size_t scratch_bytes, void* stream);
+int must3r_hip_postprocess_cam_act(const float* pointmaps, int activation, int n_views, int H, int W, float* pts3d, float* pts3d_local,
+                                   float* conf, float* focal, float* c2w, void* scratch, size_t scratch_bytes, void* stream);
 
 /* Retrieval front-end on the encoder tokens, SURVEY.md section 8f rank 4 (retrieval/model.py).
  * must3r_hip_affine: out[M,N] fp32 = (A[M,K] - sub[K]) . B + bias[N] + resid[M,N]; with is_double the subtraction, the
@@ -227,7 +234,10 @@ int must3r_hip_debug_tr_probe(void* out256_i16_dev, void* stream);
 
 /* timing hooks used by bench.py: per-stage HIP-event timers recorded on the call's stream */
 int must3r_hip_set_profiling(must3r_hip_ctx* ctx, int enabled);
-/* returns the number of records written (<= max); each record: name (<=31 chars), milliseconds, flops */
+/* returns the number of records written (<= max); each record: name (<=31 chars), milliseconds, flops.
+ * First the kernel CLASSES (gemm128, gemm64, attn_self, attn_cross, attn_combine, layernorm, misc), then (ABI 6) one row per kernel
+ * symbol, names prefixed "k:" -- GEMMs "k:<family>/e<epilogue>/w<1 plain|2 split>/n<tile width>", attention "k:attn3/q32/cross" ... --
+ * so that every row can be matched with one symbol of a rocprofv3 --kernel-trace of the same command. */
 typedef struct must3r_hip_prof_record { char name[32]; double ms; double flops; int64_t calls; } must3r_hip_prof_record;
 int must3r_hip_get_profile(must3r_hip_ctx* ctx, must3r_hip_prof_record* out, int max, int reset);
 

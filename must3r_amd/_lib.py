@@ -15,7 +15,8 @@ ATTN_FP8 = 0x100   # OR-able: fp8 (e4m3) attention operands, include/must3r_hip.
 MEM_KV, MEM_NORM_Y, MEM_RAW = 0, 1, 2
 PART_ENCODER, PART_DECODER = 1, 2
 EPI_STORE16, EPI_STORE16_GELU, EPI_QKV_ROPE, EPI_RESID_F32, EPI_F32, EPI_HEAD = range(6)
-ABI_VERSION = 5
+ABI_VERSION = 6
+ACT_NORM_EXP, ACT_LINEAR = 0, 1
 
 # every symbol include/must3r_hip.h declares
 EXPORTS = (
@@ -28,6 +29,7 @@ EXPORTS = (
     "must3r_hip_nn_query", "must3r_hip_quadrant_ids",
     "must3r_hip_affine", "must3r_hip_row_norm", "must3r_hip_l2_normalize", "must3r_hip_layernorm_act_f32", "must3r_hip_topk_gather", "must3r_hip_weighted_spoc",
     "must3r_hip_op_gemm_lnfold",
+    "must3r_hip_postprocess_act", "must3r_hip_postprocess_cam_act",
 )
 
 
@@ -83,6 +85,7 @@ def load():
     lib.must3r_hip_encode.argtypes = [vp, i32, vp, i32, i32, i32, vp, vp, vp]
     lib.must3r_hip_decode.argtypes = [vp, C.POINTER(DecodeArgs), vp]
     lib.must3r_hip_postprocess.argtypes = [vp, vp, vp, vp, C.c_size_t, vp]
+    lib.must3r_hip_postprocess_act.argtypes = [vp, i32, vp, vp, vp, C.c_size_t, vp]
     lib.must3r_hip_op_gemm.argtypes = [i32, i32, vp, vp, vp, vp, i32, i32, i32, i32, i32,
                                        vp, vp, i32, i32, vp, i32, i32, i32, i32, i32, i32, i32, vp]
     lib.must3r_hip_rope_table.argtypes = [fp, fp, i32, vp]
@@ -96,6 +99,7 @@ def load():
     lib.must3r_hip_debug_tr_probe.argtypes = [vp, vp]
     lib.must3r_hip_set_profiling.argtypes = [vp, i32]
     lib.must3r_hip_postprocess_cam.argtypes = [vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, C.c_size_t, vp]
+    lib.must3r_hip_postprocess_cam_act.argtypes = [vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, C.c_size_t, vp]
     lib.must3r_hip_affine.argtypes = [i32, vp, vp, vp, i32, vp, vp, vp, i32, i32, i32, vp]
     lib.must3r_hip_row_norm.argtypes = [vp, i32, i32, vp, vp]
     lib.must3r_hip_l2_normalize.argtypes = [vp, C.c_int64, i32, C.c_int64, vp, vp]
@@ -155,8 +159,8 @@ class Context:
         check(self.lib.must3r_hip_set_profiling(self.handle, 1 if on else 0))
 
     def get_profile(self, reset=True):
-        recs = (ProfRecord * 16)()
-        n = self.lib.must3r_hip_get_profile(self.handle, recs, 16, 1 if reset else 0)
+        recs = (ProfRecord * 160)()   # 7 class rows + one row per kernel symbol (names prefixed "k:")
+        n = self.lib.must3r_hip_get_profile(self.handle, recs, 160, 1 if reset else 0)
         return {recs[i].name.decode(): {"ms": recs[i].ms, "flops": recs[i].flops, "calls": recs[i].calls}
                 for i in range(n)}
 

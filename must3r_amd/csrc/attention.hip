@@ -936,6 +936,10 @@ int launch_tr_probe(short* out, hipStream_t s) {
     return hipGetLastError() == hipSuccess ? 0 : 1;
 }
 
+// which main kernel the last launch_attention_phase(.., 1, ..) of this thread ran (profile rows are keyed by it: one rocprofv3 symbol each)
+static thread_local const char* g_attn_pick = "";
+const char* attention_last_kernel() { return g_attn_pick; }
+
 // phase 0: (m,l) pre-fill (split-KV with holes only), 1: main kernel, 2: combine (split-KV only)
 int launch_attention_phase(DType dt, const AttnArgs& a_in, int phase, hipStream_t s, const char** err) {
     AttnArgs a = a_in;
@@ -996,6 +1000,7 @@ int launch_attention_phase(DType dt, const AttnArgs& a_in, int phase, hipStream_
         // the same per-query arithmetic, i.e. bit-identical batched and per-view calls -- stays the 16-bit path, and attn4 is the
         // fp8 (MX-scaled Q K^T) path: 983-1003 TF/s on the render shape.  M3R_ATTN=4 (experiment builds) runs its 16-bit instantiation.
 #define M3R_LAUNCH_ATTN(KERNEL) hipLaunchKernelGGL(KERNEL, dim3(grid), dim3(256), 0, s, a, nqb, ngrp, nsplit)
+        g_attn_pick = a.fp8 ? "attn4f8" : (small ? "attn3/q16" : "attn3/q32");
         if (a.fp8) {   // e4m3 Q / K through the MX-scaled 32x32x64 MFMA, 16-bit P / V
             if (dt == DT_BF16) M3R_LAUNCH_ATTN((attn4_kernel<bf16_t, 1, true>)); else M3R_LAUNCH_ATTN((attn4_kernel<f16_t, 1, true>));
         } else {

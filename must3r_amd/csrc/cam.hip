@@ -33,6 +33,7 @@ struct CamArgs {
     double* partial;      // [V][G][16] per-block partial registration sums (summed by cam_solve_kernel)
     dbl2* slots;       // [V][3][G] pair exchange slots, all-ones before the launch
     int V, G, H, W, ppt;
+    int linear;           // ActivationType.LINEAR (head.py:13-21): channels 0:3 / 3:6 pass through; conf = 1 + exp(ch 6) either way
 };
 
 __device__ __forceinline__ void norm_exp3c(const float* v, float* o) {
@@ -255,8 +256,13 @@ __global__ void __launch_bounds__(CAM_T) cam_kernel(const CamArgs p) {
 #pragma unroll
             for (int c = 0; c < 7; ++c) r[c] = src[c];
             float y[3], x[3];
-            norm_exp3c(r, y);          // pts3d (world)
-            norm_exp3c(r + 3, x);      // pts3d_local (camera)
+            if (p.linear) {            // block-uniform
+#pragma unroll
+                for (int k = 0; k < 3; ++k) { y[k] = r[k]; x[k] = r[3 + k]; }
+            } else {
+                norm_exp3c(r, y);          // pts3d (world)
+                norm_exp3c(r + 3, x);      // pts3d_local (camera)
+            }
             const float conf = 1.0f + expf(r[6]);
             float* o3 = p.p3 + (base + i) * 3;
             float* ol = p.pl + (base + i) * 3;
@@ -335,7 +341,7 @@ size_t cam_scratch_bytes(int n_views, int H, int W) {
     return (size_t)n_views * gmax * (3 * 16 + 16 * 8) + (size_t)n_views * 8 + 256;
 }
 
-int launch_postprocess_cam(const float* pm, int n_views, int H, int W, float* p3, float* pl, float* cf, float* focal,
+int launch_postprocess_cam(const float* pm, int linear, int n_views, int H, int W, float* p3, float* pl, float* cf, float* focal,
                            float* c2w, void* scratch, size_t scratch_bytes, hipStream_t s, const char** err) {
     if (n_views <= 0) return 0;
     const int P = H * W;
@@ -374,7 +380,7 @@ int launch_postprocess_cam(const float* pm, int n_views, int H, int W, float* p3
         a.sums = sums + v0;
         a.partial = partial + (size_t)v0 * gmax * 16;
         a.slots = slot_base + (size_t)v0 * 3 * gmax;
-        a.V = nv; a.G = G; a.H = H; a.W = W;
+        a.V = nv; a.G = G; a.H = H; a.W = W; a.linear = linear ? 1 : 0;
         a.ppt = (P + G * CAM_T - 1) / (G * CAM_T);
         void* args[] = {&a};
         if (hipLaunchCooperativeKernel(reinterpret_cast<const void*>(cam_kernel), dim3(nv * G), dim3(CAM_T), args, 0, s) != hipSuccess) {

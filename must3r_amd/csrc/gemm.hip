@@ -12,6 +12,7 @@
 //   ds_read_b128 side (same involution).
 // * blockIdx -> tile mapping is XCD-aware: each XCD (blockIdx % 8) walks a contiguous chunk of the tile grid in
 //   grouped order (8 row-blocks x all column-blocks) so the panels its resident blocks share stay in its L2.
+#include <cstdio>
 #include <cstdlib>
 #include <type_traits>
 #include "common.hpp"
@@ -1553,6 +1554,12 @@ static int launch_96(const GemmArgs& a, hipStream_t s) {
     return launch_96pf<T, EPI, 1>(a, s);   // the software-pipelined K loop (the lock-step form measured 3 % slower: profiles/r02_gemm96_ab.txt)
 }
 
+// which kernel the last launch_gemm of this thread picked: "<family>/e<EPI>/w<WS>/n<BN>" = one symbol of a rocprofv3 kernel trace
+// (must3r_hip_get_profile reports per-symbol times under these names so that every row can be matched with the trace)
+static thread_local char g_gemm_pick[32] = "";
+static void pick_name(const char* fam, int epi, int ws, int bn) { snprintf(g_gemm_pick, sizeof(g_gemm_pick), "%s/e%d/w%d/n%d", fam, epi, ws, bn); }
+const char* gemm_last_kernel() { return g_gemm_pick; }
+
 // Tile selection (measured on MI355X, scripts/bench_gemm.py): two resident blocks per CU beat every larger tile that
 // leaves one (128x128 3-stage, 256x128 with 4 or 8 waves: 465-613 TF/s vs 644 TF/s on the scene's big-batch shapes).
 //   plain weights : 128x128x64, 2 stages (64 KB)  for chip-filling grids, 64x64x64 4-stage ring (64 KB) otherwise
@@ -1656,20 +1663,20 @@ static int launch_epi(const GemmArgs& a, hipStream_t s, const char** err) {
             constexpr bool gelu_occ2 = true;
             if (a.ln_stats != nullptr) {
                 // LN-fold consumers: the kernels that carry the row-statistics prologue, whatever the tile count
-                if constexpr (EPI == EPI_STORE16_GELU) rc = a.N % 96 == 0 ? launch_96<T, EPI>(a, s) : 1;
-                else if constexpr (EPI == EPI_STORE16) rc = a.N % 48 == 0 ? launch_48<T, EPI, 2>(a, s) : 1;
-                else if constexpr (EPI == EPI_QKV_ROPE) rc = launch_cfg<T, 64, 64, 2, 2, EPI, 3, 2>(a, s);
+                if constexpr (EPI == EPI_STORE16_GELU) { pick_name("g96", EPI, 2, 96); rc = a.N % 96 == 0 ? launch_96<T, EPI>(a, s) : 1; }
+                else if constexpr (EPI == EPI_STORE16) { pick_name("g48", EPI, 2, 48); rc = a.N % 48 == 0 ? launch_48<T, EPI, 2>(a, s) : 1; }
+                else if constexpr (EPI == EPI_QKV_ROPE) { pick_name("g64", EPI, 2, 64); rc = launch_cfg<T, 64, 64, 2, 2, EPI, 3, 2>(a, s); }
                 else rc = 1;
-            } else if (EPI == EPI_STORE16_GELU && gelu_occ2 && mode != 0 && ok128 && t128 >= 1024) rc = launch_256<T, EPI, 2, 128, 2>(a, s);
-            else if (EPI != EPI_HEAD && use_96(a, nb)) rc = launch_96<T, EPI == EPI_HEAD ? EPI_STORE16 : EPI>(a, s);
-            else if (EPI != EPI_QKV_ROPE && EPI != EPI_HEAD && use_48(a, nb)) rc = launch_48<T, EPI == EPI_QKV_ROPE || EPI == EPI_HEAD ? EPI_STORE16 : EPI, 2>(a, s);
-            else if (pick != 0 && g256k_mode() >= 2 && ok128) rc = launch_256k<T, EPI, 2, 128>(a, s);
-            else if (pick == 256) rc = launch_256<T, EPI, 2, 256>(a, s);
-            else if (pick == 192) rc = launch_256<T, EPI == EPI_QKV_ROPE ? EPI_STORE16 : EPI, 2, 192>(a, s);
-            else if (pick == 128) rc = launch_256<T, EPI, 2, 128>(a, s);   // (two blocks per CU measured slower for every epilogue but the GELU one)
-            else if (tiles >= min_big(true) && !lnp) rc = launch_cfg<T, 128, 64, 2, 2, EPI, 2, 2>(a, s);
-            else if (small8((long)((a.M + 63) / 64) * (a.N / 64) * nb)) rc = launch_cfg<T, 64, 64, SMALL_WGM, 2, EPI, SMALL8_NST_SPLIT, 2, 64, 1>(a, s);
-            else rc = launch_cfg<T, 64, 64, 2, 2, EPI, 3, 2>(a, s);
+            } else if (EPI == EPI_STORE16_GELU && gelu_occ2 && mode != 0 && ok128 && t128 >= 1024) { pick_name("g256o2", EPI, 2, 128); rc = launch_256<T, EPI, 2, 128, 2>(a, s); }
+            else if (EPI != EPI_HEAD && use_96(a, nb)) { pick_name("g96", EPI, 2, 96); rc = launch_96<T, EPI == EPI_HEAD ? EPI_STORE16 : EPI>(a, s); }
+            else if (EPI != EPI_QKV_ROPE && EPI != EPI_HEAD && use_48(a, nb)) { pick_name("g48", EPI, 2, 48); rc = launch_48<T, EPI == EPI_QKV_ROPE || EPI == EPI_HEAD ? EPI_STORE16 : EPI, 2>(a, s); }
+            else if (pick != 0 && g256k_mode() >= 2 && ok128) { pick_name("g256k", EPI, 2, 128); rc = launch_256k<T, EPI, 2, 128>(a, s); }
+            else if (pick == 256) { pick_name("g256", EPI, 2, 256); rc = launch_256<T, EPI, 2, 256>(a, s); }
+            else if (pick == 192) { pick_name("g256", EPI, 2, 192); rc = launch_256<T, EPI == EPI_QKV_ROPE ? EPI_STORE16 : EPI, 2, 192>(a, s); }
+            else if (pick == 128) { pick_name("g256", EPI, 2, 128); rc = launch_256<T, EPI, 2, 128>(a, s); }   // (two blocks per CU measured slower for every epilogue but the GELU one)
+            else if (tiles >= min_big(true) && !lnp) { pick_name("g128", EPI, 2, 64); rc = launch_cfg<T, 128, 64, 2, 2, EPI, 2, 2>(a, s); }
+            else if (small8((long)((a.M + 63) / 64) * (a.N / 64) * nb)) { pick_name("g64p", EPI, 2, 64); rc = launch_cfg<T, 64, 64, SMALL_WGM, 2, EPI, SMALL8_NST_SPLIT, 2, 64, 1>(a, s); }
+            else { pick_name("g64", EPI, 2, 64); rc = launch_cfg<T, 64, 64, 2, 2, EPI, 3, 2>(a, s); }
         } else {
             *err = "gemm: split weights are only built for fp16";
             return 1;
@@ -1681,14 +1688,15 @@ static int launch_epi(const GemmArgs& a, hipStream_t s, const char** err) {
         const bool ok256 = a.N % 256 == 0 && a.K % 32 == 0;
         if (a.ln_stats != nullptr) {
             // LN-fold consumers on plain weights (the Mlp fc1 of a one-view update in MUST3R_F16_WA mode): the 64 x 64 ring kernel
-            if constexpr (EPI == EPI_STORE16_GELU || EPI == EPI_STORE16 || EPI == EPI_QKV_ROPE) rc = launch_cfg<T, 64, 64, 2, 2, EPI, 4, 1>(a, s);
+            if constexpr (EPI == EPI_STORE16_GELU || EPI == EPI_STORE16 || EPI == EPI_QKV_ROPE) { pick_name("g64", EPI, 1, 64); rc = launch_cfg<T, 64, 64, 2, 2, EPI, 4, 1>(a, s); }
             else rc = 1;
         } else if (EPI != EPI_QKV_ROPE && EPI != EPI_HEAD && sizeof(T) == 2 && use_48(a, nb)) {
+            pick_name("g48", EPI, 1, 48);
             rc = launch_48<T, EPI == EPI_QKV_ROPE || EPI == EPI_HEAD ? EPI_STORE16 : EPI, 1>(a, s);   // N = 768 one-view launches: 256 tiles of 48 x 48
-        } else if (ok256 && (mode == 2 || (mode == 1 && t256 >= 200 && fill256(t256) >= 80))) rc = g256k_mode() >= 1 ? launch_256k<T, EPI, 1, 256>(a, s) : launch_256<T, EPI, 1, 256>(a, s);
-        else if (n128 && tiles128 >= min_big(false) && !lnp) rc = launch_cfg<T, 128, 128, 2, 2, EPI, 2, 1>(a, s);
-        else if (small8((long)((a.M + 63) / 64) * (a.N / 64) * nb)) rc = launch_cfg<T, 64, 64, SMALL_WGM, 2, EPI, SMALL8_NST_PLAIN, 1, 64, 1>(a, s);
-        else rc = launch_cfg<T, 64, 64, 2, 2, EPI, 4, 1>(a, s);
+        } else if (ok256 && (mode == 2 || (mode == 1 && t256 >= 200 && fill256(t256) >= 80))) { pick_name(g256k_mode() >= 1 ? "g256k" : "g256", EPI, 1, 256); rc = g256k_mode() >= 1 ? launch_256k<T, EPI, 1, 256>(a, s) : launch_256<T, EPI, 1, 256>(a, s); }
+        else if (n128 && tiles128 >= min_big(false) && !lnp) { pick_name("g128", EPI, 1, 128); rc = launch_cfg<T, 128, 128, 2, 2, EPI, 2, 1>(a, s); }
+        else if (small8((long)((a.M + 63) / 64) * (a.N / 64) * nb)) { pick_name("g64p", EPI, 1, 64); rc = launch_cfg<T, 64, 64, SMALL_WGM, 2, EPI, SMALL8_NST_PLAIN, 1, 64, 1>(a, s); }
+        else { pick_name("g64", EPI, 1, 64); rc = launch_cfg<T, 64, 64, 2, 2, EPI, 4, 1>(a, s); }
     }
     if (rc) *err = "gemm: kernel launch failed";
     return rc;

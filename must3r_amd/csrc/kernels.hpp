@@ -75,6 +75,8 @@ struct GemmArgs {
 
 // returns 0 on success, non-zero (and sets *err) on an unsupported shape
 int launch_gemm(DType dt, Epi epi, const GemmArgs& a, hipStream_t s, const char** err);
+// the kernel the calling thread's last launch_gemm picked: "<family>/e<EPI>/w<WS>/n<BN>" (one symbol of a kernel trace)
+const char* gemm_last_kernel();
 
 // ---------------------------------------------------------------------------------------------
 // fused softmax attention, head dim 64, flash-style (no N x M score matrix in HBM)
@@ -123,6 +125,7 @@ int launch_attention(DType dt, const AttnArgs& a, hipStream_t s, const char** er
 bool attention_is_small(int nviews, int heads, int max_nq, int nsplit);
 // the three launches of a split-KV attention, separately (profiling): (m,l) pre-fill, main kernel, combine
 int launch_attention_phase(DType dt, const AttnArgs& a, int phase, hipStream_t s, const char** err);
+const char* attention_last_kernel();   // main kernel of the calling thread's last phase-1 launch
 
 // ---------------------------------------------------------------------------------------------
 // row / elementwise kernels
@@ -159,8 +162,8 @@ int launch_quant8(DType dt, const void* in16, int ld_in, void* out8, int ld_out,
                   size_t rows, int cols, int tail_cols, hipStream_t s, const char** err);
 // pos int64 [V, gh*gw, 2] = (y, x) row-major grid
 int launch_fill_pos(int64_t* pos, int V, int gh, int gw, hipStream_t s, const char** err);
-// pointmaps [npix,7] fp32 -> pts3d [npix,3], pts3d_local [npix,3], conf [npix]
-int launch_postprocess(const float* pm, float* pts3d, float* pts3d_local, float* conf, size_t npix, hipStream_t s,
+// pointmaps [npix,7] fp32 -> pts3d [npix,3], pts3d_local [npix,3], conf [npix]; linear: ActivationType.LINEAR instead of NORM_EXP
+int launch_postprocess(const float* pm, int linear, float* pts3d, float* pts3d_local, float* conf, size_t npix, hipStream_t s,
                        const char** err);
 // retrieval front-end on the encoder tokens (retrieval/model.py:59-101,165-183); retrieval.hip
 int launch_gemmx(int is_double, const float* A, const void* sub, const void* B, int b_transposed, const void* bias, const float* resid,
@@ -177,7 +180,7 @@ int launch_nn_query(const float* db, long long n_db, const float* q, long long n
 int launch_quadrant_ids(const float* pts, long long n, const float* cam_center_host, int div, int* out, hipStream_t s, const char** err);
 // postprocess(compute_cam=True): activation + focal (Weiszfeld) + weighted rigid registration, cam.hip
 size_t cam_scratch_bytes(int n_views, int H, int W);
-int launch_postprocess_cam(const float* pm, int n_views, int H, int W, float* pts3d, float* pts3d_local, float* conf,
+int launch_postprocess_cam(const float* pm, int linear, int n_views, int H, int W, float* pts3d, float* pts3d_local, float* conf,
                            float* focal, float* c2w, void* scratch, size_t scratch_bytes, hipStream_t s, const char** err);
 // 16-bit weight low part: lo = T(w - float(T(w)))  and hi = T(w), from fp32
 int launch_split16(DType dt, const float* in, void* hi, void* lo, size_t n, hipStream_t s, const char** err);

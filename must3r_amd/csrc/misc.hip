@@ -232,6 +232,7 @@ __device__ __forceinline__ void norm_exp3(const float* v, float* o) {
     o[2] = v[2] * sc;
 }
 
+template <bool LINEAR>
 __global__ void postprocess_kernel(const float* __restrict__ pm, float* __restrict__ p3, float* __restrict__ pl,
                                    float* __restrict__ cf, size_t npix) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += (size_t)gridDim.x * blockDim.x) {
@@ -239,8 +240,13 @@ __global__ void postprocess_kernel(const float* __restrict__ pm, float* __restri
 #pragma unroll
         for (int k = 0; k < 7; ++k) v[k] = pm[i * 7 + k];
         float a[3], b[3];
-        norm_exp3(v, a);
-        norm_exp3(v + 3, b);
+        if constexpr (LINEAR) {   // ActivationType.LINEAR (head.py:13-21): the coordinates pass through
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { a[k] = v[k]; b[k] = v[3 + k]; }
+        } else {
+            norm_exp3(v, a);
+            norm_exp3(v + 3, b);
+        }
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
             p3[i * 3 + k] = a[k];
@@ -250,11 +256,12 @@ __global__ void postprocess_kernel(const float* __restrict__ pm, float* __restri
     }
 }
 
-int launch_postprocess(const float* pm, float* pts3d, float* pts3d_local, float* conf, size_t npix, hipStream_t s,
+int launch_postprocess(const float* pm, int linear, float* pts3d, float* pts3d_local, float* conf, size_t npix, hipStream_t s,
                        const char** err) {
     if (!npix) return 0;
     const int grid = (int)((npix + 255) / 256 < 8192 ? (npix + 255) / 256 : 8192);
-    hipLaunchKernelGGL(postprocess_kernel, dim3(grid), dim3(256), 0, s, pm, pts3d, pts3d_local, conf, npix);
+    if (linear) hipLaunchKernelGGL(postprocess_kernel<true>, dim3(grid), dim3(256), 0, s, pm, pts3d, pts3d_local, conf, npix);
+    else hipLaunchKernelGGL(postprocess_kernel<false>, dim3(grid), dim3(256), 0, s, pm, pts3d, pts3d_local, conf, npix);
     if (hipGetLastError() != hipSuccess) { *err = "postprocess: launch failed"; return 1; }
     return 0;
 }

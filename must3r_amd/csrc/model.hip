@@ -60,7 +60,8 @@ struct Param {
 // softmax scale folded into q by the projection epilogues: 1/sqrt(64) * log2(e)
 static const float kQScale = 0.125f * 1.44269504088896340736f;
 
-struct ProfEntry { hipEvent_t a, b; int cat; double flops; };
+struct ProfEntry { hipEvent_t a, b; int cat; double flops; char kern[40]; };
+struct ProfKern { double ms = 0, flops = 0; long long calls = 0; };
 enum ProfCat { PC_GEMM128 = 0, PC_GEMM64, PC_ATTN_SA, PC_ATTN_CA, PC_ATTN_COMBINE, PC_LN, PC_MISC, PC_COUNT };
 static const char* kProfNames[PC_COUNT] = {"gemm128", "gemm64", "attn_self", "attn_cross", "attn_combine", "layernorm", "misc"};
 
@@ -97,6 +98,7 @@ struct must3r_hip_ctx {
     std::vector<hipEvent_t> ev_pool;
     double prof_ms[PC_COUNT] = {0}, prof_flops[PC_COUNT] = {0};
     long long prof_calls[PC_COUNT] = {0};
+    std::map<std::string, ProfKern> prof_kern;   // per kernel symbol (GEMM: family / epilogue / weight layout / tile width; attention: kernel + self / cross)
 };
 
 // The entry points run on the context's device and leave the caller's current device as they found it (a process that
@@ -164,8 +166,9 @@ static hipEvent_t ev_get(must3r_hip_ctx* c) {
 struct ProfScope {
     must3r_hip_ctx* c; hipStream_t s; ProfEntry e; bool on;
     ProfScope(must3r_hip_ctx* c_, hipStream_t s_, int cat, double flops) : c(c_), s(s_), on(c_ && c_->prof) {
-        if (on) { e.a = ev_get(c); e.b = ev_get(c); e.cat = cat; e.flops = flops; (void)hipEventRecord(e.a, s); }
+        if (on) { e.a = ev_get(c); e.b = ev_get(c); e.cat = cat; e.flops = flops; e.kern[0] = 0; (void)hipEventRecord(e.a, s); }
     }
+    void kernel(const char* name, const char* suffix = "") { if (on) snprintf(e.kern, sizeof(e.kern), "%s%s", name, suffix); }
     ~ProfScope() { if (on) { (void)hipEventRecord(e.b, s); c->prof_entries.push_back(e); } }
 };
 static void prof_flush(must3r_hip_ctx* c) {
@@ -176,6 +179,10 @@ static void prof_flush(must3r_hip_ctx* c) {
         c->prof_ms[e.cat] += ms;
         c->prof_flops[e.cat] += e.flops;
         c->prof_calls[e.cat] += 1;
+        if (e.kern[0]) {
+            ProfKern& k = c->prof_kern[e.kern];
+            k.ms += ms; k.flops += e.flops; k.calls += 1;
+        }
         c->ev_pool.push_back(e.a);
         c->ev_pool.push_back(e.b);
     }
@@ -197,6 +204,7 @@ static int gemm(must3r_hip_ctx* c, DType dt, Epi epi, GemmArgs a, hipStream_t s,
     else if (c && epi != EPI_HEAD) a.wsplit = c->wsplit;
     ProfScope ps(c, s, cat, 2.0 * a.M * a.N * a.K * (a.batch > 1 ? a.batch : 1));
     if (launch_gemm(dt, epi, a, s, &err)) return fail("%s (M=%d N=%d K=%d epi=%d)", err, a.M, a.N, a.K, (int)epi);
+    ps.kernel(gemm_last_kernel());
     return 0;
 }
 static GemmArgs gargs(const void* A, const void* W, const float* bias, void* out, int M, int N, int K, int lda, int ldc) {
@@ -239,6 +247,7 @@ static int attention(must3r_hip_ctx* c, DType dt, const AttnArgs& a, double flop
     {
         ProfScope ps(c, s, cat, flops);   // the attention kernel alone: what rocprofv3 reports under its symbol
         if (launch_attention_phase(dt, a, 1, s, &err)) return fail("%s", err);
+        ps.kernel(attention_last_kernel(), cat == PC_ATTN_SA ? "/self" : "/cross");
     }
     if (a.nsplit > 1) {
         ProfScope ps(c, s, PC_ATTN_COMBINE, 0.0);
@@ -1196,6 +1205,10 @@ extern "C" int must3r_hip_decode(must3r_hip_ctx* c, const must3r_hip_decode_args
     }
     // the per-call view tables travel through one staging slot: 2 tables x 24 B per view
     const long long max_views = (long long)(must3r_hip_ctx::kSlotBytes / (2 * sizeof(AttnView)));
+    // ... and so does an update's table of K|V destinations: 2 x dec_depth x S pointers ('kv' memory)
+    if (!A->render && A->mem_mode == MUST3R_MEM_KV && (size_t)2 * c->cfg.dec_depth * S * sizeof(void*) > must3r_hip_ctx::kSlotBytes)
+        return fail("decode: %d scenes in one memory update (limit %zu at decoder depth %d)", S,
+                    must3r_hip_ctx::kSlotBytes / (2 * sizeof(void*) * c->cfg.dec_depth), c->cfg.dec_depth);
     if (S * views_s <= max_views) return decode_impl(c, A, stream);
     if (!A->render) return fail("decode: %lld views in one memory update (limit %lld)", S * views_s, max_views);
     if (A->feats) return fail("decode: return_feats with %lld rendered views in one call (limit %lld)", S * views_s, max_views);
@@ -1241,11 +1254,15 @@ extern "C" int must3r_hip_decode(must3r_hip_ctx* c, const must3r_hip_decode_args
 // ------------------------------------------------------------------------------------------------
 // postprocess + operator-level entry points + profiling
 // ------------------------------------------------------------------------------------------------
-extern "C" int must3r_hip_postprocess(const float* pm, float* p3, float* pl, float* cf, size_t npix, void* stream) {
+extern "C" int must3r_hip_postprocess_act(const float* pm, int activation, float* p3, float* pl, float* cf, size_t npix, void* stream) {
     const char* err = "";
     if (!pm || !p3 || !pl || !cf) return fail("postprocess: null argument");
-    if (launch_postprocess(pm, p3, pl, cf, npix, reinterpret_cast<hipStream_t>(stream), &err)) return fail("%s", err);
+    if (activation != MUST3R_ACT_NORM_EXP && activation != MUST3R_ACT_LINEAR) return fail("postprocess: unknown activation %d", activation);
+    if (launch_postprocess(pm, activation == MUST3R_ACT_LINEAR, p3, pl, cf, npix, reinterpret_cast<hipStream_t>(stream), &err)) return fail("%s", err);
     return 0;
+}
+extern "C" int must3r_hip_postprocess(const float* pm, float* p3, float* pl, float* cf, size_t npix, void* stream) {
+    return must3r_hip_postprocess_act(pm, MUST3R_ACT_NORM_EXP, p3, pl, cf, npix, stream);
 }
 
 extern "C" int must3r_hip_affine(int is_double, const float* A, const void* sub, const void* B, int b_transposed, const void* bias,
@@ -1330,15 +1347,20 @@ extern "C" size_t must3r_hip_postprocess_cam_scratch_bytes(int n_views, int H, i
     return cam_scratch_bytes(n_views, H, W);
 }
 
-extern "C" int must3r_hip_postprocess_cam(const float* pm, int n_views, int H, int W, float* p3, float* pl, float* cf,
-                                          float* focal, float* c2w, void* scratch, size_t scratch_bytes, void* stream) {
+extern "C" int must3r_hip_postprocess_cam_act(const float* pm, int activation, int n_views, int H, int W, float* p3, float* pl, float* cf,
+                                              float* focal, float* c2w, void* scratch, size_t scratch_bytes, void* stream) {
     if (n_views < 0 || H <= 0 || W <= 0) return fail("postprocess_cam: bad shape");
+    if (activation != MUST3R_ACT_NORM_EXP && activation != MUST3R_ACT_LINEAR) return fail("postprocess_cam: unknown activation %d", activation);
     if (n_views == 0) return 0;
     if (!pm || !p3 || !pl || !cf || !focal || !c2w || !scratch) return fail("postprocess_cam: null argument");
     const char* err = nullptr;
-    if (launch_postprocess_cam(pm, n_views, H, W, p3, pl, cf, focal, c2w, scratch, scratch_bytes,
+    if (launch_postprocess_cam(pm, activation == MUST3R_ACT_LINEAR, n_views, H, W, p3, pl, cf, focal, c2w, scratch, scratch_bytes,
                                reinterpret_cast<hipStream_t>(stream), &err)) return fail("%s", err);
     return 0;
+}
+extern "C" int must3r_hip_postprocess_cam(const float* pm, int n_views, int H, int W, float* p3, float* pl, float* cf,
+                                          float* focal, float* c2w, void* scratch, size_t scratch_bytes, void* stream) {
+    return must3r_hip_postprocess_cam_act(pm, MUST3R_ACT_NORM_EXP, n_views, H, W, p3, pl, cf, focal, c2w, scratch, scratch_bytes, stream);
 }
 
 extern "C" int must3r_hip_op_gemm(int dtype, int epi, const void* A, const void* W, const float* bias, void* out, int M, int N,
@@ -1447,7 +1469,19 @@ extern "C" int must3r_hip_get_profile(must3r_hip_ctx* c, must3r_hip_prof_record*
         out[n].calls = c->prof_calls[i];
         ++n;
     }
-    if (reset)
+    // per-kernel rows behind the class rows, names prefixed "k:" (one rocprofv3 symbol each)
+    for (auto& kv : c->prof_kern) {
+        if (n >= max) break;
+        memset(&out[n], 0, sizeof(out[n]));
+        snprintf(out[n].name, sizeof(out[n].name), "k:%s", kv.first.c_str());
+        out[n].ms = kv.second.ms;
+        out[n].flops = kv.second.flops;
+        out[n].calls = kv.second.calls;
+        ++n;
+    }
+    if (reset) {
         for (int i = 0; i < PC_COUNT; ++i) { c->prof_ms[i] = 0; c->prof_flops[i] = 0; c->prof_calls[i] = 0; }
+        c->prof_kern.clear();
+    }
     return n;
 }

@@ -21,8 +21,11 @@ def postprocess(pointmaps, pointmaps_activation=ActivationType.NORM_EXP, compute
     ``pts3d_local -> pts3d``, all in the same native call as the activation (``must3r_hip_postprocess_cam``)."""
     if isinstance(pointmaps_activation, str):
         pointmaps_activation = ActivationType(pointmaps_activation)
-    if pointmaps_activation != ActivationType.NORM_EXP or pointmaps.shape[-1] != 7:
-        raise NotImplementedError("fused postprocess handles the 7-channel NORM_EXP layout of the released models")
+    if pointmaps_activation not in (ActivationType.NORM_EXP, ActivationType.LINEAR):
+        raise ValueError(f"Unknown activation: {pointmaps_activation}")      # head.py:21
+    if pointmaps.shape[-1] != 7:
+        raise NotImplementedError("fused postprocess handles the 7-channel (pts3d, pts3d_local, conf) layout of the released models")
+    act = _lib.ACT_LINEAR if pointmaps_activation == ActivationType.LINEAR else _lib.ACT_NORM_EXP
     if not pointmaps.is_cuda:
         raise RuntimeError("must3r_amd.postprocess: input is on CPU; the HIP path has no CPU fallback")
     pm = pointmaps.float().contiguous()
@@ -36,7 +39,7 @@ def postprocess(pointmaps, pointmaps_activation=ActivationType.NORM_EXP, compute
     out = {"pts3d": p3, "pts3d_local": pl, "conf": cf}
     if not compute_cam:
         with torch.cuda.device(pm.device):   # launch from the tensor's device whatever the caller's current device is
-            _lib.check(lib.must3r_hip_postprocess(pm.data_ptr(), p3.data_ptr(), pl.data_ptr(), cf.data_ptr(), npix, stream))
+            _lib.check(lib.must3r_hip_postprocess_act(pm.data_ptr(), act, p3.data_ptr(), pl.data_ptr(), cf.data_ptr(), npix, stream))
         return out
     if pm.dim() < 3:
         raise ValueError("compute_cam needs pointmaps of shape [..., H, W, 7]")
@@ -49,7 +52,7 @@ def postprocess(pointmaps, pointmaps_activation=ActivationType.NORM_EXP, compute
         with torch.cuda.device(pm.device):
             nbytes = lib.must3r_hip_postprocess_cam_scratch_bytes(n, H, W)
             scratch = torch.empty(nbytes, dtype=torch.uint8, device=pm.device)
-            _lib.check(lib.must3r_hip_postprocess_cam(pm.data_ptr(), n, H, W, p3.data_ptr(), pl.data_ptr(), cf.data_ptr(),
+            _lib.check(lib.must3r_hip_postprocess_cam_act(pm.data_ptr(), act, n, H, W, p3.data_ptr(), pl.data_ptr(), cf.data_ptr(),
                                                       focal.data_ptr(), c2w.data_ptr(), scratch.data_ptr(), nbytes, stream))
     out["focal"] = focal
     out["c2w"] = c2w

@@ -14,6 +14,7 @@ _DT = {"bf16": _lib.BF16, "fp16": _lib.F16, "fp16w2": _lib.F16_W2, "fp16wa": _li
 _TORCH_DT = {_lib.BF16: torch.bfloat16, _lib.F16: torch.float16, _lib.F16_W2: torch.float16, _lib.F16_WA: torch.float16}
 PRECISIONS = ("bf16", "fp16", "fp16w2", "fp16wa")
 _VERSION_OF = operator.attrgetter("_version")
+_DATA_PTR_OF = operator.methodcaller("data_ptr")
 _DEBUG_WEIGHTS = bool(int(os.environ.get("M3R_DEBUG_WEIGHTS", "0") or 0))
 
 
@@ -55,16 +56,21 @@ class HipModule(nn.Module):
         self._synced = None
 
     # -- weights -------------------------------------------------------------------------------
-    # When do the parameters have to be mirrored into the native context again?  The full fingerprint ((data_ptr, _version) of all
-    # ~600 parameters) costs ~0.1-0.3 ms of host time per call -- more than the launches of a 224x224 decoder call.  In eval mode
-    # (every inference caller of the reference) the check is:
-    #   * an epoch counter bumped by everything that replaces or moves parameters wholesale -- `load_state_dict` and `_apply`
-    #     (= .to() / .cuda() / .half() ...) of this module AND of every submodule (hooks installed on the children, so that
-    #     `model.blocks_dec[3].half()` or a child's `load_state_dict` is seen);
-    #   * the SUM of `_version` over a cached parameter list (rebuilt when the epoch moves): any in-place edit of any parameter --
-    #     an optimizer step, `p.mul_()`, `p.data.copy_()` -- changes it (~40 us);
-    #   * the data_ptr of the first, the middle and the last parameter.
-    # Not seen: a parameter OBJECT replaced on a child (`child.weight = nn.Parameter(...)`) -- call `refresh_weights()`; the switch
+    # When do the parameters have to be mirrored into the native context again?  The full fingerprint (a tuple of (data_ptr, _version)
+    # of all ~600 parameters, rebuilt from `self.parameters()`) costs 0.1-0.3 ms of host time per call.  In eval mode (every inference
+    # caller of the reference) the check works on a cached parameter list and three integers instead:
+    #   * an epoch counter bumped by what replaces or moves the parameters of THIS module wholesale (`load_state_dict`, `_apply` =
+    #     .to() / .cuda() / .half(), `train`); the cached list is rebuilt when it moves;
+    #   * the SUM of `_version` over the list: any in-place edit of a parameter tensor -- an optimizer step, `p.mul_()`,
+    #     `p.copy_()` under no_grad, a submodule's `load_state_dict` -- changes it;
+    #   * the SUM of `data_ptr()` over the list: a conversion or move of ANY submodule (`model.blocks_dec[3].half()`,
+    #     `child.to(...)`) gives its parameters new storage.  (r03 bumped the epoch from `_apply` wrappers installed on the children's
+    #     instances instead; those closures broke `copy.deepcopy(model).half()` and `torch.save(model)` -- ADVICE r03 -- and are gone:
+    #     nothing is patched onto any module.)
+    # NOT seen -- call `refresh_weights()` after these:
+    #   * edits through `.data` (`p.data.copy_(w)`, `p.data.mul_(..)`, EMA-style updates): `.data` is a detached alias with its own
+    #     version counter, so neither sum moves;
+    #   * a parameter OBJECT replaced on a child (`child.weight = nn.Parameter(...)`): the cached list still holds the old one.
     # M3R_DEBUG_WEIGHTS=1 asserts the full fingerprint on every forward to find such a caller.  Training mode keeps the full one.
     def _full_fingerprint(self):
         return tuple((p.data_ptr(), p._version) for p in self.parameters())
@@ -72,52 +78,24 @@ class HipModule(nn.Module):
     def _fingerprint(self):
         if self.training:
             return self._full_fingerprint()
-        self._install_child_hooks()
-        ps = getattr(self, "_param_cache", None)
+        ps = self.__dict__.get("_param_cache")
         if ps is None or ps[1] != self._weights_epoch:
-            allp = list(self.parameters())
-            ps = self._param_cache = (allp, self._weights_epoch, (allp[0], allp[len(allp) // 2], allp[-1]))
-        fp = (self._weights_epoch, sum(map(_VERSION_OF, ps[0])), ps[2][0].data_ptr(), ps[2][1].data_ptr(), ps[2][2].data_ptr())
+            ps = (list(self.parameters()), self._weights_epoch)
+            self.__dict__["_param_cache"] = ps
+        fp = (self._weights_epoch, sum(map(_VERSION_OF, ps[0])), sum(map(_DATA_PTR_OF, ps[0])))
         if _DEBUG_WEIGHTS:
             full = self._full_fingerprint()
-            last = getattr(self, "_debug_full", None)
+            last = self.__dict__.get("_debug_full")
             if last is not None and last[0] == fp and last[1] != full:
                 raise AssertionError("must3r_amd: parameters changed without the cheap fingerprint noticing (M3R_DEBUG_WEIGHTS); "
-                                     "call refresh_weights() after replacing parameter objects")
-            self._debug_full = (fp, full)
+                                     "call refresh_weights() after replacing parameter objects or editing them through .data")
+            self.__dict__["_debug_full"] = (fp, full)
         return fp
 
     _weights_epoch = 0
-    _hooked_children = None
 
     def _bump(self):
         self._weights_epoch = self._weights_epoch + 1
-
-    def _install_child_hooks(self):
-        """Make wholesale changes on SUBmodules bump this module's epoch (children are plain nn.Modules)."""
-        mods = list(self.modules())
-        if self._hooked_children == (id(self), len(mods)):
-            return
-        import weakref
-        me = weakref.ref(self)
-
-        def bump(*_a, **_k):
-            m = me()
-            if m is not None:
-                m._bump()
-        for m in mods:
-            owner = getattr(m, "_m3r_hooked", None)
-            if m is self or (owner is not None and owner() is self):
-                continue
-            m.register_load_state_dict_post_hook(bump)
-            orig = m._apply
-
-            def _apply(fn, *a, _orig=orig, **k):
-                bump()
-                return _orig(fn, *a, **k)
-            object.__setattr__(m, "_apply", _apply)
-            object.__setattr__(m, "_m3r_hooked", me)
-        self._hooked_children = (id(self), len(mods))   # (a deepcopy carries the original's hooks: its id differs, it installs its own)
 
     def _apply(self, fn, *a, **k):
         self._bump()
@@ -130,6 +108,34 @@ class HipModule(nn.Module):
     def train(self, mode=True):
         self._bump()   # the two modes use different fingerprints
         return super().train(mode)
+
+    # The native context, the cached parameter list and the sync stamp belong to THIS object: a copy (copy.deepcopy, pickle / torch.save)
+    # starts without them and mirrors its own parameters on its first forward.
+    _TRANSIENT = ("_ctx", "_ctx_dev", "_synced", "_param_cache", "_debug_full")
+
+    def __getstate__(self):
+        st = self.__dict__.copy()
+        for k in self._TRANSIENT:
+            st.pop(k, None)
+        return st
+
+    def __setstate__(self, st):
+        super().__setstate__(st)
+        self._ctx = None
+        self._ctx_dev = None
+        self._synced = None
+
+    def __deepcopy__(self, memo):
+        import copy
+        new = self.__class__.__new__(self.__class__)
+        memo[id(self)] = new
+        for k, v in self.__dict__.items():
+            if k not in self._TRANSIENT:
+                new.__dict__[k] = copy.deepcopy(v, memo)
+        new._ctx = None
+        new._ctx_dev = None
+        new._synced = None
+        return new
 
     def refresh_weights(self):
         """Force a re-upload of all parameters on the next forward."""

@@ -259,6 +259,14 @@ class MUSt3R(HipModule):
             # read-only: any [B, Nm, mem_D] tensors whose rows are contiguous and whose scene stride is the same in every layer
             # (the prefix views of this module's own buffers are: stride cap x mem_D) are read in place
             vals, stride = [], None
+            if fp8_rows:
+                # rows are opaque bytes [K e4m3 | V 16-bit] (3 D per row): a memory written in 16-bit mode ([., Nm, 2 D] 16-bit elements) has
+                # another row format -- a numeric cast would hand the kernel garbage and let it read Nm x D bytes past the buffer
+                for v in mem_vals:
+                    if v.dtype != torch.uint8 or int(v.shape[2]) != mem_D:
+                        raise ValueError(f"attention_fp8 with memory_mode 'kv': the memory must be the uint8 [B, Nm, {mem_D}] rows an fp8-mode "
+                                         f"update returned, got {v.dtype} [.., {int(v.shape[2])}] (a memory written with attention_fp8 off cannot "
+                                         "be rendered with it on; re-run the update in this mode)")
             for v in mem_vals:
                 if not v.is_cuda or v.dtype != tdt or v.stride(2) != 1 or v.stride(1) != mem_D or (B > 1 and v.stride(0) % mem_D):
                     v = v.to(device=device, dtype=tdt).contiguous()

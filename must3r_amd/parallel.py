@@ -46,8 +46,8 @@ def all_gather_varlen(t, group=None, counts=None):
     """Concatenate ``t`` ([k_rank, ...], k may differ per rank, may be 0) over ranks, in rank order.  ``counts``: the row
     counts of all ranks when the caller already knows them (saves the count exchange and its device->host read-back)."""
     rank, world = _world(group)
-    if world == 1:
-        return t
+    if world == 1 and not (dist.is_available() and dist.is_initialized()):
+        return t      # no process group at all; an initialised group of ONE rank still runs the collective (a 1-GPU box exercises RCCL)
     if t.is_cuda and dist.get_backend(group) == "gloo":
         # gloo has no CUDA all_gather: stage through the host (only used when ranks share a GPU in tests)
         return all_gather_varlen(t.cpu(), group, counts).to(t.device)
@@ -96,24 +96,58 @@ def _encode_local(encoder, imgs_local, true_shape_local):
             torch.zeros((0, N, 2), dtype=torch.int64, device=imgs_local.device))
 
 
-def _gather_keyframes(x, pos, true_shape_local, keyframe_local, group, comm_dtype, counts=None):
-    """All-gather of the encoded keyframe tokens (+ positions, shapes) in rank order.  The keyframe selection is a host
+def grid_positions(gh, gw, device):
+    """croco PositionGetter: int64 [gh*gw, 2] = (y, x) of a row-major gh x gw token grid -- what the encoder
+    returns as ``pos`` for one view, so positions never have to travel between ranks."""
+    y = torch.arange(gh, dtype=torch.int64, device=device)
+    x = torch.arange(gw, dtype=torch.int64, device=device)
+    return torch.cartesian_prod(y, x)
+
+
+def _gather_keyframes(x, pos, true_shape_local, keyframe_local, group, comm_dtype, counts=None, grid=None, many_ar=False):
+    """ONE all-gather of the encoded keyframe tokens in rank order -- the scene's only exchange.  The keyframe selection is a host
     index list (no boolean-mask indexing on the device = no nonzero() sync).  ``counts``: keyframes per rank when the caller
-    knows the schedule (a benchmark, a fixed keyframe stride): no count exchange, no device->host read-back at all."""
+    knows the schedule (a benchmark, a fixed keyframe stride): no count exchange at all.
+
+    r04 ("pos is recomputable from the grid"): positions and true shapes no longer ride two more collectives.
+    Each keyframe's payload is its [N, C] tokens plus ONE extra row whose first four entries are (h // 256, h % 256, w // 256, w % 256)
+    of its true shape -- integers below 256, exact in bf16 and fp16 -- and the positions are rebuilt from the token grid
+    (``grid`` = (H/16, W/16) of the stored images, the same on every rank; transposed for the portrait views of a ManyAR patch embed)."""
     idx = torch.nonzero(keyframe_local.cpu()).flatten()
     if counts is None:
-        counts = gather_counts(int(idx.numel()), x.device, group)           # one exchange for all three gathers
+        counts = gather_counts(int(idx.numel()), x.device, group)
     else:
         counts = [int(c) for c in counts]
         assert counts[_world(group)[0]] == int(idx.numel()), (counts, int(idx.numel()))
     idx_d = idx.to(x.device)
     kx = x.index_select(0, idx_d)
+    ts = true_shape_local.cpu().index_select(0, idx).to(torch.int64)
+    meta = torch.zeros((kx.shape[0], 1, kx.shape[2]), dtype=torch.float32)
+    meta[:, 0, 0], meta[:, 0, 1] = ts[:, 0] // 256, ts[:, 0] % 256
+    meta[:, 0, 2], meta[:, 0, 3] = ts[:, 1] // 256, ts[:, 1] % 256
+    pay = torch.cat([kx, meta.to(kx.device)], dim=1)
     if comm_dtype is not None:
-        kx = kx.to(comm_dtype)  # 16-bit on the wire; the decoder rounds its operands to this type anyway
-    kx = all_gather_varlen(kx, group, counts).float()
-    kpos = all_gather_varlen(pos.index_select(0, idx_d), group, counts)
-    kts = all_gather_varlen(true_shape_local.cpu().index_select(0, idx).to(x.device), group, counts).cpu()   # host copy
+        pay = pay.to(comm_dtype)  # 16-bit on the wire; the decoder rounds its operands to this type anyway
+    pay = all_gather_varlen(pay, group, counts)
+    kx = pay[:, :-1].float()
+    m = pay[:, -1, :4].float().round().to(torch.int64).cpu()            # host copy of the shapes (the decoder needs host integers)
+    kts = torch.stack([m[:, 0] * 256 + m[:, 1], m[:, 2] * 256 + m[:, 3]], dim=1)
+    if grid is None:   # single-process callers without images: fall back to the positions themselves
+        return kx, all_gather_varlen(pos.index_select(0, idx_d), group, counts), kts
+    gh, gw = grid
+    land = grid_positions(gh, gw, kx.device)
+    if many_ar and bool((kts[:, 0] > kts[:, 1]).any()):
+        port = grid_positions(gw, gh, kx.device)
+        sel = (kts[:, 0] > kts[:, 1]).to(kx.device)
+        kpos = torch.where(sel[:, None, None], port.unsqueeze(0), land.unsqueeze(0)).contiguous()
+    else:
+        kpos = land.unsqueeze(0).expand(kx.shape[0], -1, -1).contiguous()
     return kx, kpos, kts
+
+
+def _grid_of(encoder, imgs_local):
+    many_ar = getattr(getattr(encoder, "patch_embed", None), "kind", "PatchEmbedDust3R") == "ManyAR_PatchEmbed"
+    return (int(imgs_local.shape[-2]) // 16, int(imgs_local.shape[-1]) // 16), many_ar
 
 
 def _render_local(decoder, x, pos, true_shape_local, mem, imgs_local):
@@ -135,7 +169,8 @@ def run_scene_sharded(encoder, decoder, imgs_local, true_shape_local, keyframe_l
     ``keyframe_counts``: keyframes per rank, when known on the host (skips the count exchange).
     """
     x, pos = _encode_local(encoder, imgs_local, true_shape_local)
-    kx, kpos, kts = _gather_keyframes(x, pos, true_shape_local, keyframe_local, group, comm_dtype, keyframe_counts)
+    grid, many_ar = _grid_of(encoder, imgs_local)
+    kx, kpos, kts = _gather_keyframes(x, pos, true_shape_local, keyframe_local, group, comm_dtype, keyframe_counts, grid, many_ar)
     K = kx.shape[0]
     if K == 0:
         raise ValueError("run_scene_sharded: no keyframe on any rank")
@@ -169,7 +204,8 @@ def run_video_sharded(encoder, decoder, imgs_local, true_shape_local, group=None
     from .engine import run_video
     x, pos = _encode_local(encoder, imgs_local, true_shape_local)
     all_kf = torch.ones(x.shape[0], dtype=torch.bool)
-    ax, apos, ats = _gather_keyframes(x, pos, true_shape_local, all_kf, group, comm_dtype, frame_counts)
+    grid, many_ar = _grid_of(encoder, imgs_local)
+    ax, apos, ats = _gather_keyframes(x, pos, true_shape_local, all_kf, group, comm_dtype, frame_counts, grid, many_ar)
     mem, pm0, keyframes = run_video(None, decoder, None, ats, local_context_size=local_context_size, is_keyframe=is_keyframe,
                                     init_num_images=init_num_images, encoder_tokens=(ax, apos))
     out = {"mem": mem, "keyframes": keyframes, "pointmaps_0": pm0}

@@ -302,3 +302,47 @@ def test_epilogue_lane_exchange_gives_whole_line_stores():
                 assert r == row and c == col0 + 2 * d, (name, l, d, (r, c), (row, col0 + 2 * d))
                 seen.add((r, c)); seen.add((r, c + 1))
     assert len(seen) == 16 * 64
+
+
+def test_copies_and_pickles_of_the_modules_are_independent(tmp_path):
+    """nothing may be patched onto the (sub)modules -- `copy.deepcopy(model).half()` converts the COPY and only the copy,
+    `torch.save(model)` works, and a conversion of a child moves the cheap eval-mode fingerprint of its owner."""
+    import copy
+    cfg = TINY
+    dec = M.MUSt3R(img_size=(cfg.img_size, cfg.img_size), enc_embed_dim=cfg.enc_dim, embed_dim=cfg.dec_dim, depth=cfg.dec_depth,
+                   num_heads=cfg.dec_heads).eval()
+    fp0 = dec._fingerprint()
+    assert dec._fingerprint() == fp0                                   # stable while nothing changes
+    assert not any("_apply" in m.__dict__ or "_m3r_hooked" in m.__dict__ for m in dec.modules())
+    cp = copy.deepcopy(dec).half()
+    assert all(p.dtype == torch.float16 for p in cp.parameters())
+    assert all(p.dtype == torch.float32 for p in dec.parameters())
+    assert dec._fingerprint() == fp0                                   # the original did not move
+    assert cp._ctx is None and cp._synced is None and "_param_cache" not in cp.__dict__
+    # a child converted on its own: new storage -> the owner's fingerprint moves (and back to a different one after the round trip)
+    dec.blocks_dec[1].attn.qkv.double()
+    fp1 = dec._fingerprint()
+    assert fp1 != fp0
+    dec.blocks_dec[1].attn.qkv.float()
+    # in-place edits: version counters
+    fp2 = dec._fingerprint()
+    with torch.no_grad():
+        dec.blocks_dec[0].mlp.fc1.bias.add_(1.0)
+    assert dec._fingerprint() != fp2
+    fp3 = dec._fingerprint()
+    dec.blocks_dec[0].load_state_dict(dec.blocks_dec[0].state_dict())   # a child's load_state_dict = in-place copies
+    assert dec._fingerprint() != fp3
+    # pickling the whole module (the reference's checkpoints hold state dicts, but torch.save(model) is what ad-hoc scripts do)
+    path = tmp_path / "dec.pt"
+    torch.save(dec, path)
+    back = torch.load(path, weights_only=False)
+    assert back._ctx is None and back._synced is None
+    assert all(torch.equal(a, b) for a, b in zip(back.state_dict().values(), dec.state_dict().values()))
+    assert back._fingerprint() != dec._fingerprint()                    # its own storage
+
+
+def test_fp8_memory_rows_are_not_cast_from_a_16_bit_memory():
+    """with attention_fp8 + 'kv' the memory rows are opaque uint8 [B, Nm, 3 D]; a 16-bit memory must be refused, not cast."""
+    src = open(os.path.join(ROOT, "must3r_amd", "model", "decoder.py")).read()
+    i = src.index("if fp8_rows:\n                # rows are opaque bytes")
+    assert "raise ValueError" in src[i:i + 900] and "torch.uint8" in src[i:i + 900]

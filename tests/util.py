@@ -32,6 +32,9 @@ def load_golden(name):
 #          scripts/emul/gemm_precision.py; measured: profiles/).
 TOL = {"fp16w2": 1.0e-3, "fp16wa": 1.0e-3, "fp16": 2.0e-3, "bf16": 1.15e-2}
 PRECISIONS = ("fp16w2", "fp16wa", "fp16", "bf16")
+# the module default (what bench.py times) against the real-reference fixture of the benched scene, worst single view: tightened with the
+# default's measured margin (tests/test_zz_r04_gpu.py::test_benched_configuration_scenes_in_flight_vs_reference_fixture)
+TOL_DEFAULT_FIXTURE = 1.0e-3
 
 
 from must3r_amd.synthetic import make_cam_pointmaps as cam_scene  # noqa: E402,F401
