@@ -102,14 +102,19 @@ def main():
     ap.add_argument("--no-alt", action="store_true")
     ap.add_argument("--no-single", action="store_true", help="skip the one-scene-at-a-time leg (the PMC passes use this)")
     ap.add_argument("--no-configs", action="store_true", help="skip the extra BASELINE.json configurations")
+    ap.add_argument("--step-only", action="store_true", help="the S-scene step and nothing else (no single-scene leg, other configurations, other "
+                    "precisions, cam timing or CPU baseline): every launch of the process belongs to the step, so a rocprofv3 --kernel-trace of "
+                    "this command has per-symbol averages that equal the line's (scripts/gpu_profile_r04.sh)")
     ap.add_argument("--stream-frames", type=int, default=200)
     ap.add_argument("--cpu-timeout", type=float, default=420.0)
     args = ap.parse_args()
+    if args.step_only:
+        args.no_single = args.no_configs = args.no_alt = args.no_cpu_baseline = True
 
     import torch.distributed as dist
     from must3r_amd.config import MUST3R_512, MUST3R_224
     from must3r_amd import synthetic as S
-    from must3r_amd.engine import run_scene, run_scenes, run_scene_mixed, run_video, demo_mem_batches
+    from must3r_amd.engine import run_scene, run_scenes, run_scene_mixed, run_scenes_mixed, run_video, demo_mem_batches
     from must3r_amd.parallel import run_scene_sharded, run_video_sharded, shard_range
 
     rank = int(os.environ.get("RANK", "0"))
@@ -176,15 +181,16 @@ def main():
             m._context().set_profiling(True)
         fn()
         torch.cuda.synchronize(device)
-        prof = {}
+        prof, kern_rows = {}, {}
         for m in (enc, dec):
             for k, v in m._context().get_profile().items():
-                p = prof.setdefault(k, {"ms": 0.0, "flops": 0.0, "calls": 0})
+                p = (kern_rows if k.startswith("k:") else prof).setdefault(k[2:] if k.startswith("k:") else k, {"ms": 0.0, "flops": 0.0, "calls": 0})
                 p["ms"] += v["ms"]; p["flops"] += v["flops"]; p["calls"] += v["calls"]
             m._context().set_profiling(False)
         classes = {k: {"ms": round(v["ms"], 3), "calls": int(v["calls"]),
                        "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1) if v["ms"] > 0 and v["flops"] > 0 else None}
                    for k, v in prof.items()}
+        prof["_kernels"] = kern_rows
         return prof, classes
 
     def stage_split(n_scenes, warm=True):
@@ -263,13 +269,43 @@ def main():
                                    + str(pmc_doc.get("commit", "?")) + "; not this run)")
         return r
 
-    roofline = roof("attn3_kernel")
+    def symbol_rows(prefixes):
+        """one row per kernel symbol of the step (in-library HIP events around every launch): what a rocprofv3 --kernel-trace --stats of
+        `bench.py --step-only` lists under the same symbol (profiles/r04_step_kernel_stats.txt; scripts/prof_match.py joins the two)"""
+        rows = []
+        for name, v in sorted(prof.get("_kernels", {}).items(), key=lambda kv: -kv[1]["ms"]):
+            if not name.startswith(prefixes) or v["ms"] <= 0:
+                continue
+            tf = v["flops"] / (v["ms"] * 1e-3) / 1e12
+            rows.append({"kernel": name, "launches": int(v["calls"]), "ms": round(v["ms"], 3), "avg_launch_us": round(v["ms"] * 1e3 / max(1, v["calls"]), 2),
+                         "algorithmic_gflop_per_launch": round(v["flops"] / max(1, v["calls"]) / 1e9, 3), "achieved_tflops": round(tf, 1),
+                         "frac": round(tf / PEAK_TFLOPS[args.precision], 4)})
+        return rows
+
+    roofline_attention = roof("attn3_kernel")
+    roofline_attention["per_symbol"] = symbol_rows(("attn",))
     roofline_gemm = [roof("gemm_kernel<big tile>"), roof("gemm_kernel<small-M>")]
+    # `roofline` = the kernel CLASS that takes the most time of the step (VERDICT r03: the GEMM family, not the single top symbol)
+    gemm_ms = sum(prof[c]["ms"] for c in ("gemm128", "gemm64") if c in prof)
+    attn_ms = sum(prof[c]["ms"] for c in ("attn_self", "attn_cross") if c in prof)
+    if gemm_ms >= attn_ms:
+        a = {f: sum(prof[c][f] for c in ("gemm128", "gemm64") if c in prof) for f in ("ms", "flops", "calls")}
+        ach = a["flops"] / (a["ms"] * 1e-3) / 1e12 if a["ms"] > 0 else 0.0
+        roofline = {"bound": "mfma", "kernel": "GEMM family (every out = epi(A W^T + b) launch of the step: gemm256k / gemm256 / gemm_kernel / gemm96 / gemm48 symbols)",
+                    "achieved": round(ach, 1), "peak": PEAK_TFLOPS[args.precision], "unit": "TFLOP/s", "frac": round(ach / PEAK_TFLOPS[args.precision], 4),
+                    "traffic": roofline_gemm[0].get("traffic"), "traffic_note": "bytes per launch of the chip-filling GEMM symbols (PMC, corrected), see roofline_gemm[0]",
+                    "ms_per_step": round(a["ms"], 3), "share_of_step_kernel_time": round(a["ms"] / max(1e-9, sum(v["ms"] for k, v in prof.items() if k != "_kernels")), 4),
+                    "launches": int(a["calls"]), "avg_launch_us": round(a["ms"] * 1e3 / max(1, a["calls"]), 2),
+                    "algorithmic_flops": "2 M N K per launch, ONE pass (split-weight launches run two MFMA passes for it)",
+                    "sustained_mfma_only": SUSTAINED_TFLOPS, "frac_of_sustained": round(ach / SUSTAINED_TFLOPS, 4),
+                    "per_symbol": symbol_rows(("g",))}
+    else:
+        roofline = roofline_attention
 
     # SURVEY.md section 8f rank 1: postprocess(compute_cam=True) on one scene's 20 rendered pointmaps (HBM-bound:
     # 28 B read + 28 B written per pixel; the focal iteration and the registration add no HBM pass)
     cam = None
-    if rank == 0 and world == 1:
+    if rank == 0 and world == 1 and not args.step_only:
         from must3r_amd.engine import postprocess
         pmaps = run_scene(enc, dec, imgs, ts)["render"]
         for _ in range(3):
@@ -327,8 +363,39 @@ def main():
                 mixed["modes"].append(mode)
             enc.precision = dec.precision = args.precision
             enc.attention_fp8 = dec.attention_fp8 = False
+            del ref_mixed, om
+            # ... and with Sm mixed-resolution scenes IN FLIGHT (forward_list with B = Sm): every attention launch is chip-filling, the only
+            # regime in which the 32 x 32 fp8 kernel can beat the 16-bit one -- reported with its error on all views
+            Sm = min(Sn, 8)
+            if Sm > 1:
+                gS = [torch.stack([g] + [S.make_images(4, h, 512, seed=300 + 10 * b + gi)[0].to(device) for b in range(1, Sm)])
+                      for gi, (g, h) in enumerate(zip(groups, MIXED_H))]
+                inflight = {"scenes": Sm, "views_per_step": 20 * Sm, "modes": []}
+                ref_r = None
+                for fp8 in (False, True):
+                    enc.attention_fp8 = dec.attention_fp8 = fp8
+                    fnm = lambda: run_scenes_mixed(enc, dec, gS)  # noqa: E731
+                    om = fnm()
+                    d = timed(fnm, max(2, ksteps // 2))
+                    mode = {"dtype": args.precision + (" + fp8 attention" if fp8 else ""), "value": round(20 * Sm * max(2, ksteps // 2) / d, 2),
+                            "ms_per_step": round(d / max(2, ksteps // 2) * 1e3, 3), "mfma_frac": round(Sm * fl * max(2, ksteps // 2) / d / 1e12 / 2500.0, 4)}
+                    if not fp8:
+                        ref_r = [r.clone() for r in om["render"]]
+                        ref_u = [u.clone() for u in om["update"]]
+                    else:
+                        mode["render_rel_inf_vs_16bit_path_worst_view"] = max(float((a[b, v] - r[b, v]).abs().max() / r[b, v].abs().max())
+                                                                             for a, r in zip(om["render"], ref_r) for b in range(Sm) for v in range(a.shape[1]))
+                        mode["update_rel_inf_vs_16bit_path_worst_view"] = max(float((a[b] - r[b]).abs().max() / r[b].abs().max())
+                                                                             for a, r in zip(om["update"], ref_u) for b in range(Sm))
+                    inflight["modes"].append(mode)
+                enc.attention_fp8 = dec.attention_fp8 = False
+                v16, v8 = inflight["modes"][0]["value"], inflight["modes"][1]["value"]
+                inflight["verdict"] = (f"fp8 attention {'WINS' if v8 > v16 else 'LOSES'} with {Sm} mixed scenes in flight: {v8} vs {v16} views/s; its error vs the 16-bit "
+                                       f"path {inflight['modes'][1]['render_rel_inf_vs_16bit_path_worst_view']:.2e} (render) is outside the 1e-3 target -> off by default")
+                mixed["scenes_in_flight"] = inflight
+                del gS, ref_r, ref_u, om
             configs.append(mixed)
-            del groups, ref_mixed, om
+            del groups
             # configs[3] on one GPU: online streaming memory, every frame updates the memory (engine.run_video)
             F = args.stream_frames
             vimgs, vts = S.make_images(F, H, W, seed=7)
@@ -471,6 +538,10 @@ def main():
         line = {
             "metric": "views/sec (whole node) MUSt3R_512 20-view 512x384; pointmap max-abs-err vs ref",
             "value": round(value, 2), "unit": "views/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            # BASELINE.md section 2 (r04 wording): `value` = whole-GPU throughput with S independent scenes in flight; `value_single_scene` = the same
+            # scene ONE AT A TIME (V / wall-time(scene): the definition rounds 1-2 reported as `value` -- r01 243, r02 285, r03 322)
+            "value_single_scene": (single or {}).get("value") if Sn > 1 else round(value, 2),
+            "value_definition": f"{Sn} independent 20-view scenes in flight per GPU ({views_per_step} views per step) / step time; value_single_scene: one scene at a time",
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": dtype_label, "data": "synthetic",
             "config": {"workload": f"MUSt3R_512 ViT-L/ViT-B random-init, {V}-view 384x512 scenes with a {V}-view memory each (encode {V} + update[2,1..] + "
@@ -479,7 +550,7 @@ def main():
                        "H": H, "W": W, "ms_per_scene": round(dt / args.steps / Sn * 1e3, 3),
                        "parallelism": "single GPU" if world == 1 else f"{world} replicas (independent scenes per rank, no data-path collective; "
                                                                        f"barrier + max over ranks) [{backend}]"},
-            "roofline": roofline, "roofline_gemm": roofline_gemm, "cpu_baseline": cpu_baseline, "parity_vs_cpu_oracle": parity,
+            "roofline": roofline, "roofline_attention": roofline_attention, "roofline_gemm": roofline_gemm, "cpu_baseline": cpu_baseline, "parity_vs_cpu_oracle": parity,
             "kernel_classes": classes, "stages_ms": stages, "single_scene": single, "alt": alt, "configs": configs, "postprocess_cam": cam,
             "multi_gpu": ("this line is a 1-GPU run; no RCCL run of the N > 1 paths has happened in the build environment (one GPU per box): the "
                           "view-sharded path is covered by world-size-2 gloo tests and a 2-rank gloo dry run of this script" if world == 1 else

@@ -196,6 +196,55 @@ def run_scene_mixed(encoder, decoder, img_groups, mem_batches=None, activate=Tru
     return out
 
 
+@torch.no_grad()
+def run_scenes_mixed(encoder, decoder, img_groups, mem_batches=None, activate=True):
+    """S independent mixed-resolution scenes IN FLIGHT TOGETHER (BASELINE.json configs[4] with every launch chip-filling): ``img_groups``
+    is a list of fp32 [S, n_g, 3, H_g, W_g] cuda tensors, one per aspect ratio; scene b is ``[g[b] for g in img_groups]`` with
+    ``run_scene_mixed``'s view order and schedule.  The scenes ride the batch dimension of ``forward_list`` (decoder.py:158-265 takes
+    lists of [B, nimg_i, N_i, C]); encoder calls are batched over S x n_g views per aspect ratio.
+
+    Returns dict(update=[per-view [S,H,W,7]], render=[per-group [S,n_g,H_g,W_g,7]], mem[, pts3d/pts3d_local/conf per group])."""
+    S = int(img_groups[0].shape[0])
+    enc = []
+    for g in img_groups:
+        _, n, _, H, W = g.shape
+        ts = torch.tensor([[H, W]] * n, dtype=torch.int64)
+        x, pos = encoder(g.reshape(S * n, 3, H, W), ts.repeat(S, 1))
+        enc.append((x.view(S, n, *x.shape[1:]), pos.view(S, n, *pos.shape[1:]), ts.unsqueeze(0).expand(S, -1, -1)))
+    owner = [(gi, j) for gi, g in enumerate(img_groups) for j in range(g.shape[1])]
+    V = len(owner)
+    if mem_batches is None:
+        mem_batches = demo_mem_batches(V)
+    if hasattr(decoder, "reserve_memory_tokens"):
+        decoder.reserve_memory_tokens = sum(int(enc[gi][0].shape[2]) for gi, _ in owner[:sum(mem_batches)])
+    mem, upd, i = None, [], 0
+    for nb in mem_batches:
+        batch = owner[i:i + nb]
+        gids = sorted({gi for gi, _ in batch})
+        xs, ps, tss = [], [], []
+        for gi in gids:
+            js = [j for g2, j in batch if g2 == gi]
+            x, pos, ts = enc[gi]
+            xs.append(x[:, js[0]:js[-1] + 1].contiguous())
+            ps.append(pos[:, js[0]:js[-1] + 1].contiguous())
+            tss.append(ts[:, js[0]:js[-1] + 1])
+        if len(gids) == 1:
+            mem, pm = decoder(xs[0], ps[0], tss[0], mem)
+            pms = [pm]
+        else:
+            mem, pms = decoder(xs, ps, tss, mem)
+        for pm in pms:
+            upd += [pm[:, k] for k in range(pm.shape[1])]
+        i += nb
+    _, ren = decoder([e[0] for e in enc], [e[1] for e in enc], [e[2] for e in enc], mem, render=True)
+    out = {"update": upd, "render": list(ren), "mem": mem}
+    if activate:
+        pp = [postprocess(r) for r in out["render"]]
+        for k in ("pts3d", "pts3d_local", "conf"):
+            out[k] = [p[k] for p in pp]
+    return out
+
+
 # ------------------------------------------------------------------------------------------------------------------
 # memory surgery of the L3 engine (SURVEY.md section 8f rank 2) -- same semantics as the reference helpers
 # engine/inference.py:205-228, but the per-layer buffers are compacted IN PLACE, so the tensors stay prefix views of

@@ -1,0 +1,51 @@
+#!/bin/bash
+# r04 closing evidence: everything the bench line's roofline numbers can be recomputed from, taken at ONE commit.
+#   1. rocprofv3 --kernel-trace --stats of `bench.py --step-only` (the S-scene step and nothing else: per-symbol averages = the line's)
+#   2. separate --pmc passes of the SAME command (kernel-trace only; --steps 1 --warmup 1):
+#        FETCH_SIZE | WRITE_SIZE | TCC_HIT_sum TCC_MISS_sum | SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_WAVES GRBM_GUI_ACTIVE
+#   S (scenes in flight) for the PMC passes: $M3R_PMC_SCENES (default 8: rocprofv3 hung on the 20-scene step in r03); recorded in the summary.
+# Output: gpurun_out/r04_step_* ; scripts/prof_match.py joins them into profiles/r04_roofline_evidence.{json,txt}
+set -u
+cd "${GRAFT_REPO_ROOT:-/root/repo}"
+export TMPDIR=/tmp PYTHONDONTWRITEBYTECODE=1
+O=gpurun_out
+S_STEP=${M3R_STEP_SCENES:-20}
+S_PMC=${M3R_PMC_SCENES:-8}
+mkdir -p $O
+rm -rf $O/prof_step
+echo "== kernel trace of the step (S=$S_STEP)"
+timeout 600 rocprofv3 --kernel-trace --stats -d $O/prof_step -o step -- python bench.py --gpus 1 --steps 3 --warmup 1 --scenes $S_STEP --step-only > $O/r04_step_line.json 2> $O/r04_step.err
+echo "rc=$?"; tail -c 300 $O/r04_step_line.json | head -c 300; echo
+python scripts/prof_summary.py $(ls $O/prof_step/*.db $O/prof_step/*/*.db 2>/dev/null | tail -1) $O/r04_step_kernel_stats.txt | head -14
+find $O/prof_step -name "*.db" -size +20M -delete; find $O/prof_step -name "*.csv" -size +8M -delete
+pmc_pass() {   # $1 = tag, rest = counters
+  local TAG=$1; shift
+  rm -rf $O/pmc_$TAG
+  echo "== pmc $TAG: $* (S=$S_PMC)"
+  timeout 420 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $O/pmc_$TAG -o run -- \
+      python bench.py --gpus 1 --steps 1 --warmup 1 --scenes $S_PMC --step-only > $O/pmc_$TAG.log 2>&1
+  echo "rc=$?"
+  python - "$TAG" "$S_PMC" "$@" <<'PY'
+import sys, glob, json, csv, re, collections
+tag, scenes, ctrs = sys.argv[1], int(sys.argv[2]), sys.argv[3:]
+files = glob.glob(f"gpurun_out/pmc_{tag}/**/*counter_collection.csv", recursive=True)
+agg = collections.defaultdict(lambda: collections.defaultdict(float))
+cnt = collections.defaultdict(lambda: collections.Counter())
+for f in files:
+    with open(f) as fh:
+        for row in csv.DictReader(fh):
+            name = re.sub(r"\(.*", "", row.get("Kernel_Name", ""))[:140]
+            agg[name][row["Counter_Name"]] += float(row["Counter_Value"])
+            cnt[name][row["Counter_Name"]] += 1
+out = {k: {"launches": max(cnt[k].values()), **{c: v / max(1, cnt[k][c]) for c, v in d.items()}} for k, d in agg.items() if "m3r" in k}
+json.dump({"tag": tag, "counters": ctrs, "scenes": scenes, "per_launch_means": out}, open(f"gpurun_out/r04_pmc_{tag}.json", "w"), indent=1)
+print(tag, "kernels:", len(out))
+PY
+  find $O/pmc_$TAG -name "*.csv" -size +4M -delete; find $O/pmc_$TAG -name "*.db" -size +20M -delete
+}
+pmc_pass fetch FETCH_SIZE
+pmc_pass write WRITE_SIZE
+pmc_pass tcc TCC_HIT_sum TCC_MISS_sum
+pmc_pass sq SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_WAVES GRBM_GUI_ACTIVE
+python scripts/prof_match.py
+echo "== profile done"

@@ -157,3 +157,42 @@ def test_linear_activation_in_the_fused_postprocess(compute_cam):
     a = postprocess(pm.cuda(), compute_cam=compute_cam)
     b = postprocess(pm.cuda(), pointmaps_activation=ActivationType.NORM_EXP, compute_cam=compute_cam)
     assert all(torch.equal(a[k], b[k]) for k in a)
+
+
+def test_mixed_resolution_scenes_in_flight_equal_their_single_scene_runs():
+    """engine.run_scenes_mixed (BASELINE.json configs[4] with S scenes riding forward_list's batch dimension) against engine.run_scene_mixed
+    of every scene alone and against the oracle's list path."""
+    from must3r_amd.engine import run_scene_mixed, run_scenes_mixed
+    from oracle import must3r_ref as R
+    cfg = TINY
+    enc, dec = build(cfg, "fp16w2")
+    sde, sdd = S.make_encoder_state_dict(cfg, 0), S.make_decoder_state_dict(cfg, 0)
+    shapes = [(2, 48, 64), (1, 32, 64), (2, 64, 64)]
+    Sn = 3
+    groups = [torch.stack([S.make_images(n, h, w, 70 + 10 * b + gi)[0] for b in range(Sn)]) for gi, (n, h, w) in enumerate(shapes)]
+    out = run_scenes_mixed(enc, dec, [g.cuda() for g in groups])
+    torch.cuda.synchronize()
+    assert [tuple(r.shape) for r in out["render"]] == [(Sn, n, h, w, 7) for n, h, w in shapes]
+    worst = 0.0
+    for b in range(Sn):
+        one = run_scene_mixed(enc, dec, [g[b].cuda() for g in groups])
+        for gi in range(len(shapes)):
+            worst = max(worst, rel_inf(out["render"][gi][b].cpu(), one["render"][gi].cpu()))
+            assert torch.allclose(out["pts3d"][gi][b], one["pts3d"][gi], rtol=1e-2, atol=1e-3)
+        for v, u in enumerate(one["update"]):
+            worst = max(worst, rel_inf(out["update"][v][b].cpu(), u.cpu()))
+    # oracle of scene 1: encode per group, update [2,1,1,1] over the view order (group order, then order in the group), render all groups
+    b = 1
+    xs = [R.encoder_forward(sde, cfg, g[b], torch.tensor([[g.shape[-2], g.shape[-1]]] * g.shape[1])) for g in groups]
+    tss = [torch.tensor([[g.shape[-2], g.shape[-1]]] * g.shape[1]) for g in groups]
+    U = lambda t: t.unsqueeze(0)  # noqa: E731
+    mem, _ = R.decoder_forward(sdd, cfg, U(xs[0][0]), U(xs[0][1]), U(tss[0]), None, False, "kv")
+    mem, _ = R.decoder_forward(sdd, cfg, U(xs[1][0]), U(xs[1][1]), U(tss[1]), mem, False, "kv")
+    for j in range(2):
+        mem, _ = R.decoder_forward(sdd, cfg, U(xs[2][0][j:j + 1]), U(xs[2][1][j:j + 1]), U(tss[2][j:j + 1]), mem, False, "kv")
+    err = 0.0
+    for gi in range(len(shapes)):
+        _, ro = R.decoder_forward(sdd, cfg, U(xs[gi][0]), U(xs[gi][1]), U(tss[gi]), mem, True, "kv")
+        err = max(err, rel_inf(out["render"][gi][b].cpu(), torch.as_tensor(ro)[0]))
+    record("mixed_scenes_in_flight", vs_single=worst, vs_oracle=err)
+    assert worst < TOL["fp16w2"] and err < TOL["fp16w2"], (worst, err)
