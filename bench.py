@@ -473,14 +473,16 @@ def main():
     cpu_baseline, parity = None, None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         # the oracle (a port of the reference's CPU path) on the metric's OWN unit of work -- one full 20-view scene: encode 20,
-        # memory update [2,1,...,1], render 20 -- in its own process, <= 32 threads, hard time limit.  It is pinned on the
+        # memory update [2,1,...,1], render 20 -- in its own process, 16 threads (the fastest count measured on the box), hard time limit.  It is pinned on the
         # committed real-reference fixture in the same pass (oracle_vs_reference_fixture), and the HIP pointmaps of ALL
         # views (update and render) are compared with it.
         import subprocess
         import tempfile
         import numpy as np
         ncores = os.cpu_count() or 1
-        threads = min(32, ncores)
+        # 16 threads: the best count on the GPU box's host (profiles/r04_cpu_threads.txt: the 2-view scene takes 2.1 / 3.9 / 8.3 / 20.1 s at
+        # 16 / 32 / 64 / 128 threads -- torch's CPU GEMMs lose to NUMA traffic and oversubscription beyond one socket's slice)
+        threads = min(16, ncores)
         nv = min(args.cpu_views, V)
         with tempfile.TemporaryDirectory() as td:
             outp = os.path.join(td, "cpu.npz")

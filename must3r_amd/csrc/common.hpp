@@ -166,8 +166,13 @@ __device__ __forceinline__ int swz32(int row, int chunk) {
     const int q = (row >> 2) & 3;
     return chunk ^ ((0x1320 >> (q * 4)) & 3);   // q: 0,1,2,3 -> 0,2,3,1
 }
+// [rows][128 x 16-bit] (256-byte rows = one full bank row, 16 chunks): every row puts logical chunk c on the same banks, so the 16 rows of a
+// fragment read would collide 16 ways; XOR with the row's low 4 bits spreads them over the 16 slots (and keeps the two halves of a
+// ds_read_b128 service group -- rows {0-3, 12-15} at chunk c, rows {4-11} at chunk c ^ 1 -- on disjoint slots).
+__device__ __forceinline__ int swz128(int row, int chunk) { return chunk ^ (row & 15); }
 template <int BK> __device__ __forceinline__ int swzk(int row, int chunk) {
-    if constexpr (BK == 64) return swz(row, chunk);
+    if constexpr (BK == 128) return swz128(row, chunk);
+    else if constexpr (BK == 64) return swz(row, chunk);
     else return swz32(row, chunk);
 }
 

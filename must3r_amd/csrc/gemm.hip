@@ -1165,10 +1165,16 @@ static int launch_256k(const GemmArgs& a, hipStream_t s) {
 // MFMAs per wave and K-tile.  Measured (split weights, M = N = 768): proj 8.0 -> 6.9 us, fc2 20.6 -> 18.9 us, same bits.
 // (The K-loop slope stays ~0.33 us per tile even here, so per-wave issue is not the whole story either; the gain is in
 // the fixed part.)  Plain weights (r03): 12 pieces over 9 waves -- waves 0-2 issue two per tile, the others one, each counting its own.
-template <class T, int EPI, int WS, int NST>
+// r04: K-tile depth BK = 128 where K allows (every launch of the scene: K = 768 / 3072).  The K loop of these launches is a latency chain per
+// tile -- counted wait, block barrier, DMA issue, fragment reads, two dependent MFMAs per weight part -- of ~0.33 us whatever the tile holds
+// (profiles/r02_gemm_small_*.txt: the slope is per TILE, not per byte); 128-deep tiles walk the chain half as often.  256-byte LDS rows, 4 rows per
+// DMA piece, swz128; the fragments of the four 32-deep steps are read up front, the accumulation order (k ascending, hi before lo per step) and
+// therefore the bits are those of every other tile shape.
+template <class T, int EPI, int WS, int NST, int BK>
 __global__ void __launch_bounds__(576) gemm48_kernel(const GemmArgs p) {
     typedef typename Vec<T>::v8 v8;
-    constexpr int BM = 48, BN = 48, BK = 64, NW = 9, RPP = 8;
+    static_assert(BK == 64 || BK == 128, "K-tile depth");
+    constexpr int BM = 48, BN = 48, NW = 9, CPR = BK / 8, RPP = 64 / CPR, KS = BK / 32;
     constexpr int ROWS = BM + WS * BN;                 // staging region: A rows, then W rows (hi, then lo)
     constexpr int NPIECE = ROWS / RPP;                 // 18 (split: 2 per wave) or 12 (plain: waves 0-2 issue 2, the others 1)
     constexpr int STAGE = ROWS * BK;
@@ -1201,7 +1207,7 @@ __global__ void __launch_bounds__(576) gemm48_kernel(const GemmArgs p) {
     constexpr int TMAX = (NPIECE + NW - 1) / NW;
     constexpr int NFULL = NPIECE - NW * (TMAX - 1);   // waves that issue TMAX pieces per tile; the others TMAX - 1 (their counted vmcnt differs)
     const bool full_wave = wave < NFULL;
-    const int srow = lane >> 3, pch = lane & 7;
+    const int srow = lane / CPR, pch = lane % CPR;
     const T* src[TMAX];
     bool has[TMAX];
 #pragma unroll
@@ -1212,10 +1218,10 @@ __global__ void __launch_bounds__(576) gemm48_kernel(const GemmArgs p) {
         if (r < BM) {
             int gr = m0 + r;
             gr = gr < p.M ? gr : p.M - 1;
-            src[t] = A + (size_t)gr * p.lda + swz(r, pch) * 8;
+            src[t] = A + (size_t)gr * p.lda + swzk<BK>(r, pch) * 8;
         } else {
             const int rr = r - BM, part = rr / BN, wrow = rr - part * BN;
-            src[t] = W + (size_t)(n0 + wrow) * (size_t)(p.K * WS) + (size_t)part * p.K + swz(rr, pch) * 8;
+            src[t] = W + (size_t)(n0 + wrow) * (size_t)(p.K * WS) + (size_t)part * p.K + swzk<BK>(rr, pch) * 8;
         }
     }
     auto stage = [&](int kt, int buf) {
@@ -1231,15 +1237,15 @@ __global__ void __launch_bounds__(576) gemm48_kernel(const GemmArgs p) {
     epilogue_prefetch<T, EPI, 1>(p, outp, bias, m0 + wm * 16 + fr, n0 + wn * 16, fg, pre);
     constexpr bool LNF = EPI == EPI_STORE16 || EPI == EPI_STORE16_GELU;
     float* const sm_ln = reinterpret_cast<float*>(smem + (size_t)NST * STAGE * sizeof(T));
-    int a_off[2], w_off[2][WS];
+    int a_off[KS], w_off[KS][WS];
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
+    for (int ks = 0; ks < KS; ++ks) {
         const int r = wm * 16 + fr;
-        a_off[ks] = r * BK + swz(r, ks * 4 + fg) * 8;
+        a_off[ks] = r * BK + swzk<BK>(r, ks * 4 + fg) * 8;
 #pragma unroll
         for (int part = 0; part < WS; ++part) {
             const int rr = part * BN + wn * 16 + fr;
-            w_off[ks][part] = (BM + rr) * BK + swz(rr, ks * 4 + fg) * 8;
+            w_off[ks][part] = (BM + rr) * BK + swzk<BK>(rr, ks * 4 + fg) * 8;
         }
     }
 #pragma unroll
@@ -1263,15 +1269,15 @@ __global__ void __launch_bounds__(576) gemm48_kernel(const GemmArgs p) {
             stage(nt, nb);
         }
         const T* base = lds + buf * STAGE;
-        v8 af[2], wf[2][WS];
+        v8 af[KS], wf[KS][WS];
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
+        for (int ks = 0; ks < KS; ++ks) {
             af[ks] = *reinterpret_cast<const v8*>(base + a_off[ks]);
 #pragma unroll
             for (int part = 0; part < WS; ++part) wf[ks][part] = *reinterpret_cast<const v8*>(base + w_off[ks][part]);
         }
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
+        for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
             for (int part = 0; part < WS; ++part) acc = mfma16(wf[ks][part], af[ks], acc);
         buf = buf + 1 == NST ? 0 : buf + 1;
@@ -1290,18 +1296,35 @@ __global__ void __launch_bounds__(576) gemm48_kernel(const GemmArgs p) {
     }
 }
 
-template <class T, int EPI, int WS>
-static int launch_48(const GemmArgs& a, hipStream_t s) {
-    constexpr int NST = 6;
+template <class T, int EPI, int WS, int BK>
+static int launch_48k(const GemmArgs& a, hipStream_t s) {
+    constexpr int NST = BK == 128 ? (WS == 2 ? 4 : 6) : 6;   // 4 x 36 KB (split) / 6 x 24 KB (plain) of 128-deep stages; 6 x 18 / 12 KB at 64
     const int nbn = a.N / 48, nbm = (a.M + 47) / 48;
-    const size_t lds = (size_t)NST * (48 + WS * 48) * 64 * sizeof(T) + ln_fold_lds_bytes<48, 576>();
+    const size_t lds = (size_t)NST * (48 + WS * 48) * BK * sizeof(T) + ln_fold_lds_bytes<48, 576>();
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm48_kernel<T, EPI, WS, NST>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm48_kernel<T, EPI, WS, NST, BK>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm48_kernel<T, EPI, WS, NST>), dim3(nbm * nbn, a.batch > 1 ? a.batch : 1), dim3(576), lds, s, a);
+    hipLaunchKernelGGL((gemm48_kernel<T, EPI, WS, NST, BK>), dim3(nbm * nbn, a.batch > 1 ? a.batch : 1), dim3(576), lds, s, a);
     return hipGetLastError() == hipSuccess ? 0 : 1;
+}
+// M3R_BK128 (A/B instrument): 0 = 64-deep K-tiles everywhere (the r03 kernels).  Measured (profiles/r04_bk128_m768.txt): same
+// bits; fc2 (K = 3072) 17.4 -> 14.1 us plain, 19.0 -> 17.9 us split; the K = 768 launches +-0.2 us (their 12 tiles are not what they spend their
+// time on); one-scene-at-a-time 331 -> 336 views/s.  The same depth in the 64 x 64 ring kernels (2 x 128-deep stages): qkv 11.1 -> 15.1 us,
+// K|V 10.2 -> 14.4 us, fc1 13.3 -> 12.5 us, scene 326 views/s -- not kept.
+static int bk128_mode() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("M3R_BK128");
+        v = e ? atoi(e) : 1;
+    }
+    return v;
+}
+template <class T, int EPI, int WS>
+static int launch_48(const GemmArgs& a, hipStream_t s) {
+    if (a.K % 128 == 0 && a.K >= 256 && bk128_mode() != 0) return launch_48k<T, EPI, WS, 128>(a, s);
+    return launch_48k<T, EPI, WS, 64>(a, s);
 }
 
 // ------------------------------------------------------------------------------------------------------------------

@@ -727,7 +727,11 @@ extern "C" int must3r_hip_encode(must3r_hip_ctx* c, int dtype, const float* img,
     DeviceGuard dev_guard(c->device);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const int N = (H / 16) * (W / 16);
-    int per = 32768 / N;  // bound the workspace: ~32k token rows per chunk ...
+    // rows per chunk: bounds the workspace (~32k token rows: the 16-bit activations of a chunk stay inside the 256 MB MALL between producer and
+    // consumer launches).  M3R_ENC_CHUNK_ROWS: A/B instrument -- larger chunks lose less to the round quantisation of the
+    // one-block-per-CU GEMMs (40 views: 94 % tile fill; 64 / 128 views: 100 %) but stream their activations through HBM.
+    static const int chunk_rows = getenv("M3R_ENC_CHUNK_ROWS") ? atoi(getenv("M3R_ENC_CHUNK_ROWS")) : 32768;
+    int per = (chunk_rows > 0 ? chunk_rows : 32768) / N;
     if (per < 1) per = 1;
     {   // ... in chunks of equal size (80 views of 768 tokens: 2 x 40 -- 94 % tile fill -- instead of 42 + 38)
         const int nch = (n_views + per - 1) / per;

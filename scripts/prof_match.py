@@ -69,7 +69,7 @@ def main():
                 tot = sum(stats[s]["total_ms"] for s in syms)
                 row["rocprof_calls_whole_process"] = calls
                 row["rocprof_avg_us"] = round(tot * 1e3 / max(1, calls), 2)
-                row["frac_from_rocprof"] = round(r["algorithmic_gflop_per_launch"] / row["rocprof_avg_us"] / 1e3 / 2500.0, 4)
+                row["frac_from_rocprof"] = round(r["algorithmic_gflop_per_launch"] / row["rocprof_avg_us"] * 1e3 / 2.5e6, 4)   # GF / us = PF/s
             for tag, d in pmc.items():
                 if not d:
                     continue
@@ -90,8 +90,10 @@ def main():
                     busy, act = mean("SQ_VALU_MFMA_BUSY_CYCLES"), mean("GRBM_GUI_ACTIVE")
                     row["SQ_VALU_MFMA_BUSY_CYCLES"] = int(busy)
                     row["GRBM_GUI_ACTIVE"] = int(act)
-                    # busy cycles summed over the 1024 SIMDs of the chip / (1024 x kernel cycles) = share of time a SIMD's matrix pipe is busy
-                    row["mfma_pipe_busy_share"] = round(busy / 1024.0 / max(1.0, act), 4)
+                    # SQ_VALU_MFMA_BUSY_CYCLES is summed over the chip's 1024 SIMDs (= 16 x SQ_INSTS_MFMA for the 16x16x32 MFMA), GRBM_GUI_ACTIVE over the
+                    # 8 XCDs (cross-check: SQ_BUSY_CYCLES / 32 shader engines gives the same kernel cycles): share of time a SIMD's matrix pipe is busy
+                    row["kernel_cycles"] = int(act / 8.0)
+                    row["mfma_pipe_busy_share"] = round(busy / 1024.0 / max(1.0, act / 8.0), 4)
                     row["valu_per_mfma"] = round(mean("SQ_INSTS_VALU") / max(1.0, mean("SQ_INSTS_MFMA")), 2)
                 row.setdefault("pmc_scenes", d["scenes"])
             if "FETCH_SIZE_KiB_per_launch" in row and "WRITE_SIZE_KiB_per_launch" in row:
@@ -102,7 +104,7 @@ def main():
            "command_pmc": "rocprofv3 --kernel-trace --pmc <set> -- python bench.py --gpus 1 --steps 1 --warmup 1 --scenes S_pmc --step-only (one pass per set)",
            "line": {k: line.get(k) for k in ("value", "ms_per_step", "config", "roofline", "roofline_attention", "kernel_classes", "end_to_end_mfma_frac")},
            "rows": rows,
-           "how_to_recompute": "frac = algorithmic_gflop_per_launch / avg_us / 1e3 / 2500 with avg_us from r04_step_kernel_stats.txt (rocprof_avg_us; the trace also "
+           "how_to_recompute": "frac = algorithmic_gflop_per_launch / avg_us * 1e3 / 2.5e6 (GF per us = PF/s; peak 2500 TF/s) with avg_us from r04_step_kernel_stats.txt (rocprof_avg_us; the trace also "
                                "holds the warm-up / stage-split passes of the same step, same launch mix); fabric bytes = (2 FETCH + WRITE) KiB x 1024 (PMC passes "
                                "at pmc_scenes scenes in flight: per-launch figures scale with the rows per launch, compare like with like)"}
     os.makedirs("profiles", exist_ok=True)

@@ -28,7 +28,8 @@ def test_benched_configuration_scenes_in_flight_vs_reference_fixture():
     g = load_golden("must3r512_v20")
     H, W, V, ps, tks = (int(v) for v in g["meta"][:5])
     mb = [int(v) for v in g["meta"][5:]]
-    prec = M.MUSt3R(img_size=(64, 64), enc_embed_dim=64, embed_dim=64, depth=1, num_heads=1).precision   # the module default = bench.py's default
+    import inspect
+    prec = inspect.signature(M.MUSt3R.__init__).parameters["precision"].default   # the module default = bench.py's default
     enc, dec = build(MUST3R_512, prec)
     Sn = 8
     scenes = torch.stack([S.make_images(V, H, W, 0 if b == 0 else 500 + b)[0] for b in range(Sn)]).cuda()
