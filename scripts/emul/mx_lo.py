@@ -29,8 +29,13 @@ def q_grid(v, grid):
     return torch.sign(v) * grid[idx]
 
 
-def mx_quant(t, fmt, unit_scale=False):
+def mx_quant(t, fmt, unit_scale=False, blk=32):
     """MX block quantisation along the last dim, blocks of 32, scale 2^e with the block max mapped into (max/2, max]"""
+    if blk != 32:   # one scale per ROW (it factors out of the K sum: no MX scale hardware needed, separate low-part accumulators instead)
+        grid = GRID[fmt]
+        amax = t.abs().amax(dim=-1, keepdim=True).clamp(min=1e-30)
+        s = torch.exp2(torch.ceil(torch.log2(amax / float(grid[-1]))))
+        return q_grid(t / s, grid) * s
     if fmt == "fp8":
         K = t.shape[-1]
         b = t.reshape(*t.shape[:-1], K // 32, 32)
@@ -49,9 +54,9 @@ def mx_quant(t, fmt, unit_scale=False):
 
 class EmuLo(Emu):
     """lo(name) -> None (plain fp16 weight), "split" (fp16 low part, 2 passes) or an MX format for the low-part product"""
-    def __init__(self, sds, lo, x_unit_scale=False):
+    def __init__(self, sds, lo, x_unit_scale=False, w_blk=32, x_blk=32):
         super().__init__(sds)
-        self.lo, self.x_unit = lo, x_unit_scale
+        self.lo, self.x_unit, self.w_blk, self.x_blk = lo, x_unit_scale, w_blk, x_blk
         self.cache = {}
 
     def linear(self, x, w, b, opq=None):
@@ -68,8 +73,8 @@ class EmuLo(Emu):
         elif mode is not None:
             key = (id(w), mode)
             if key not in self.cache:
-                self.cache[key] = mx_quant(w - wh, mode)
-            y = y + mx_quant(xh, mode, self.x_unit) @ self.cache[key].t()
+                self.cache[key] = mx_quant(w - wh, mode, blk=self.w_blk)
+            y = y + mx_quant(xh, mode, self.x_unit, blk=self.x_blk) @ self.cache[key].t()
         return y + b if b is not None else y
 
 
@@ -93,6 +98,9 @@ def main(V, filt):
         "LN-fed fp4 lo, others plain": lambda n: "fp4" if n.endswith(("attn.qkv.weight", "mlp.fc1.weight", "cross_attn.projq.weight", "cross_attn.projk.weight", "cross_attn.projv.weight", "feedback_layer.fc1.weight", "feat_embed_enc_to_dec.weight")) else None,
         "LN-fed attention-side fp4 lo (qkv, projq, projk/v, enc->dec), others plain": lambda n: "fp4" if n.endswith(("attn.qkv.weight", "cross_attn.projq.weight", "cross_attn.projk.weight", "cross_attn.projv.weight", "feat_embed_enc_to_dec.weight")) else None,
         "all fp4 lo, x unit scale": lambda n: "fp4",
+        "all fp4 lo, per-ROW scales (W and x)": lambda n: "fp4",
+        "all fp4 lo, per-ROW W scale, per-block x": lambda n: "fp4",
+        "all fp4 lo, per-block W, per-ROW x scale": lambda n: "fp4",
         "all fp4 lo but fc2 plain": lambda n: None if "fc2" in n else "fp4",
         "all fp4 lo but fc2 + output proj plain": lambda n: None if ("fc2" in n or n.endswith("proj.weight")) else "fp4",
         "all fp4 lo but output proj plain": lambda n: None if n.endswith("proj.weight") else "fp4",
@@ -103,7 +111,8 @@ def main(V, filt):
     for label, fn in sets.items():
         if filt and not any(f in label for f in filt):
             continue
-        emu = EmuLo((("e.", sde), ("d.", sdd)), fn, x_unit_scale="unit scale" in label)
+        emu = EmuLo((("e.", sde), ("d.", sdd)), fn, x_unit_scale="unit scale" in label,
+                    w_blk=0 if ("per-ROW scales" in label or "per-ROW W" in label) else 32, x_blk=0 if ("per-ROW scales" in label or "per-ROW x" in label) else 32)
         u, r, _ = run_emu(emu, sde, sdd, cfg, imgs, ts)
         print(f"V={V} {label:76s} update {rel(u, u0):.3e} render {rel(r, r0):.3e}", flush=True)
 
