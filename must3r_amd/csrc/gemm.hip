@@ -1649,6 +1649,9 @@ static int g256k_mode() {
     }
     return v;
 }
+// (r04, measured and removed: two 256 x 128 blocks per CU -- the GELU launches' OCC = 2 form -- for the other split-weight epilogues, so that one
+// block's fp32 read-modify-write epilogue runs under the other's K loop: RESID proj 44.7 -> 52.1 us (dec) / 67.2 -> 68.2 us (enc), fc2 122 -> 152 us,
+// STORE16 K|V 71.9 -> 77.8 us, RoPE qkv +-1 %; nine split shapes 1246 -> 1308 us, step 497.6 -> 487.9 views/s.  profiles/r04_occ2_ab.txt.)
 template <class T, int EPI>
 static int launch_epi(const GemmArgs& a, hipStream_t s, const char** err) {
     const long nb = a.batch > 1 ? a.batch : 1;

@@ -2,7 +2,7 @@
 # r04 closing evidence: everything the bench line's roofline numbers can be recomputed from, taken at ONE commit.
 #   1. rocprofv3 --kernel-trace --stats of `bench.py --step-only` (the S-scene step and nothing else: per-symbol averages = the line's)
 #   2. separate --pmc passes of the SAME command (kernel-trace only; --steps 1 --warmup 1):
-#        FETCH_SIZE | WRITE_SIZE | TCC_HIT_sum TCC_MISS_sum | SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_WAVES GRBM_GUI_ACTIVE
+#        L2 -> fabric read requests by size | write requests by size | TCC_HIT_sum TCC_MISS_sum | SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_WAVES GRBM_GUI_ACTIVE
 #   S (scenes in flight) for the PMC passes: $M3R_PMC_SCENES (default 8: rocprofv3 hung on the 20-scene step in r03); recorded in the summary.
 # Output: gpurun_out/r04_step_* ; scripts/prof_match.py joins them into profiles/r04_roofline_evidence.{json,txt}
 set -u
@@ -40,11 +40,18 @@ for f in files:
 out = {k: {"launches": max(cnt[k].values()), **{c: v / max(1, cnt[k][c]) for c, v in d.items()}} for k, d in agg.items() if "m3r" in k}
 json.dump({"tag": tag, "counters": ctrs, "scenes": scenes, "per_launch_means": out}, open(f"gpurun_out/r04_pmc_{tag}.json", "w"), indent=1)
 print(tag, "kernels:", len(out))
+sys.exit(0 if out else 3)
 PY
-  find $O/pmc_$TAG -name "*.csv" -size +4M -delete; find $O/pmc_$TAG -name "*.db" -size +20M -delete
+  local RC=$?
+  find $O/pmc_$TAG -name "*.csv" -size +4M -delete 2>/dev/null; find $O/pmc_$TAG -name "*.db" -size +20M -delete 2>/dev/null
+  return $RC
 }
-pmc_pass fetch FETCH_SIZE
-pmc_pass write WRITE_SIZE
+# fabric traffic: the derived FETCH_SIZE / WRITE_SIZE passes crash rocprofv3 on this image (segfault ~9 s in; r03: hangs) -> on failure the raw
+# L2 -> fabric request counters they are derived from (MI355X_MICROARCH.md "HBM": FETCH_SIZE = TCC_EA0_RDREQ x 64 B)
+rocprofv3 -L 2>/dev/null | grep -o "TCC_EA0_[A-Z0-9_]*\(_sum\)\?" | sort -u | head -40 > $O/r04_tcc_ea0_counters.txt
+pmc_pass fetch TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum
+pmc_pass write TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum
+pmc_pass dram TCC_EA0_RDREQ_DRAM_sum TCC_EA0_RDREQ_sum
 pmc_pass tcc TCC_HIT_sum TCC_MISS_sum
 pmc_pass sq SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_WAVES GRBM_GUI_ACTIVE
 python scripts/prof_match.py

@@ -4,7 +4,8 @@
    * the rocprofv3 --kernel-trace --stats summary of the SAME process (per symbol: calls, avg us)
    * the --pmc passes of the same command (per symbol and launch: FETCH_SIZE, WRITE_SIZE, TCC hit rate, MFMA-busy share)
 so that every `frac` of the line can be recomputed from files under profiles/ alone:  frac = GFLOP/launch / avg_us(rocprof) / 1e3 / 2500.
-Corrections (MI355X_MICROARCH.md "HBM"): bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024; FETCH_SIZE counts MALL hits (fabric, not HBM, traffic)."""
+Fabric bytes = sum over the L2's memory-side requests by size (TCC_EA0_RDREQ_{32,64,128}B, TCC_EA0_WRREQ_64B / rest 32 B): exact, where the derived
+FETCH_SIZE (= RDREQ x 64 B, MI355X_MICROARCH.md "HBM") needs the x2 correction -- and its pass crashes rocprofv3 on this image.  These count MALL hits too."""
 import json
 import os
 import re
@@ -52,7 +53,7 @@ def main():
         if m:
             stats[m.group(1)] = {"calls": int(m.group(2)), "total_ms": float(m.group(3)), "avg_us": float(m.group(4)), "pct": float(m.group(5))}
     pmc = {}
-    for tag in ("fetch", "write", "tcc", "sq"):
+    for tag in ("fetch", "write", "dram", "tcc", "sq"):
         try:
             d = json.load(open(f"{G}/r04_pmc_{tag}.json"))
             pmc[tag] = d
@@ -69,7 +70,7 @@ def main():
                 tot = sum(stats[s]["total_ms"] for s in syms)
                 row["rocprof_calls_whole_process"] = calls
                 row["rocprof_avg_us"] = round(tot * 1e3 / max(1, calls), 2)
-                row["frac_from_rocprof"] = round(r["algorithmic_gflop_per_launch"] / row["rocprof_avg_us"] * 1e3 / 2.5e6, 4)   # GF / us = PF/s
+                row["frac_from_rocprof"] = round(r["algorithmic_gflop_per_launch"] / row["rocprof_avg_us"] * 1e3 / 2500.0, 4)   # GF / us = 1000 TF/s
             for tag, d in pmc.items():
                 if not d:
                     continue
@@ -79,9 +80,16 @@ def main():
                 n = sum(p["launches"] for p in per)
                 mean = lambda c: sum(p.get(c, 0.0) * p["launches"] for p in per) / max(1, n)  # noqa: E731
                 if tag == "fetch":
-                    row["FETCH_SIZE_KiB_per_launch"] = round(mean("FETCH_SIZE"), 1)
+                    # L2 -> fabric read requests by size (exact bytes: no halving correction needed, unlike the derived FETCH_SIZE = RDREQ x 64 B)
+                    r32, r64, r128, rall = mean("TCC_EA0_RDREQ_32B_sum"), mean("TCC_EA0_RDREQ_64B_sum"), mean("TCC_EA0_RDREQ_128B_sum"), mean("TCC_EA0_RDREQ_sum")
+                    row["TCC_EA0_RDREQ_per_launch"] = {"all": int(rall), "32B": int(r32), "64B": int(r64), "128B": int(r128)}
+                    row["fabric_read_bytes_per_launch"] = int(32 * r32 + 64 * r64 + 128 * r128 + 64 * max(0.0, rall - r32 - r64 - r128))
                 elif tag == "write":
-                    row["WRITE_SIZE_KiB_per_launch"] = round(mean("WRITE_SIZE"), 1)
+                    w64, wall = mean("TCC_EA0_WRREQ_64B_sum"), mean("TCC_EA0_WRREQ_sum")
+                    row["TCC_EA0_WRREQ_per_launch"] = {"all": int(wall), "64B": int(w64)}
+                    row["fabric_write_bytes_per_launch"] = int(64 * w64 + 32 * max(0.0, wall - w64))
+                elif tag == "dram":
+                    row["RDREQ_DRAM_share"] = round(mean("TCC_EA0_RDREQ_DRAM_sum") / max(1.0, mean("TCC_EA0_RDREQ_sum")), 4)
                 elif tag == "tcc":
                     h, m_ = mean("TCC_HIT_sum"), mean("TCC_MISS_sum")
                     row["TCC_hit_rate"] = round(h / max(1.0, h + m_), 4)
@@ -96,16 +104,16 @@ def main():
                     row["mfma_pipe_busy_share"] = round(busy / 1024.0 / max(1.0, act / 8.0), 4)
                     row["valu_per_mfma"] = round(mean("SQ_INSTS_VALU") / max(1.0, mean("SQ_INSTS_MFMA")), 2)
                 row.setdefault("pmc_scenes", d["scenes"])
-            if "FETCH_SIZE_KiB_per_launch" in row and "WRITE_SIZE_KiB_per_launch" in row:
-                row["fabric_bytes_per_launch_corrected"] = int((2 * row["FETCH_SIZE_KiB_per_launch"] + row["WRITE_SIZE_KiB_per_launch"]) * 1024)
+            if "fabric_read_bytes_per_launch" in row and "fabric_write_bytes_per_launch" in row:
+                row["fabric_bytes_per_launch_corrected"] = row["fabric_read_bytes_per_launch"] + row["fabric_write_bytes_per_launch"]
             rows.append(row)
     commit = os.environ.get("M3R_COMMIT", "?")
     doc = {"commit": commit, "command_trace": "rocprofv3 --kernel-trace --stats -- python bench.py --gpus 1 --steps 3 --warmup 1 --scenes S --step-only",
            "command_pmc": "rocprofv3 --kernel-trace --pmc <set> -- python bench.py --gpus 1 --steps 1 --warmup 1 --scenes S_pmc --step-only (one pass per set)",
            "line": {k: line.get(k) for k in ("value", "ms_per_step", "config", "roofline", "roofline_attention", "kernel_classes", "end_to_end_mfma_frac")},
            "rows": rows,
-           "how_to_recompute": "frac = algorithmic_gflop_per_launch / avg_us * 1e3 / 2.5e6 (GF per us = PF/s; peak 2500 TF/s) with avg_us from r04_step_kernel_stats.txt (rocprof_avg_us; the trace also "
-                               "holds the warm-up / stage-split passes of the same step, same launch mix); fabric bytes = (2 FETCH + WRITE) KiB x 1024 (PMC passes "
+           "how_to_recompute": "frac = algorithmic_gflop_per_launch / avg_us * 1000 / 2500 (1 GF per us = 1000 TF/s; peak 2500 TF/s) with avg_us from r04_step_kernel_stats.txt (rocprof_avg_us; the trace also "
+                               "holds the warm-up / stage-split passes of the same step, same launch mix); fabric bytes = 32/64/128-byte read requests + 64/32-byte write requests of the L2 (PMC passes "
                                "at pmc_scenes scenes in flight: per-launch figures scale with the rows per launch, compare like with like)"}
     os.makedirs("profiles", exist_ok=True)
     json.dump(doc, open(f"{G}/r04_roofline_evidence.json", "w"), indent=1)
