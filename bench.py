@@ -301,6 +301,27 @@ def main():
                     "per_symbol": symbol_rows(("g",))}
     else:
         roofline = roofline_attention
+    # fabric bytes per launch (L2 -> MALL / HBM requests by size, PMC) from the closing profile of the round, joined per symbol by
+    # scripts/prof_match.py -- only when it was taken at this step size (per-launch bytes scale with the rows per launch)
+    try:
+        ev = json.load(open(os.path.join(ROOT, "profiles", "r04_roofline_evidence.json")))
+        by = {r["kernel"]: r for r in ev["rows"] if r.get("fabric_bytes_per_launch_corrected")}
+        for rf in (roofline, roofline_attention):
+            tot_b = tot_n = 0
+            for row in rf.get("per_symbol", []):
+                e = by.get(row["kernel"])
+                if e and e.get("pmc_scenes") == Sn:
+                    row["traffic"] = e["fabric_bytes_per_launch_corrected"]
+                    row["TCC_hit_rate"], row["mfma_pipe_busy_share"] = e.get("TCC_hit_rate"), e.get("mfma_pipe_busy_share")
+                    tot_b += row["traffic"] * row["launches"]; tot_n += row["launches"]
+            if tot_n:
+                rf["traffic"] = int(tot_b / tot_n)
+                rf["traffic_unit"] = "fabric bytes per launch (sized TCC_EA0 read / write requests, launch-weighted over the class's symbols)"
+                rf["traffic_source"] = f"profiles/r04_roofline_evidence.json (separate --pmc passes of `bench.py --step-only`, commit {ev.get('commit', '?')}; not this run)"
+            elif by:
+                rf["traffic_note"] = f"profiles/r04_roofline_evidence.json was taken at another number of scenes in flight than this run's {Sn}"
+    except Exception:
+        pass
 
     # postprocess(compute_cam=True) on one scene's 20 rendered pointmaps (HBM-bound:
     # 28 B read + 28 B written per pixel; the focal iteration and the registration add no HBM pass)

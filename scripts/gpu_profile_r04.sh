@@ -3,14 +3,15 @@
 #   1. rocprofv3 --kernel-trace --stats of `bench.py --step-only` (the S-scene step and nothing else: per-symbol averages = the line's)
 #   2. separate --pmc passes of the SAME command (kernel-trace only; --steps 1 --warmup 1):
 #        L2 -> fabric read requests by size | write requests by size | TCC_HIT_sum TCC_MISS_sum | SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_WAVES GRBM_GUI_ACTIVE
-#   S (scenes in flight) for the PMC passes: $M3R_PMC_SCENES (default 8: rocprofv3 hung on the 20-scene step in r03); recorded in the summary.
+#   S (scenes in flight) for the PMC passes: $M3R_PMC_SCENES (default 20 = the step's; falls back to 8 when the first pass fails -- rocprofv3 hung on
+#   the 20-scene step in r03); recorded in the summary.
 # Output: gpurun_out/r04_step_* ; scripts/prof_match.py joins them into profiles/r04_roofline_evidence.{json,txt}
 set -u
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 export TMPDIR=/tmp PYTHONDONTWRITEBYTECODE=1
 O=gpurun_out
 S_STEP=${M3R_STEP_SCENES:-20}
-S_PMC=${M3R_PMC_SCENES:-8}
+S_PMC=${M3R_PMC_SCENES:-20}
 mkdir -p $O
 rm -rf $O/prof_step
 echo "== kernel trace of the step (S=$S_STEP)"
@@ -49,7 +50,7 @@ PY
 # fabric traffic: the derived FETCH_SIZE / WRITE_SIZE passes crash rocprofv3 on this image (segfault ~9 s in; r03: hangs) -> on failure the raw
 # L2 -> fabric request counters they are derived from (MI355X_MICROARCH.md "HBM": FETCH_SIZE = TCC_EA0_RDREQ x 64 B)
 rocprofv3 -L 2>/dev/null | grep -o "TCC_EA0_[A-Z0-9_]*\(_sum\)\?" | sort -u | head -40 > $O/r04_tcc_ea0_counters.txt
-pmc_pass fetch TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum
+pmc_pass fetch TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum || { echo "fetch pass failed at S=$S_PMC -> 8 scenes for all passes"; S_PMC=8; pmc_pass fetch TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum; }
 pmc_pass write TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum
 pmc_pass dram TCC_EA0_RDREQ_DRAM_sum TCC_EA0_RDREQ_sum
 pmc_pass tcc TCC_HIT_sum TCC_MISS_sum
