@@ -3,15 +3,15 @@
 #   1. rocprofv3 --kernel-trace --stats of `bench.py --step-only` (the S-scene step and nothing else: per-symbol averages = the line's)
 #   2. separate --pmc passes of the SAME command (kernel-trace only; --steps 1 --warmup 1):
 #        L2 -> fabric read requests by size | write requests by size | TCC_HIT_sum TCC_MISS_sum | SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_WAVES GRBM_GUI_ACTIVE
-#   S (scenes in flight) for the PMC passes: $M3R_PMC_SCENES (default 20 = the step's; falls back to 8 when the first pass fails -- rocprofv3 hung on
-#   the 20-scene step in r03); recorded in the summary.
+#   S (scenes in flight) for the PMC passes: $M3R_PMC_SCENES (default 8: rocprofv3 hangs on the 20-scene step -- r03, and again in r04: 420 s timeout --;
+#   M3R_PMC_SCENES=20 falls back to 8 when the first pass fails); recorded in the summary.
 # Output: gpurun_out/r04_step_* ; scripts/prof_match.py joins them into profiles/r04_roofline_evidence.{json,txt}
 set -u
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 export TMPDIR=/tmp PYTHONDONTWRITEBYTECODE=1
 O=gpurun_out
 S_STEP=${M3R_STEP_SCENES:-20}
-S_PMC=${M3R_PMC_SCENES:-20}
+S_PMC=${M3R_PMC_SCENES:-8}
 mkdir -p $O
 rm -rf $O/prof_step
 echo "== kernel trace of the step (S=$S_STEP)"

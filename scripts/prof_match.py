@@ -107,6 +107,20 @@ def main():
             if "fabric_read_bytes_per_launch" in row and "fabric_write_bytes_per_launch" in row:
                 row["fabric_bytes_per_launch_corrected"] = row["fabric_read_bytes_per_launch"] + row["fabric_write_bytes_per_launch"]
             rows.append(row)
+    # rows that share a rocprofv3 symbol (self and cross attention run the same kernel): the trace cannot tell them apart, so the recomputed
+    # fraction is that of the symbol as a whole -- sum of the rows' algorithmic GFLOP over the symbol's total time
+    groups = {}
+    for r in rows:
+        if r.get("symbols"):
+            groups.setdefault(tuple(r["symbols"]), []).append(r)
+    for syms, rs in groups.items():
+        if len(rs) > 1:
+            gf = sum(r["algorithmic_gflop_per_launch"] * r["launches"] for r in rs)
+            n = sum(r["launches"] for r in rs)
+            us = rs[0]["rocprof_avg_us"]
+            for r in rs:
+                r["frac_from_rocprof"] = round(gf / n / us * 1e3 / 2500.0, 4)
+                r["frac_from_rocprof_note"] = "symbol shared by " + " + ".join(x["kernel"] for x in rs) + ": fraction of the symbol as a whole"
     commit = os.environ.get("M3R_COMMIT", "?")
     doc = {"commit": commit, "command_trace": "rocprofv3 --kernel-trace --stats -- python bench.py --gpus 1 --steps 3 --warmup 1 --scenes S --step-only",
            "command_pmc": "rocprofv3 --kernel-trace --pmc <set> -- python bench.py --gpus 1 --steps 1 --warmup 1 --scenes S_pmc --step-only (one pass per set)",
