@@ -72,12 +72,129 @@ __global__ void __launch_bounds__(256) ln_kernel(const LnArgs p) {
     }
 }
 
+// r04: the same arithmetic per row (same bits), several rows per wave.  A wave of ln_kernel loads its row, reduces twice, loads the affine
+// parameters, stores and exits: every row pays the full memory latency once, in series with two cross-lane reductions, and the launch is 7680-76800
+// four-row blocks long.  Here a wave walks rows (stride = waves of the grid), requests row r + stride BEFORE it reduces row r, and keeps gamma / beta
+// in registers (ungrouped launches).  NV = float4 chunks per lane (C <= 256 NV).
+template <class T, int NV>
+__global__ void __launch_bounds__(256) ln_rows_kernel(const LnArgs p) {
+    typedef typename Vec<T>::v4 v4;
+    const int lane = threadIdx.x & 63;
+    const int nwaves = gridDim.x * 4;
+    int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= p.M) return;
+    const bool grouped = p.rows_per_group > 0;
+    bool act[NV];
+    f32x4 w[NV], b[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        act[i] = (i * 64 + lane) * 4 < p.C;
+        w[i] = b[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (act[i] && !grouped) {
+            w[i] = *reinterpret_cast<const f32x4*>(p.w + (i * 64 + lane) * 4);
+            b[i] = *reinterpret_cast<const f32x4*>(p.b + (i * 64 + lane) * 4);
+        }
+    }
+    auto load = [&](int r, f32x4 (&v)[NV]) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = (i * 64 + lane) * 4;
+            v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (act[i]) {
+                if (p.x) v[i] = *reinterpret_cast<const f32x4*>(p.x + (size_t)r * p.C + c);
+                else v[i] = __builtin_convertvector(*reinterpret_cast<const v4*>(reinterpret_cast<const T*>(p.x16) + (size_t)r * p.C + c), f32x4);
+            }
+        }
+    };
+    f32x4 v[NV], nx[NV];
+    load(row, v);
+    for (; row < p.M; row += nwaves) {
+        const int nr = row + nwaves;
+        if (nr < p.M) load(nr, nx);
+        const float* addp = p.add ? p.add + (size_t)row * p.C : nullptr;
+        if (grouped) {
+            const int g = row / p.rows_per_group;
+            addp = (p.add && g < p.add_groups) ? p.add + (size_t)(row - g * p.rows_per_group) * p.C : nullptr;
+#pragma unroll
+            for (int i = 0; i < NV; ++i)
+                if (act[i]) {
+                    w[i] = *reinterpret_cast<const f32x4*>(p.w + (size_t)g * p.C + (i * 64 + lane) * 4);
+                    b[i] = *reinterpret_cast<const f32x4*>(p.b + (size_t)g * p.C + (i * 64 + lane) * 4);
+                }
+        }
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = (i * 64 + lane) * 4;
+            if (act[i]) {
+                if (addp) v[i] += *reinterpret_cast<const f32x4*>(addp + c);
+                if (p.copy32) *reinterpret_cast<f32x4*>(p.copy32 + (size_t)row * p.C + c) = v[i];
+                if (p.raw16) *reinterpret_cast<v4*>(reinterpret_cast<T*>(p.raw16) + (size_t)row * p.C + c) = cvt4<T>(v[i]);
+                s += v[i][0] + v[i][1] + v[i][2] + v[i][3];
+            }
+        }
+        const float mean = wave_sum_dpp(s) / (float)p.C;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+            if (act[i]) {
+                v[i] -= mean;
+                q += v[i][0] * v[i][0] + v[i][1] * v[i][1] + v[i][2] * v[i][2] + v[i][3] * v[i][3];
+            }
+        const float rstd = rsqrtf(wave_sum_dpp(q) / (float)p.C + p.eps);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = (i * 64 + lane) * 4;
+            if (act[i]) {
+                const f32x4 y = v[i] * rstd * w[i] + b[i];
+                if (p.out32) *reinterpret_cast<f32x4*>(p.out32 + (size_t)row * p.C + c) = y;
+                if (p.out16) {
+                    const size_t ld = p.ld16 ? (size_t)p.ld16 : (size_t)p.C;
+                    const v4 h = cvt4<T>(y);
+                    *reinterpret_cast<v4*>(reinterpret_cast<T*>(p.out16) + row * ld + c) = h;
+                    if (p.out16_dup) *reinterpret_cast<v4*>(reinterpret_cast<T*>(p.out16_dup) + row * ld + c) = h;
+                    if (p.out16_lo) {
+                        const f32x4 hf = __builtin_convertvector(h, f32x4);
+                        *reinterpret_cast<v4*>(reinterpret_cast<T*>(p.out16_lo) + row * ld + c) = cvt4<T>(y - hf);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NV; ++i) v[i] = nx[i];
+    }
+}
+
+// M3R_LN_ROWS (A/B instrument): 0 = one row per wave (ln_kernel, r01-r03), 1 = row-walking waves with the next row in flight (default)
+static int ln_rows_mode() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("M3R_LN_ROWS");
+        v = e ? atoi(e) : 1;
+    }
+    return v;
+}
+template <class T>
+static void launch_ln_t(const LnArgs& a, hipStream_t s) {
+    // Measured (profiles/r04_ln_rows_ab.txt, same bits): the walk wins where the rows stream from HBM -- the render batch, 307200 x 768:
+    // 324 -> 276 us, 4.4 -> 5.1 TB/s -- and loses where the producer GEMM left them in the 256 MB MALL -- an encoder chunk, 30720 x 1024:
+    // 32.4 -> 39.2 us (5.8 -> 4.8 TB/s: 194 VGPRs = 2 walkers per SIMD cannot keep as many lines in flight as 8 one-row waves can).
+    // Hence: only launches whose rows cannot be MALL-resident (> 64 k rows = 300+ MB).
+    const int grid_one = (a.M + 3) / 4;
+    if (ln_rows_mode() == 0 || a.M < 65536) {
+        hipLaunchKernelGGL(ln_kernel<T>, dim3(grid_one), dim3(256), 0, s, a);
+        return;
+    }
+    const int grid = 256 * 8;   // 8 resident blocks per CU (32 waves): every wave slot of the chip holds one walker
+    if (a.C <= 768) hipLaunchKernelGGL((ln_rows_kernel<T, 3>), dim3(grid), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((ln_rows_kernel<T, 4>), dim3(grid), dim3(256), 0, s, a);
+}
+
 int launch_layernorm(DType dt, const LnArgs& a, hipStream_t s, const char** err) {
     if (a.M <= 0) return 0;
     if (a.C > 1024 || a.C % 4) { *err = "layernorm: C must be <= 1024 and a multiple of 4"; return 1; }
-    const int grid = (a.M + 3) / 4;
-    if (dt == DT_BF16) hipLaunchKernelGGL(ln_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL(ln_kernel<f16_t>, dim3(grid), dim3(256), 0, s, a);
+    if (dt == DT_BF16) launch_ln_t<bf16_t>(a, s);
+    else launch_ln_t<f16_t>(a, s);
     if (hipGetLastError() != hipSuccess) { *err = "layernorm: launch failed"; return 1; }
     return 0;
 }
