@@ -9,6 +9,7 @@
 set -u
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 export TMPDIR=/tmp PYTHONDONTWRITEBYTECODE=1
+export M3R_COMMIT=${M3R_COMMIT:-$(cat .commit 2>/dev/null || echo "?")}
 O=gpurun_out
 S_STEP=${M3R_STEP_SCENES:-20}
 S_PMC=${M3R_PMC_SCENES:-8}
@@ -39,7 +40,10 @@ for f in files:
             agg[name][row["Counter_Name"]] += float(row["Counter_Value"])
             cnt[name][row["Counter_Name"]] += 1
 out = {k: {"launches": max(cnt[k].values()), **{c: v / max(1, cnt[k][c]) for c, v in d.items()}} for k, d in agg.items() if "m3r" in k}
-json.dump({"tag": tag, "counters": ctrs, "scenes": scenes, "per_launch_means": out}, open(f"gpurun_out/r04_pmc_{tag}.json", "w"), indent=1)
+import os
+if out or not os.path.exists(f"gpurun_out/r04_pmc_{tag}.json"):   # a failed pass (rocprofv3 crash) does not overwrite an earlier good one
+    json.dump({"tag": tag, "counters": ctrs, "scenes": scenes, "commit": os.environ.get("M3R_COMMIT", "?"), "per_launch_means": out},
+              open(f"gpurun_out/r04_pmc_{tag}.json", "w"), indent=1)
 print(tag, "kernels:", len(out))
 sys.exit(0 if out else 3)
 PY
@@ -50,7 +54,8 @@ PY
 # fabric traffic: the derived FETCH_SIZE / WRITE_SIZE passes crash rocprofv3 on this image (segfault ~9 s in; r03: hangs) -> on failure the raw
 # L2 -> fabric request counters they are derived from (MI355X_MICROARCH.md "HBM": FETCH_SIZE = TCC_EA0_RDREQ x 64 B)
 rocprofv3 -L 2>/dev/null | grep -o "TCC_EA0_[A-Z0-9_]*\(_sum\)\?" | sort -u | head -40 > $O/r04_tcc_ea0_counters.txt
-pmc_pass fetch TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum || { echo "fetch pass failed at S=$S_PMC -> 8 scenes for all passes"; S_PMC=8; pmc_pass fetch TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum; }
+# (rocprofv3 on this image crashes in about one pass out of three with the TCC_EA0 read counters: one retry, at 8 scenes)
+pmc_pass fetch TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum || { echo "fetch pass failed at S=$S_PMC -> retry at 8 scenes"; S_PMC=8; pmc_pass fetch TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum; }
 pmc_pass write TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum
 pmc_pass dram TCC_EA0_RDREQ_DRAM_sum TCC_EA0_RDREQ_sum
 pmc_pass tcc TCC_HIT_sum TCC_MISS_sum

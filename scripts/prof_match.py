@@ -122,7 +122,7 @@ def main():
                 r["frac_from_rocprof"] = round(gf / n / us * 1e3 / 2500.0, 4)
                 r["frac_from_rocprof_note"] = "symbol shared by " + " + ".join(x["kernel"] for x in rs) + ": fraction of the symbol as a whole"
     commit = os.environ.get("M3R_COMMIT", "?")
-    doc = {"commit": commit, "command_trace": "rocprofv3 --kernel-trace --stats -- python bench.py --gpus 1 --steps 3 --warmup 1 --scenes S --step-only",
+    doc = {"commit": commit, "pmc_pass_commits": {t: (d or {}).get("commit") for t, d in pmc.items()}, "command_trace": "rocprofv3 --kernel-trace --stats -- python bench.py --gpus 1 --steps 3 --warmup 1 --scenes S --step-only",
            "command_pmc": "rocprofv3 --kernel-trace --pmc <set> -- python bench.py --gpus 1 --steps 1 --warmup 1 --scenes S_pmc --step-only (one pass per set)",
            "line": {k: line.get(k) for k in ("value", "ms_per_step", "config", "roofline", "roofline_attention", "kernel_classes", "end_to_end_mfma_frac")},
            "rows": rows,
