@@ -1,4 +1,4 @@
-"""Microbenchmark of the update-pass (M = 768) GEMMs; env M3R_GEMM_MIN_BIG(_SPLIT) moves the tile-class threshold."""
+"""Microbenchmark of the update-pass (M = 768) GEMMs (r02; scripts/bench_gemm_m768.py is the r04 form with per-layout shapes and digests)."""
 import os, sys, math, torch, ctypes as C
 sys.path.insert(0, '/root/repo')
 from must3r_amd import _lib as lib
@@ -35,24 +35,4 @@ for name, M, N, K, epi in shapes:
     us = e0.elapsed_time(e1) / 50 * 1e3
     tot += us
     print(f"  {name:9s} M={M:5d} N={N:5d} K={K:5d} {us:7.1f} us {2.0*M*N*K/us/1e6:7.1f} TF/s")
-if split:   # fc2 as a split-K launch + the LayerNorm that reduces its slabs, against the residual GEMM + plain LayerNorm
-    M, N, K, KS = 768, 768, 3072, 4
-    A = torch.randn((M, K), device="cuda").half()
-    W = (torch.randn((N, 2 * K), device="cuda") / math.sqrt(K)).half()
-    b = torch.randn((N,), device="cuda"); x = torch.zeros((M, N), device="cuda"); h = torch.empty((M, N), device="cuda", dtype=torch.float16)
-    lw = torch.ones((N,), device="cuda"); lb = torch.zeros((N,), device="cuda"); slabs = torch.empty((KS, M, N), device="cuda")
-    def split_route():
-        lib.check(L.must3r_hip_op_gemm_splitk(1, P(A), P(W), P(slabs), M, N, K, K, N, KS, M * N, st))
-        lib.check(L.must3r_hip_op_layernorm_slabs(1, P(x), P(slabs), KS, M * N, P(b), P(lw), P(lb), P(h), None, M, N, 1e-6, st))
-    def plain_route():
-        lib.check(L.must3r_hip_op_gemm(1, lib.EPI_RESID_F32, P(A), P(W), P(b), P(x), M, N, K, K, N, None, None, 0, 0, None, 0, 0, 0, 0, 0, 0, 2, st))
-        lib.check(L.must3r_hip_op_layernorm(1, P(x), None, P(lw), P(lb), P(h), None, None, None, M, N, 1e-6, st))
-    for nm, fn in (("fc2+LN plain", plain_route), ("fc2+LN splitK4", split_route), ("fc2+LN plain", plain_route), ("fc2+LN splitK4", split_route)):
-        for _ in range(5): fn()
-        torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(50): fn()
-        e1.record(); torch.cuda.synchronize()
-        print(f"  {nm:16s} {e0.elapsed_time(e1) / 50 * 1e3:7.1f} us")
 print(f"SPLIT={split} MIN_BIG={os.environ.get('M3R_GEMM_MIN_BIG','-')} MIN_BIG_SPLIT={os.environ.get('M3R_GEMM_MIN_BIG_SPLIT','-')}: total {tot:.1f} us")
