@@ -105,3 +105,15 @@ def test_sharded_scene_equals_single_process(tmp_path):
     assert kf == v0["kf"] and torch.equal(memv[1], v0["labels"])
     assert torch.allclose(pm0, v0["pm0"], atol=1e-6) and torch.allclose(renv[0], v0["render_all"], atol=1e-6)
     assert torch.allclose(memv[0][-1], v0["mem_last"], atol=1e-6)
+
+
+def test_positions_rebuilt_from_the_grid_equal_the_encoders():
+    """r04: positions never travel between ranks -- `grid_positions` must be exactly what the encoder returns for a view (croco
+    PositionGetter, SURVEY.md Appendix A: row-major (y, x))."""
+    from oracle import must3r_ref as R
+    from must3r_amd.parallel import grid_positions
+    sde = S.make_encoder_state_dict(TINY, 0)
+    for h, w in ((48, 64), (64, 64), (32, 96)):
+        imgs, ts = S.make_images(1, h, w, 0)
+        _, pos = R.encoder_forward(sde, TINY, imgs, ts)
+        assert torch.equal(grid_positions(h // 16, w // 16, torch.device("cpu")), pos[0])
