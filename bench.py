@@ -345,6 +345,20 @@ def main():
                "unit": "GB/s", "frac": round(nbytes / ms / 1e6 / 8000.0, 4), "algorithmic_bytes": nbytes}
         del pmaps
 
+    # the step at another number of scenes in flight: 28 fills the rounds of every decoder GEMM of the update to 98 % (84 row blocks x 9 / 12 / 3 / 6
+    # column tiles over 256 CUs; at 20: 70-94 %) -- reported beside `value`, never in it (DESIGN.md section 3.4 "round quantisation")
+    sweep = None
+    if not args.no_alt and world == 1 and Sn == 20:
+        S2 = 28
+        more = torch.stack([S.make_images(V, H, W, seed=2000 + b)[0] for b in range(S2 - Sn)]).to(device)
+        scenes2 = torch.cat([scenes, more], dim=0)
+        fn2 = lambda: run_scenes(enc, dec, scenes2, ts)  # noqa: E731
+        fn2()
+        k2 = max(2, args.steps // 2)
+        d2 = timed(fn2, k2)
+        sweep = [{"scenes_in_flight": S2, "value": round(S2 * V * k2 / d2, 2), "ms_per_step": round(d2 / k2 * 1e3, 3)}]
+        del more, scenes2
+
     alt = None
     if not args.no_alt and world == 1:
         alt = []
@@ -574,7 +588,7 @@ def main():
                        "parallelism": "single GPU" if world == 1 else f"{world} replicas (independent scenes per rank, no data-path collective; "
                                                                        f"barrier + max over ranks) [{backend}]"},
             "roofline": roofline, "roofline_attention": roofline_attention, "roofline_gemm": roofline_gemm, "cpu_baseline": cpu_baseline, "parity_vs_cpu_oracle": parity,
-            "kernel_classes": classes, "stages_ms": stages, "single_scene": single, "alt": alt, "configs": configs, "postprocess_cam": cam,
+            "kernel_classes": classes, "stages_ms": stages, "single_scene": single, "alt": alt, "scenes_in_flight_sweep": sweep, "configs": configs, "postprocess_cam": cam,
             "multi_gpu": ("this line is a 1-GPU run; no RCCL run of the N > 1 paths has happened in the build environment (one GPU per box): the "
                           "view-sharded path is covered by world-size-2 gloo tests and a 2-rank gloo dry run of this script" if world == 1 else
                           f"{world} ranks, backend {backend}"),
