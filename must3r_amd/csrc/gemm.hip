@@ -1652,6 +1652,9 @@ static int g256k_mode() {
 // (r04, measured and removed: two 256 x 128 blocks per CU -- the GELU launches' OCC = 2 form -- for the other split-weight epilogues, so that one
 // block's fp32 read-modify-write epilogue runs under the other's K loop: RESID proj 44.7 -> 52.1 us (dec) / 67.2 -> 68.2 us (enc), fc2 122 -> 152 us,
 // STORE16 K|V 71.9 -> 77.8 us, RoPE qkv +-1 %; nine split shapes 1246 -> 1308 us, step 497.6 -> 487.9 views/s.  profiles/r04_occ2_ab.txt.)
+// (r04, measured and removed: the same two-blocks-per-CU form for the PLAIN-weight GELU launches instead of gemm256k -- enc fc1 146.8 -> 172.8 us, dec fc1 92.6 ->
+// 105.4 us, step 495.9 -> 486.3 views/s: the 64-byte DMA rows and 256 x 128 tiles cost more than the hidden erf epilogue (~8 us of a 39 us tile) gives back.
+// profiles/r04_plain_gelu_occ2.txt.)
 template <class T, int EPI>
 static int launch_epi(const GemmArgs& a, hipStream_t s, const char** err) {
     const long nb = a.batch > 1 ? a.batch : 1;
