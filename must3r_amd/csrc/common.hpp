@@ -181,47 +181,46 @@ template <int BK> __device__ __forceinline__ int swzk(int row, int chunk) {
 // of the 256-byte bank row (rows r, r+1 already sit in different halves); swz() would alias rows r and r+2.
 __device__ __forceinline__ int swz_v(int row, int chunk) { return chunk ^ (((row >> 1) & 3) << 1); }
 
-// exact-erf GELU (nn.GELU default).  erf by Abramowitz-Stegun 7.1.26: |error| <= 1.5e-7 absolute, i.e. three orders
-// below the 16-bit rounding of the result, branch-free (1 rcp + 1 exp2 + 7 fma) instead of libm's two-branch erff.
+// exact-erf GELU (nn.GELU default), r04 form:  GELU(x) = max(x, 0) - (|x| / 2) erfc(|x| / sqrt 2)  with  erfc(z) ~ 2^(-z P(z)),
+// P a quartic fitted to -log2(erfc(z)) / z on [0, 4.3] (scripts/emul: least-squares start, reweighted to the minimax of the ABSOLUTE erfc error):
+// |erfc error| <= 5.9e-7, |GELU error| <= 1.3e-6 absolute in fp32 arithmetic (relative 6e-5 where |GELU| > 1e-2) -- an eighth of the 16-bit rounding
+// of the result.  P is positive and z P(z) increasing for every z >= 0 (leading coefficient > 0), so large |x| need no clamp: 2^(-z P) underflows to 0
+// and the result is max(x, 0) exactly; the negative tail is a product, not a cancellation (0.5 x (1 + erf) loses the tail to 1 - 1).
+// ONE transcendental (exp2) + 4 FMAs per value instead of two (rcp, exp2) + 7 of the Abramowitz-Stegun 7.1.26 form used through r03 (1.5e-7): the erf
+// epilogue was ~8 us of a 39 us fc1 tile, VALU-bound with the quarter-rate transcendentals at 44 % of it.
+constexpr float kErfcP0 = 1.6278890371322632f, kErfcP1 = 0.9185093641281128f, kErfcP2 = 0.1486656814813614f, kErfcP3 = -0.02959008701145649f,
+                kErfcP4 = 0.002944170031696558f;
 __device__ __forceinline__ float gelu_erf(float x) {
-    const float z = fabsf(x) * 0.70710678118654752440f;
-    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
-    float p = fmaf(1.061405429f, t, -1.453152027f);
-    p = fmaf(p, t, 1.421413741f);
-    p = fmaf(p, t, -0.284496736f);
-    p = fmaf(p, t, 0.254829592f);
-    const float e = __builtin_amdgcn_exp2f(-z * z * 1.44269504088896340736f);
-    const float erf_abs = fmaf(-p * t, e, 1.0f);               // erf(|x|/sqrt2)
-    const float erf_v = __builtin_copysignf(erf_abs, x);
-    return 0.5f * x * (1.0f + erf_v);
+    const float ax = fabsf(x);
+    const float z = ax * 0.70710678118654752440f;
+    float p = fmaf(kErfcP4, z, kErfcP3);
+    p = fmaf(p, z, kErfcP2);
+    p = fmaf(p, z, kErfcP1);
+    p = fmaf(p, z, kErfcP0);
+    const float e = __builtin_amdgcn_exp2f(-(z * p));             // erfc(|x| / sqrt 2)
+    return fmaf(-(0.5f * ax), e, fmaxf(x, 0.0f));
 }
 
 // The same arithmetic on two values at once: clang maps the ext_vector float2 operations to the packed fp32 VALU instructions of gfx950
-// (v_pk_mul_f32 / v_pk_fma_f32 / v_pk_add_f32 -- IEEE per component, i.e. the bits of the scalar form) -- 10 instead of 18 VALU instructions
-// per output.  (Packed fp32 beside MFMAs is an anti-lever; in a GEMM epilogue no MFMA runs on the CU.)
+// (v_pk_mul_f32 / v_pk_fma_f32 -- IEEE per component, i.e. the bits of the scalar form).  (Packed fp32 beside MFMAs is an anti-lever; in a GEMM
+// epilogue no MFMA runs on the CU.)
 typedef __attribute__((ext_vector_type(2))) float f32x2;
 __device__ __forceinline__ f32x2 gelu_erf2(const f32x2 x) {
-    f32x2 ax;
+    f32x2 ax, r;
     ax[0] = fabsf(x[0]);
     ax[1] = fabsf(x[1]);
+    r[0] = fmaxf(x[0], 0.0f);
+    r[1] = fmaxf(x[1], 0.0f);
     const f32x2 z = ax * 0.70710678118654752440f;
-    const f32x2 d = __builtin_elementwise_fma(f32x2{0.3275911f, 0.3275911f}, z, f32x2{1.0f, 1.0f});
-    f32x2 t;
-    t[0] = __builtin_amdgcn_rcpf(d[0]);
-    t[1] = __builtin_amdgcn_rcpf(d[1]);
-    f32x2 p = __builtin_elementwise_fma(f32x2{1.061405429f, 1.061405429f}, t, f32x2{-1.453152027f, -1.453152027f});
-    p = __builtin_elementwise_fma(p, t, f32x2{1.421413741f, 1.421413741f});
-    p = __builtin_elementwise_fma(p, t, f32x2{-0.284496736f, -0.284496736f});
-    p = __builtin_elementwise_fma(p, t, f32x2{0.254829592f, 0.254829592f});
-    const f32x2 a = -z * z * 1.44269504088896340736f;
+    f32x2 p = __builtin_elementwise_fma(f32x2{kErfcP4, kErfcP4}, z, f32x2{kErfcP3, kErfcP3});
+    p = __builtin_elementwise_fma(p, z, f32x2{kErfcP2, kErfcP2});
+    p = __builtin_elementwise_fma(p, z, f32x2{kErfcP1, kErfcP1});
+    p = __builtin_elementwise_fma(p, z, f32x2{kErfcP0, kErfcP0});
+    const f32x2 a = -(z * p);
     f32x2 e;
     e[0] = __builtin_amdgcn_exp2f(a[0]);
     e[1] = __builtin_amdgcn_exp2f(a[1]);
-    const f32x2 erf_abs = __builtin_elementwise_fma(-p * t, e, f32x2{1.0f, 1.0f});
-    f32x2 erf_v;
-    erf_v[0] = __builtin_copysignf(erf_abs[0], x[0]);
-    erf_v[1] = __builtin_copysignf(erf_abs[1], x[1]);
-    return 0.5f * x * (1.0f + erf_v);
+    return __builtin_elementwise_fma(-(0.5f * ax), e, r);
 }
 __device__ __forceinline__ f32x4 gelu_erf4(const f32x4 v) {
     const f32x2 lo = gelu_erf2(f32x2{v[0], v[1]}), hi = gelu_erf2(f32x2{v[2], v[3]});
