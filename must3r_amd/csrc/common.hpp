@@ -186,41 +186,41 @@ __device__ __forceinline__ int swz_v(int row, int chunk) { return chunk ^ (((row
 // |erfc error| <= 5.9e-7, |GELU error| <= 1.3e-6 absolute in fp32 arithmetic (relative 6e-5 where |GELU| > 1e-2) -- an eighth of the 16-bit rounding
 // of the result.  P is positive and z P(z) increasing for every z >= 0 (leading coefficient > 0), so large |x| need no clamp: 2^(-z P) underflows to 0
 // and the result is max(x, 0) exactly; the negative tail is a product, not a cancellation (0.5 x (1 + erf) loses the tail to 1 - 1).
-// ONE transcendental (exp2) + 4 FMAs per value instead of two (rcp, exp2) + 7 of the Abramowitz-Stegun 7.1.26 form used through r03 (1.5e-7): the erf
+// ONE transcendental (exp2) + 6 FMAs per value instead of two (rcp, exp2) + 7 FMAs + 6 other of the Abramowitz-Stegun 7.1.26 form used through r03 (1.5e-7): the erf
 // epilogue was ~8 us of a 39 us fc1 tile, VALU-bound with the quarter-rate transcendentals at 44 % of it.
-constexpr float kErfcP0 = 1.6278890371322632f, kErfcP1 = 0.9185093641281128f, kErfcP2 = 0.1486656814813614f, kErfcP3 = -0.02959008701145649f,
-                kErfcP4 = 0.002944170031696558f;
+// Coefficients in a = |x| directly (Q_k = P_k / sqrt(2)^(k+1)), and the factor 1/2 folded into the exponent:
+//   GELU(x) = max(x, 0) - a 2^(-a Q(a) - 1)                                   4 + 1 + 1 FMAs, one exp2
+constexpr float kErfcQ0 = 1.1510913372039795f, kErfcQ1 = 0.4592546820640564f, kErfcQ2 = 0.052561257034540176f, kErfcQ3 = -0.007397521752864122f,
+                kErfcQ4 = 0.0005204606568440795f;
 __device__ __forceinline__ float gelu_erf(float x) {
-    const float ax = fabsf(x);
-    const float z = ax * 0.70710678118654752440f;
-    float p = fmaf(kErfcP4, z, kErfcP3);
-    p = fmaf(p, z, kErfcP2);
-    p = fmaf(p, z, kErfcP1);
-    p = fmaf(p, z, kErfcP0);
-    const float e = __builtin_amdgcn_exp2f(-(z * p));             // erfc(|x| / sqrt 2)
-    return fmaf(-(0.5f * ax), e, fmaxf(x, 0.0f));
+    const float a = fabsf(x);
+    float q = fmaf(kErfcQ4, a, kErfcQ3);
+    q = fmaf(q, a, kErfcQ2);
+    q = fmaf(q, a, kErfcQ1);
+    q = fmaf(q, a, kErfcQ0);
+    const float e = __builtin_amdgcn_exp2f(fmaf(-a, q, -1.0f));   // erfc(|x| / sqrt 2) / 2
+    return fmaf(-a, e, fmaxf(x, 0.0f));
 }
 
 // The same arithmetic on two values at once: clang maps the ext_vector float2 operations to the packed fp32 VALU instructions of gfx950
-// (v_pk_mul_f32 / v_pk_fma_f32 -- IEEE per component, i.e. the bits of the scalar form).  (Packed fp32 beside MFMAs is an anti-lever; in a GEMM
-// epilogue no MFMA runs on the CU.)
+// (v_pk_fma_f32 -- IEEE per component, i.e. the bits of the scalar form).  (Packed fp32 beside MFMAs is an anti-lever; in a GEMM epilogue no MFMA
+// runs on the CU.)
 typedef __attribute__((ext_vector_type(2))) float f32x2;
 __device__ __forceinline__ f32x2 gelu_erf2(const f32x2 x) {
-    f32x2 ax, r;
-    ax[0] = fabsf(x[0]);
-    ax[1] = fabsf(x[1]);
+    f32x2 a, r;
+    a[0] = fabsf(x[0]);
+    a[1] = fabsf(x[1]);
     r[0] = fmaxf(x[0], 0.0f);
     r[1] = fmaxf(x[1], 0.0f);
-    const f32x2 z = ax * 0.70710678118654752440f;
-    f32x2 p = __builtin_elementwise_fma(f32x2{kErfcP4, kErfcP4}, z, f32x2{kErfcP3, kErfcP3});
-    p = __builtin_elementwise_fma(p, z, f32x2{kErfcP2, kErfcP2});
-    p = __builtin_elementwise_fma(p, z, f32x2{kErfcP1, kErfcP1});
-    p = __builtin_elementwise_fma(p, z, f32x2{kErfcP0, kErfcP0});
-    const f32x2 a = -(z * p);
+    f32x2 q = __builtin_elementwise_fma(f32x2{kErfcQ4, kErfcQ4}, a, f32x2{kErfcQ3, kErfcQ3});
+    q = __builtin_elementwise_fma(q, a, f32x2{kErfcQ2, kErfcQ2});
+    q = __builtin_elementwise_fma(q, a, f32x2{kErfcQ1, kErfcQ1});
+    q = __builtin_elementwise_fma(q, a, f32x2{kErfcQ0, kErfcQ0});
+    const f32x2 t = __builtin_elementwise_fma(-a, q, f32x2{-1.0f, -1.0f});
     f32x2 e;
-    e[0] = __builtin_amdgcn_exp2f(a[0]);
-    e[1] = __builtin_amdgcn_exp2f(a[1]);
-    return __builtin_elementwise_fma(-(0.5f * ax), e, r);
+    e[0] = __builtin_amdgcn_exp2f(t[0]);
+    e[1] = __builtin_amdgcn_exp2f(t[1]);
+    return __builtin_elementwise_fma(-a, e, r);
 }
 __device__ __forceinline__ f32x4 gelu_erf4(const f32x4 v) {
     const f32x2 lo = gelu_erf2(f32x2{v[0], v[1]}), hi = gelu_erf2(f32x2{v[2], v[3]});
