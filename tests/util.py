@@ -34,7 +34,7 @@ TOL = {"fp16w2": 1.0e-3, "fp16wa": 1.0e-3, "fp16": 2.0e-3, "bf16": 1.15e-2}
 PRECISIONS = ("fp16w2", "fp16wa", "fp16", "bf16")
 # the module default (what bench.py times) against the real-reference fixture of the benched scene, worst single view: tightened with the
 # default's measured margin (tests/test_zz_r04_gpu.py::test_benched_configuration_scenes_in_flight_vs_reference_fixture).  r04, fp16wa, 8 scenes in
-# flight: worst update view 9.47e-4, worst render view 8.96e-4 (one scene at a time: 9.3e-4) -- deterministic (no atomics on the path), so the thin
+# flight: worst update view 9.45e-4, worst render view 9.29e-4 (one scene at a time: 8.6e-4) -- deterministic (no atomics on the path), so the thin
 # margin does not flake; DESIGN.md section 4 says what it would cost to widen it.
 TOL_DEFAULT_FIXTURE = 1.0e-3
 
