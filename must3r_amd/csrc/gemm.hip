@@ -1157,6 +1157,297 @@ static int launch_256k(const GemmArgs& a, hipStream_t s) {
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// gemm256p_kernel (r05): 256 x BN tile, 8 waves, K-tiles of 64 (128-byte operand rows like gemm256k), the two wave groups ALTERNATING between a
+// load interval and a multiply interval (like gemm256_kernel), and the tile staged in HALF-TILES of 16 KB that are restaged one phase after their
+// last read -- the "8-phase" structure of cdna_hip_programming.md section 5, which that guide measures at 1320-1470 TF/s on random operands where the
+// symmetric loop of gemm256k_kernel reaches ~1050 (K loop only, profiles/r03_gemm256k_fixed2.txt).
+//   Why the symmetric loop stalls: its eight waves run the same instruction stream in near lock step behind one barrier per chunk, so both waves of a
+//   SIMD reach their LDS-DMA instruction together, both sit in the CU's vector-memory front end (8 pieces x ~17 cycles), and the matrix pipe idles
+//   until the first of them gets back to its MFMAs (MFMA busy 0.46-0.48, profiles/r04_pmc_sq.json).  Here a wave issues NO memory instruction between
+//   the first and the last MFMA of a multiply interval, and while it multiplies its SIMD partner (the other group) does all of its reads and DMA.
+// Geometry.  Waves (wr, wc) = (wave >> 2, wave & 3): wave tile 128 rows x BN/4 columns.  Per K-tile four half-tiles of 128 LDS rows x 128 B:
+//   A_h (h = 0, 1): rows {wr' * 128 + h * 64 + r} of the tile at LDS row wr' * 64 + r  -- every wave's row sub-tile h (4 row fragments)
+//   B_g (g = 0, 1): plain weights: weight rows {wc' * 64 + g * 32 + r} at LDS row wc' * 32 + r -- every wave's column sub-tile g (2 fragments);
+//                   split weights (BN = 128): part g (hi / lo) of weight rows {wc' * 32 + r}.
+//   Two buffers of 4 x 16 KB.  A phase = [load interval | barrier | multiply interval | barrier]; group 1 runs one barrier behind group 0.
+//   NPH = 4 (plain): phases (a0,b0) (a0,b1) (a1,b1) (a1,b0), 16 MFMAs each; reads 12 / 4 / 8 / 0 ds_read_b128; ONE half-tile (2 DMA pieces per wave) per phase.
+//   NPH = 2        : phases a0 x (b0,b1), a1 x (b0,b1), 32 MFMAs each (split: hi then lo inside each 32-deep step); reads 16 / 8; two half-tiles per phase.
+// Ordering (cdna_hip_programming.md "Read a staged buffer one phase AFTER the wait that retires it"):
+//   RAW  a wave's counted vmcnt for a half-tile sits in the load interval of phase w (group 0: before global barrier #2w, group 1: before #2w+1);
+//        the first read of that half-tile is in phase w+1 (group 0: after #2w+1, group 1: after #2w+2).
+//   WAR  every wave retires its ds_reads (lgkmcnt 0) BEFORE the barrier that ends its load interval, so a half-tile last read in phase r is
+//        restaged in phase r+1 at the earliest: group 0 issues after #2r+1 (group 1's reads retired before #2r+1), group 1 after #2r+2.
+// Same accumulation order per output as every other tile shape (k ascending, hi before lo in each 32-deep step): identical bits.
+// SYNC = 2: two barriers per phase, the groups' multiply intervals exclusive (above).  SYNC = 1 (NPH = 2 only): ONE barrier per phase.  Between two
+// barriers group 0 runs [load block of phase p | its 32 MFMAs of phase p] and group 1 [its 32 MFMAs of phase p-1 | load block of phase p]: the two waves of
+// a SIMD are in anti-phase by construction, but nothing stops the wave that finishes its loads early from multiplying beside its partner (two waves
+// alternating MFMAs issue one every 16 cycles where a single wave needs ~17.8, profiles/r02_gemm256_trace.txt), and the hand-over hole of the exclusive
+// form (~80 cycles per barrier with the matrix pipe drained, same trace) is paid once per phase instead of twice.
+//   RAW  the counted wait for phase q's half-tiles sits in every wave's load block of interval q-1 (before barrier #q); both groups read them in interval q.
+//   WAR  group 1 retires its reads of phase r at the end of interval r (lgkmcnt 0 before barrier #r+1); the restage goes out in interval r+1.
+template <class T, int EPI, int WS, int BN, int NPH, int SYNC = 2>
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) gemm256p_kernel(const GemmArgs p) {
+    typedef typename Vec<T>::v8 v8;
+    constexpr int BM = 256, BK = 64;
+    static_assert(WS * BN == 256, "the staged weight region is 256 rows: 256 plain columns or 128 columns hi + lo");
+    static_assert(NPH == 2 || (NPH == 4 && WS == 1), "the four-phase form multiplies (a, b0) and (a, b1) in different phases: plain weights only");
+    static_assert(SYNC == 2 || NPH == 2, "the one-barrier form is built on the two-phase schedule");
+    constexpr int WN = BN / 4, MF = 8, NF = WN / 16;       // plain: NF = 4 (two column sub-tiles of 2); split: NF = 2 (hi and lo fragments of the same 2)
+    constexpr unsigned HALFB = 128 * BK * 2;               // bytes per half-tile (16 KB)
+    constexpr unsigned BUFB = 4 * HALFB;                   // A0 A1 B0 B1
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+
+    const int nbn = p.N / BN;
+    const int nbm = (p.M + BM - 1) / BM;
+    const int nwg = nbm * nbn;
+    int bid = blockIdx.x;
+    {
+        const int xcd = bid & 7, slot = bid >> 3;
+        const int q = nwg >> 3, r = nwg & 7;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+    }
+    constexpr int GM = 4;
+    const int tpg = GM * nbn;
+    const int gidx = bid / tpg;
+    const int gfirst = gidx * GM;
+    const int gsz = (nbm - gfirst < GM) ? nbm - gfirst : GM;
+    const int gin = bid - gidx * tpg;
+    const int m0 = (gfirst + gin % gsz) * BM;
+    const int n0 = (gin / gsz) * BN;
+
+    const int grp = blockIdx.y;
+    const T* __restrict__ A = reinterpret_cast<const T*>(p.A) + (size_t)grp * p.strideA;
+    const int wgrp = p.wdiv > 1 ? grp / p.wdiv : grp;
+    const T* __restrict__ W = reinterpret_cast<const T*>(p.W) + (size_t)wgrp * p.strideW;
+    const float* __restrict__ bias = p.bias ? p.bias + (size_t)wgrp * p.strideB : nullptr;
+    void* const outp = p.out_table ? p.out_table[grp] : p.out;
+
+    // ---- staging: a wave moves pieces 2 wave, 2 wave + 1 (8 rows x 128 B each) of every half-tile
+    const int srow = lane >> 3, pch = lane & 7;
+    const T* a_src[2][2];   // [half][piece]
+    const T* w_src[2][2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int hr = (wave * 2 + j) * 8 + srow;                    // LDS row inside the half-tile, 0..127
+            int gr = m0 + (hr >> 6) * 128 + h * 64 + (hr & 63);
+            gr = gr < p.M ? gr : p.M - 1;
+            a_src[h][j] = A + (size_t)gr * p.lda + swz(hr, pch) * 8;
+            if constexpr (WS == 1) {
+                const int col = (hr >> 5) * 64 + h * 32 + (hr & 31);
+                w_src[h][j] = W + (size_t)(n0 + col) * (size_t)p.K + swz(hr, pch) * 8;
+            } else {
+                w_src[h][j] = W + (size_t)(n0 + hr) * (size_t)(p.K * 2) + (size_t)h * p.K + swz(hr, pch) * 8;
+            }
+        }
+    // which: 0 A0, 1 A1, 2 B0, 3 B1 (the half-tile's place in a buffer); kt: K-tile
+    auto stage = [&](auto whichc, int kt) {
+        constexpr int which = decltype(whichc)::value;
+        char* const base = smem + (kt & 1) * BUFB + which * HALFB + wave * 2048;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const T* s = which < 2 ? a_src[which & 1][j] : w_src[which & 1][j];
+            glds16(s + (size_t)kt * BK, base + j * 1024);
+        }
+    };
+    typedef std::integral_constant<int, 0> HA0;
+    typedef std::integral_constant<int, 1> HA1;
+    typedef std::integral_constant<int, 2> HB0;
+    typedef std::integral_constant<int, 3> HB1;
+
+    f32x4 acc[MF][NF];
+#pragma unroll
+    for (int i = 0; i < MF; ++i)
+#pragma unroll
+        for (int j = 0; j < NF; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int fr = lane & 15, fg = lane >> 4;
+    const int nk = p.K / BK;
+    // byte offsets of this lane's fragments inside a buffer: + i * 2048 per row fragment, + HALFB per sub-tile
+    unsigned a_lane[2], w_lane[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        const int ra = wr * 64 + fr, rw = wc * 32 + fr;
+        a_lane[ks] = (unsigned)(ra * 128 + swz(ra, ks * 4 + fg) * 16);
+        w_lane[ks] = 2 * HALFB + (unsigned)(rw * 128 + swz(rw, ks * 4 + fg) * 16);
+    }
+    f32x4 bpre[NF];   // bias columns, in front of the first DMA (gemm256k_kernel)
+    epilogue_bias<EPI, NF>(p, bias, n0 + wc * WN, fg, bpre);
+
+    v8 af[2][4], bf[2][2][2];   // [ks][row fragment of the sub-tile]; [sub-tile g][ks][fragment]
+    auto read_a = [&](int h, unsigned bufb) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) af[ks][i] = *reinterpret_cast<const v8*>(smem + bufb + h * HALFB + a_lane[ks] + i * 2048);
+    };
+    auto read_b = [&](auto gc, unsigned bufb) {
+        constexpr int g = decltype(gc)::value;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) bf[g][ks][j] = *reinterpret_cast<const v8*>(smem + bufb + g * HALFB + w_lane[ks] + j * 2048);
+    };
+    // multiply interval: sub-tile h of the rows against column sub-tile g (plain, 16 MFMAs) ...
+    auto mma_q = [&](auto hc, auto gc) {
+        constexpr int h = decltype(hc)::value, g = decltype(gc)::value;
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[h * 4 + i][g * 2 + j] = mfma16(bf[g][ks][j], af[ks][i], acc[h * 4 + i][g * 2 + j]);
+        __builtin_amdgcn_s_setprio(0);
+    };
+    // ... or against everything staged of W (32 MFMAs): plain -- both column sub-tiles; split -- hi then lo of the same two fragments in each 32-deep step
+    auto mma_h = [&](auto hc) {
+        constexpr int h = decltype(hc)::value;
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int g = 0; g < 2; ++g)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        if constexpr (WS == 1) acc[h * 4 + i][g * 2 + j] = mfma16(bf[g][ks][j], af[ks][i], acc[h * 4 + i][g * 2 + j]);
+                        else acc[h * 4 + i][j] = mfma16(bf[g][ks][j], af[ks][i], acc[h * 4 + i][j]);
+                    }
+        __builtin_amdgcn_s_setprio(0);
+    };
+    typedef std::integral_constant<int, 0> I0;
+    typedef std::integral_constant<int, 1> I1;
+#define M3R_VMCNT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
+    // end of a load interval: own reads retired (WAR, and the fragments are there for the MFMAs), then the hand-over barrier
+#define M3R_P_LOAD_END() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define M3R_P_MUL_END() do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); } while (0)
+
+    // ---- prologue: what the steady state would have issued before K-tile 0
+    if constexpr (NPH == 4) {
+        stage(HA0{}, 0); stage(HB0{}, 0); stage(HB1{}, 0); stage(HA1{}, 0);
+        if (nk > 1) { stage(HA0{}, 1); stage(HB0{}, 1); stage(HB1{}, 1); M3R_VMCNT(8); }
+        else M3R_VMCNT(2);
+    } else {
+        stage(HA0{}, 0); stage(HB0{}, 0); stage(HB1{}, 0); stage(HA1{}, 0);
+        if (nk > 1) { stage(HA0{}, 1); stage(HB0{}, 1); M3R_VMCNT(6); }
+        else M3R_VMCNT(2);
+    }
+    __builtin_amdgcn_s_barrier();
+    if constexpr (SYNC == 2) {
+    if (wr == 1) __builtin_amdgcn_s_barrier();   // group 1 runs one barrier behind
+
+    // one K-tile; REM = min(2, K-tiles behind this one): which half-tiles are still to be staged, and the counted waits that go with them
+    auto ktile = [&](auto remc, int t) {
+        constexpr int REM = decltype(remc)::value;
+        const unsigned bufb = (t & 1) * BUFB;
+        if constexpr (NPH == 4) {
+            // phase 0: (a0, b0)
+            read_a(0, bufb); read_b(I0{}, bufb);
+            if constexpr (REM >= 1) stage(HA1{}, t + 1);
+            M3R_P_LOAD_END(); mma_q(I0{}, I0{}); M3R_P_MUL_END();
+            // phase 1: (a0, b1); A1 of this K-tile landed
+            read_b(I1{}, bufb);
+            if constexpr (REM >= 2) stage(HA0{}, t + 2);
+            M3R_VMCNT(REM == 2 ? 10 : (REM == 1 ? 8 : 0));
+            M3R_P_LOAD_END(); mma_q(I0{}, I1{}); M3R_P_MUL_END();
+            // phase 2: (a1, b1)
+            read_a(1, bufb);
+            if constexpr (REM >= 2) stage(HB0{}, t + 2);
+            M3R_P_LOAD_END(); mma_q(I1{}, I1{}); M3R_P_MUL_END();
+            // phase 3: (a1, b0) from the registers of phase 0; A0, B0, B1 of the next K-tile landed
+            if constexpr (REM >= 2) stage(HB1{}, t + 2);
+            if constexpr (REM >= 1) M3R_VMCNT(REM == 2 ? 8 : 2);
+            M3R_P_LOAD_END(); mma_q(I1{}, I0{}); M3R_P_MUL_END();
+        } else {
+            // phase 0: a0 x (b0, b1); A1 of this K-tile landed
+            read_a(0, bufb); read_b(I0{}, bufb); read_b(I1{}, bufb);
+            if constexpr (REM >= 1) { stage(HB1{}, t + 1); stage(HA1{}, t + 1); }
+            M3R_VMCNT(REM >= 1 ? 8 : 0);
+            M3R_P_LOAD_END(); mma_h(I0{}); M3R_P_MUL_END();
+            // phase 1: a1 x (b0, b1); A0, B0, B1 of the next K-tile landed
+            read_a(1, bufb);
+            if constexpr (REM >= 2) { stage(HA0{}, t + 2); stage(HB0{}, t + 2); }
+            if constexpr (REM >= 1) M3R_VMCNT(REM == 2 ? 6 : 2);
+            M3R_P_LOAD_END(); mma_h(I1{}); M3R_P_MUL_END();
+        }
+    };
+    int t = 0;
+    for (; t + 2 < nk; ++t) ktile(std::integral_constant<int, 2>{}, t);
+    if (t + 1 < nk) { ktile(std::integral_constant<int, 1>{}, t); ++t; }
+    ktile(std::integral_constant<int, 0>{}, t);
+    if (wr == 0) __builtin_amdgcn_s_barrier();
+    } else {
+        // load blocks of the two phases of K-tile t (the same for both groups; the schedule and the counted waits of the SYNC = 2 form)
+        auto load0 = [&](auto remc, int t) {
+            constexpr int REM = decltype(remc)::value;
+            const unsigned bufb = (t & 1) * BUFB;
+            read_a(0, bufb); read_b(I0{}, bufb); read_b(I1{}, bufb);
+            if constexpr (REM >= 1) { stage(HB1{}, t + 1); stage(HA1{}, t + 1); }
+            M3R_VMCNT(REM >= 1 ? 8 : 0);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        auto load1 = [&](auto remc, int t) {
+            constexpr int REM = decltype(remc)::value;
+            const unsigned bufb = (t & 1) * BUFB;
+            read_a(1, bufb);
+            if constexpr (REM >= 2) { stage(HA0{}, t + 2); stage(HB0{}, t + 2); }
+            if constexpr (REM >= 1) M3R_VMCNT(REM == 2 ? 6 : 2);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        if (wr == 0) {
+            auto ktile = [&](auto remc, int t) {
+                load0(remc, t); mma_h(I0{}); M3R_P_MUL_END();
+                load1(remc, t); mma_h(I1{}); M3R_P_MUL_END();
+            };
+            int t = 0;
+            for (; t + 2 < nk; ++t) ktile(std::integral_constant<int, 2>{}, t);
+            if (t + 1 < nk) { ktile(std::integral_constant<int, 1>{}, t); ++t; }
+            ktile(std::integral_constant<int, 0>{}, t);
+        } else {
+            auto ktile = [&](auto remc, int t) {
+                if (t > 0) { mma_h(I1{}); __builtin_amdgcn_sched_barrier(0); }   // the second half of K-tile t - 1, on the fragments read in the last interval
+                load0(remc, t); M3R_P_MUL_END();
+                mma_h(I0{}); __builtin_amdgcn_sched_barrier(0);
+                load1(remc, t); M3R_P_MUL_END();
+            };
+            int t = 0;
+            for (; t + 2 < nk; ++t) ktile(std::integral_constant<int, 2>{}, t);
+            if (t + 1 < nk) { ktile(std::integral_constant<int, 1>{}, t); ++t; }
+            ktile(std::integral_constant<int, 0>{}, t);
+            mma_h(I1{});
+        }
+    }
+#undef M3R_VMCNT
+#undef M3R_P_LOAD_END
+#undef M3R_P_MUL_END
+
+    epilogue_tile<T, EPI, NF, MF, 4, false>(p, outp, bias, m0 + wr * 128 + fr, n0 + wc * WN, fg, acc, NoLnFold{}, bpre);
+}
+
+template <class T, int EPI, int WS, int BN, int NPH, int SYNC = 2>
+static int launch_256p(const GemmArgs& a, hipStream_t s) {
+    const int nbn = a.N / BN, nbm = (a.M + 255) / 256;
+    const size_t lds = (size_t)2 * 4 * 128 * 64 * sizeof(T);
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256p_kernel<T, EPI, WS, BN, NPH, SYNC>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return 1;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((gemm256p_kernel<T, EPI, WS, BN, NPH, SYNC>), dim3(nbm * nbn, a.batch > 1 ? a.batch : 1), dim3(512), lds, s, a);
+    return hipGetLastError() == hipSuccess ? 0 : 1;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // M = 768 launches with N = 768 (proj, fc2, projq of the memory update): 48 x 48 tiles = exactly 256 blocks, ONE per CU,
 // 9 waves (3 x 3, wave tile 16 x 16).  A cycle trace of the 64 x 64 kernels (scripts/probes/gemm_trace.hip) shows where a
 // K-tile's 0.35 us go: every wave spends ~250 cycles ISSUING its three 1 KB LDS-DMA instructions (~80 cycles each), ~270
@@ -1649,6 +1940,16 @@ static int g256k_mode() {
     }
     return v;
 }
+// M3R_G256P: the phase-staggered 64-deep kernel (gemm256p_kernel) for the chip-filling launches.  plain weights: 0 never, 2 / 4 = phases per K-tile;
+// M3R_G256P_SPLIT: 0 never, 2 = the 256 x 128 split-weight form.
+static int g256p_mode(bool split) {
+    static int v[2] = {-1, -1};
+    if (v[split] < 0) {
+        const char* e = getenv(split ? "M3R_G256P_SPLIT" : "M3R_G256P");
+        v[split] = e ? atoi(e) : 0;
+    }
+    return v[split];
+}
 // (r04, measured and removed: two 256 x 128 blocks per CU -- the GELU launches' OCC = 2 form -- for the other split-weight epilogues, so that one
 // block's fp32 read-modify-write epilogue runs under the other's K loop: RESID proj 44.7 -> 52.1 us (dec) / 67.2 -> 68.2 us (enc), fc2 122 -> 152 us,
 // STORE16 K|V 71.9 -> 77.8 us, RoPE qkv +-1 %; nine split shapes 1246 -> 1308 us, step 497.6 -> 487.9 views/s.  profiles/r04_occ2_ab.txt.)
@@ -1699,6 +2000,8 @@ static int launch_epi(const GemmArgs& a, hipStream_t s, const char** err) {
             } else if (EPI == EPI_STORE16_GELU && gelu_occ2 && mode != 0 && ok128 && t128 >= 1024) { pick_name("g256o2", EPI, 2, 128); rc = launch_256<T, EPI, 2, 128, 2>(a, s); }
             else if (EPI != EPI_HEAD && use_96(a, nb)) { pick_name("g96", EPI, 2, 96); rc = launch_96<T, EPI == EPI_HEAD ? EPI_STORE16 : EPI>(a, s); }
             else if (EPI != EPI_QKV_ROPE && EPI != EPI_HEAD && use_48(a, nb)) { pick_name("g48", EPI, 2, 48); rc = launch_48<T, EPI == EPI_QKV_ROPE || EPI == EPI_HEAD ? EPI_STORE16 : EPI, 2>(a, s); }
+            else if (pick != 0 && g256p_mode(true) == 2 && ok128 && a.K % 64 == 0) { pick_name("g256p2", EPI, 2, 128); rc = launch_256p<T, EPI, 2, 128, 2>(a, s); }
+            else if (pick != 0 && g256p_mode(true) == 1 && ok128 && a.K % 64 == 0) { pick_name("g256p1", EPI, 2, 128); rc = launch_256p<T, EPI, 2, 128, 2, 1>(a, s); }
             else if (pick != 0 && g256k_mode() >= 2 && ok128) { pick_name("g256k", EPI, 2, 128); rc = launch_256k<T, EPI, 2, 128>(a, s); }
             else if (pick == 256) { pick_name("g256", EPI, 2, 256); rc = launch_256<T, EPI, 2, 256>(a, s); }
             else if (pick == 192) { pick_name("g256", EPI, 2, 192); rc = launch_256<T, EPI == EPI_QKV_ROPE ? EPI_STORE16 : EPI, 2, 192>(a, s); }
@@ -1722,6 +2025,10 @@ static int launch_epi(const GemmArgs& a, hipStream_t s, const char** err) {
         } else if (EPI != EPI_QKV_ROPE && EPI != EPI_HEAD && sizeof(T) == 2 && use_48(a, nb)) {
             pick_name("g48", EPI, 1, 48);
             rc = launch_48<T, EPI == EPI_QKV_ROPE || EPI == EPI_HEAD ? EPI_STORE16 : EPI, 1>(a, s);   // N = 768 one-view launches: 256 tiles of 48 x 48
+        } else if (ok256 && a.K % 64 == 0 && g256p_mode(false) != 0 && (mode == 2 || (mode == 1 && t256 >= 200 && fill256(t256) >= 80))) {
+            if (g256p_mode(false) == 4) { pick_name("g256p4", EPI, 1, 256); rc = launch_256p<T, EPI, 1, 256, 4>(a, s); }
+            else if (g256p_mode(false) == 1) { pick_name("g256p1", EPI, 1, 256); rc = launch_256p<T, EPI, 1, 256, 2, 1>(a, s); }
+            else { pick_name("g256p2", EPI, 1, 256); rc = launch_256p<T, EPI, 1, 256, 2>(a, s); }
         } else if (ok256 && (mode == 2 || (mode == 1 && t256 >= 200 && fill256(t256) >= 80))) { pick_name(g256k_mode() >= 1 ? "g256k" : "g256", EPI, 1, 256); rc = g256k_mode() >= 1 ? launch_256k<T, EPI, 1, 256>(a, s) : launch_256<T, EPI, 1, 256>(a, s); }
         else if (n128 && tiles128 >= min_big(false) && !lnp) { pick_name("g128", EPI, 1, 128); rc = launch_cfg<T, 128, 128, 2, 2, EPI, 2, 1>(a, s); }
         else if (small8((long)((a.M + 63) / 64) * (a.N / 64) * nb)) { pick_name("g64p", EPI, 1, 64); rc = launch_cfg<T, 64, 64, SMALL_WGM, 2, EPI, SMALL8_NST_PLAIN, 1, 64, 1>(a, s); }

@@ -15,6 +15,7 @@ _TORCH_DT = {_lib.BF16: torch.bfloat16, _lib.F16: torch.float16, _lib.F16_W2: to
 PRECISIONS = ("bf16", "fp16", "fp16w2", "fp16wa")
 _VERSION_OF = operator.attrgetter("_version")
 _DATA_PTR_OF = operator.methodcaller("data_ptr")
+_DTYPE_OF = operator.attrgetter("dtype")
 _DEBUG_WEIGHTS = bool(int(os.environ.get("M3R_DEBUG_WEIGHTS", "0") or 0))
 
 
@@ -61,13 +62,16 @@ class HipModule(nn.Module):
     # caller of the reference) the check works on a cached parameter list and three integers instead:
     #   * an epoch counter bumped by what replaces or moves the parameters of THIS module wholesale (`load_state_dict`, `_apply` =
     #     .to() / .cuda() / .half(), `train`); the cached list is rebuilt when it moves;
-    #   * the SUM of `_version` over the list: any in-place edit of a parameter tensor -- an optimizer step, `p.mul_()`,
+    #   * the ordered hash of `_version` over the list (r05; a sum through r04): any in-place edit of a parameter tensor -- an optimizer step, `p.mul_()`,
     #     `p.copy_()` under no_grad, a submodule's `load_state_dict` -- changes it;
-    #   * the SUM of `data_ptr()` over the list: a conversion or move of ANY submodule (`model.blocks_dec[3].half()`,
+    #   * the ordered hash of `data_ptr()` (and of the dtypes) over the list: a conversion or move of ANY submodule (`model.blocks_dec[3].half()`,
     #     `child.to(...)`) gives its parameters new storage.  (r03 bumped the epoch from `_apply` wrappers installed on the children's
     #     instances instead; those closures broke `copy.deepcopy(model).half()` and `torch.save(model)` -- ADVICE r03 -- and are gone:
     #     nothing is patched onto any module.)
     # NOT seen -- call `refresh_weights()` after these:
+    #   * a CHILD converted and converted back (`model.blocks_dec[i].half().float()`) when the caching allocator hands the same blocks
+    #     back: same pointers, same dtypes, same version counters, fp16-rounded values (`param.data = fn(param.data)` keeps `_version`).
+    #     Converting the WHOLE module goes through its own `_apply` and is seen;
     #   * edits through `.data` (`p.data.copy_(w)`, `p.data.mul_(..)`, EMA-style updates): `.data` is a detached alias with its own
     #     version counter, so neither sum moves;
     #   * a parameter OBJECT replaced on a child (`child.weight = nn.Parameter(...)`): the cached list still holds the old one.
@@ -82,7 +86,8 @@ class HipModule(nn.Module):
         if ps is None or ps[1] != self._weights_epoch:
             ps = (list(self.parameters()), self._weights_epoch)
             self.__dict__["_param_cache"] = ps
-        fp = (self._weights_epoch, sum(map(_VERSION_OF, ps[0])), sum(map(_DATA_PTR_OF, ps[0])))
+        # (r05, ADVICE r04: ORDERED hashes, not sums -- a swap or permutation of storages between parameters keeps a sum -- and the dtypes)
+        fp = (self._weights_epoch, hash(tuple(map(_VERSION_OF, ps[0]))), hash(tuple(map(_DATA_PTR_OF, ps[0]))), hash(tuple(map(_DTYPE_OF, ps[0]))))
         if _DEBUG_WEIGHTS:
             full = self._full_fingerprint()
             last = self.__dict__.get("_debug_full")

@@ -168,6 +168,21 @@ class MUSt3R(HipModule):
                     b[:, :Nm].copy_(v.reshape(B, Nm, mem_D))
         return owner
 
+    def _check_memory_rows(self, mem_vals, mem_D, fp8_rows):
+        """The row format of a memory handed back by the caller must be the one this module's mode reads: fp8 'kv' rows are opaque
+        bytes [K e4m3: D | V 16-bit: 2 D] (uint8, 3 D per row), every other mode holds 16-bit (or wider floating) elements, mem_D per row.  A
+        numeric cast between the two would hand the kernels garbage and, in one direction, let them read past the buffer -- refuse instead."""
+        for v in mem_vals:
+            if fp8_rows:
+                if v.dtype != torch.uint8 or int(v.shape[2]) != mem_D:
+                    raise ValueError(f"attention_fp8 with memory_mode 'kv': the memory must be the uint8 [B, Nm, {mem_D}] rows an fp8-mode "
+                                     f"update returned, got {v.dtype} [.., {int(v.shape[2])}] (a memory written with attention_fp8 off cannot "
+                                     "be read with it on; re-run the update in this mode)")
+            elif not v.dtype.is_floating_point or int(v.shape[2]) != mem_D:
+                raise ValueError(f"memory_mode {self.memory_mode!r} without attention_fp8: the memory must be floating-point [B, Nm, {mem_D}] rows, "
+                                 f"got {v.dtype} [.., {int(v.shape[2])}] (a memory written with attention_fp8 on holds opaque e4m3 | 16-bit bytes "
+                                 "and cannot be read with it off; re-run the update in this mode)")
+
     # -- forward -------------------------------------------------------------------------------
     @torch.no_grad()
     def forward(self, x, pos, true_shape, current_mem=None, render=False, return_feats=False):
@@ -255,18 +270,12 @@ class MUSt3R(HipModule):
             assert all(int(v.shape[0]) == B for v in mem_vals), "memory and inputs must share the batch size"
 
         mem_D = (3 * D if fp8_rows else 2 * D) if self.memory_mode == "kv" else D
+        if current_mem is not None:
+            self._check_memory_rows(mem_vals, mem_D, fp8_rows)
         if render:
             # read-only: any [B, Nm, mem_D] tensors whose rows are contiguous and whose scene stride is the same in every layer
             # (the prefix views of this module's own buffers are: stride cap x mem_D) are read in place
             vals, stride = [], None
-            if fp8_rows:
-                # rows are opaque bytes [K e4m3 | V 16-bit] (3 D per row): a memory written in 16-bit mode ([., Nm, 2 D] 16-bit elements) has
-                # another row format -- a numeric cast would hand the kernel garbage and let it read Nm x D bytes past the buffer
-                for v in mem_vals:
-                    if v.dtype != torch.uint8 or int(v.shape[2]) != mem_D:
-                        raise ValueError(f"attention_fp8 with memory_mode 'kv': the memory must be the uint8 [B, Nm, {mem_D}] rows an fp8-mode "
-                                         f"update returned, got {v.dtype} [.., {int(v.shape[2])}] (a memory written with attention_fp8 off cannot "
-                                         "be rendered with it on; re-run the update in this mode)")
             for v in mem_vals:
                 if not v.is_cuda or v.dtype != tdt or v.stride(2) != 1 or v.stride(1) != mem_D or (B > 1 and v.stride(0) % mem_D):
                     v = v.to(device=device, dtype=tdt).contiguous()

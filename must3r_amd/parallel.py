@@ -112,7 +112,7 @@ def _gather_keyframes(x, pos, true_shape_local, keyframe_local, group, comm_dtyp
     r04 ("pos is recomputable from the grid"): positions and true shapes no longer ride two more collectives.
     Each keyframe's payload is its [N, C] tokens plus ONE extra row whose first four entries are (h // 256, h % 256, w // 256, w % 256)
     of its true shape -- integers below 256, exact in bf16 and fp16 -- and the positions are rebuilt from the token grid
-    (``grid`` = (H/16, W/16) of the stored images, the same on every rank; transposed for the portrait views of a ManyAR patch embed)."""
+    (``grid`` = the encoder's patch size; r05: each keyframe's grid is (h / patch) x (w / patch) of ITS OWN gathered true shape)."""
     idx = torch.nonzero(keyframe_local.cpu()).flatten()
     if counts is None:
         counts = gather_counts(int(idx.numel()), x.device, group)
@@ -122,6 +122,8 @@ def _gather_keyframes(x, pos, true_shape_local, keyframe_local, group, comm_dtyp
     idx_d = idx.to(x.device)
     kx = x.index_select(0, idx_d)
     ts = true_shape_local.cpu().index_select(0, idx).to(torch.int64)
+    if ts.numel() and (int(ts.max()) >= 65536 or int(ts.min()) < 0):   # two base-256 digits per extent ride in one 16-bit token row (exact below 65536)
+        raise ValueError(f"true_shape {tuple(ts.max(dim=0).values.tolist())} does not fit the keyframe payload's (h // 256, h % 256, w // 256, w % 256) row")
     meta = torch.zeros((kx.shape[0], 1, kx.shape[2]), dtype=torch.float32)
     meta[:, 0, 0], meta[:, 0, 1] = ts[:, 0] // 256, ts[:, 0] % 256
     meta[:, 0, 2], meta[:, 0, 3] = ts[:, 1] // 256, ts[:, 1] % 256
@@ -134,20 +136,27 @@ def _gather_keyframes(x, pos, true_shape_local, keyframe_local, group, comm_dtyp
     kts = torch.stack([m[:, 0] * 256 + m[:, 1], m[:, 2] * 256 + m[:, 3]], dim=1)
     if grid is None:   # single-process callers without images: fall back to the positions themselves
         return kx, all_gather_varlen(pos.index_select(0, idx_d), group, counts), kts
-    gh, gw = grid
-    land = grid_positions(gh, gw, kx.device)
-    if many_ar and bool((kts[:, 0] > kts[:, 1]).any()):
-        port = grid_positions(gw, gh, kx.device)
-        sel = (kts[:, 0] > kts[:, 1]).to(kx.device)
-        kpos = torch.where(sel[:, None, None], port.unsqueeze(0), land.unsqueeze(0)).contiguous()
-    else:
-        kpos = land.unsqueeze(0).expand(kx.shape[0], -1, -1).contiguous()
+    # r05: every keyframe's positions come from ITS OWN true shape, which arrived with its tokens -- (h / p) x (w / p) row-major
+    # grid, exactly what both patch embeds of the reference hand out (PatchEmbedDust3R: the stored H x W IS the true shape; ManyAR: a portrait
+    # view is transposed before the projection and gets the transposed grid).  r04 used the LOCAL rank's stored image
+    # grid for all of them: wrong as soon as ranks hold different stored shapes with the same token count (384 x 512 on one, 512 x 384 on another).
+    patch = int(grid)
+    N = int(kx.shape[1])
+    kpos = torch.empty((kx.shape[0], N, 2), dtype=torch.int64, device=kx.device)
+    shapes = kts.tolist()
+    for hw in sorted(set(map(tuple, shapes))):
+        gh, gw = hw[0] // patch, hw[1] // patch
+        if gh * gw != N or hw[0] % patch or hw[1] % patch:
+            raise ValueError(f"gathered keyframe of true shape {hw} does not have the {N} tokens of this stack (patch {patch})")
+        sel = torch.tensor([i for i, s_ in enumerate(shapes) if tuple(s_) == hw], dtype=torch.int64, device=kx.device)
+        kpos.index_copy_(0, sel, grid_positions(gh, gw, kx.device).unsqueeze(0).expand(sel.numel(), -1, -1).contiguous())
     return kx, kpos, kts
 
 
 def _grid_of(encoder, imgs_local):
+    """The patch size positions are rebuilt with (the gathered true shapes do the rest); second value kept for callers of the r04 signature."""
     many_ar = getattr(getattr(encoder, "patch_embed", None), "kind", "PatchEmbedDust3R") == "ManyAR_PatchEmbed"
-    return (int(imgs_local.shape[-2]) // 16, int(imgs_local.shape[-1]) // 16), many_ar
+    return int(getattr(encoder, "patch_size", 16) or 16), many_ar
 
 
 def _render_local(decoder, x, pos, true_shape_local, mem, imgs_local):

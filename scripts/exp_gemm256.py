@@ -24,7 +24,7 @@ shapes = [("enc qkv", 15360, 3072, 1024, lib.EPI_STORE16), ("enc proj", 15360, 1
           ("dec fc1", 15360, 3072, 768, lib.EPI_STORE16_GELU), ("dec fc2", 15360, 768, 3072, lib.EPI_RESID_F32),
           ("dec kv", 15360, 1536, 768, lib.EPI_STORE16), ("tail M", 15360 - 100, 1024, 1024, lib.EPI_F32),
           ("enc18 fc1", 13824, 4096, 1024, lib.EPI_STORE16_GELU), ("k192", 4096, 1024, 192, lib.EPI_STORE16)]
-if os.environ.get("ONLY"):   # timing-experiment shapes (the fixed per-tile cost; a long K loop)
+if os.environ.get("ONLY") or os.environ.get("EXTRA"):   # timing-experiment shapes (the fixed per-tile cost; a long K loop)
     shapes += [("k64", 15360, 3072, 64, lib.EPI_STORE16), ("k128", 15360, 3072, 128, lib.EPI_STORE16), ("k4096", 15360, 3072, 4096, lib.EPI_STORE16),
                ("k64 f32", 15360, 3072, 64, lib.EPI_RESID_F32), ("k16384", 15360, 1024, 16384, lib.EPI_STORE16)]
 if os.environ.get("MROWS"):   # the decoder shapes at another row count (S scenes in flight: M = S * 768 in the batched update)
@@ -67,6 +67,14 @@ for name, M, N, K, epi in shapes:
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / 10
+    if True:
+        if epi == lib.EPI_RESID_F32:   # the in-place residual epilogue accumulates: start from the same zeros again
+            out.zero_()
+            run()
+            torch.cuda.synchronize()
+        digest2 = hashlib.sha1(out.view(torch.int16 if out.element_size() == 2 else torch.int32).cpu().numpy().tobytes()).hexdigest()[:12]
+        if digest2 != digest:
+            print(f"RACE: {name}: output bits changed between launches ({digest} -> {digest2})", flush=True)
     fl = 2.0 * M * N * K
     if M >= 15000 or only or os.environ.get("MROWS"):
         tot_t += ms

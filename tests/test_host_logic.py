@@ -326,6 +326,15 @@ def test_copies_and_pickles_of_the_modules_are_independent(tmp_path):
     dec.blocks_dec[1].attn.qkv.float()
     # in-place edits: version counters
     fp2 = dec._fingerprint()
+    # (the convert-and-back round trip of a CHILD is the documented blind spot when the allocator returns the same blocks -- _hip_module.py,
+    # "NOT seen": refresh_weights() -- ; what IS guaranteed: the fingerprint is stable again, and an order-changing swap of two storages moves it)
+    assert dec._fingerprint() == fp2
+    a, b = dec.blocks_dec[0].norm1.weight, dec.blocks_dec[0].norm2.weight
+    da, db = a.data, b.data
+    a.data, b.data = db, da                                             # same multiset of pointers, versions and dtypes: only the ORDER moved
+    assert dec._fingerprint() != fp2
+    a.data, b.data = da, db
+    assert dec._fingerprint() == fp2
     with torch.no_grad():
         dec.blocks_dec[0].mlp.fc1.bias.add_(1.0)
     assert dec._fingerprint() != fp2
@@ -341,8 +350,26 @@ def test_copies_and_pickles_of_the_modules_are_independent(tmp_path):
     assert back._fingerprint() != dec._fingerprint()                    # its own storage
 
 
-def test_fp8_memory_rows_are_not_cast_from_a_16_bit_memory():
-    """with attention_fp8 + 'kv' the memory rows are opaque uint8 [B, Nm, 3 D]; a 16-bit memory must be refused, not cast."""
+def test_memory_rows_of_the_other_attention_mode_are_refused_not_cast():
+    """ADVICE r03 + r04: with attention_fp8 + 'kv' the memory rows are opaque uint8 [B, Nm, 3 D]; every other mode holds floating-point [B, Nm, mem_D]
+    rows.  A memory of the OTHER format must be refused in BOTH directions (a numeric cast would be silently wrong), update and render alike: the
+    check runs in front of both branches of `_forward_scene`."""
+    cfg = TINY
+    dec = M.MUSt3R(img_size=(cfg.img_size, cfg.img_size), enc_embed_dim=cfg.enc_dim, embed_dim=cfg.dec_dim, depth=cfg.dec_depth,
+                   num_heads=cfg.dec_heads, memory_mode="kv").eval()
+    D, Nm = cfg.dec_dim, 8
+    mem16 = [torch.zeros((1, Nm, 2 * D), dtype=torch.float16) for _ in range(cfg.dec_depth)]
+    mem8 = [torch.zeros((1, Nm, 3 * D), dtype=torch.uint8) for _ in range(cfg.dec_depth)]
+    dec._check_memory_rows(mem16, 2 * D, False)                       # the right format passes, both ways
+    dec._check_memory_rows(mem8, 3 * D, True)
+    dec._check_memory_rows([m.float() for m in mem16], 2 * D, False)   # a wider floating type is a legitimate numeric cast
+    with pytest.raises(ValueError, match="attention_fp8 on holds opaque"):
+        dec._check_memory_rows(mem8, 2 * D, False)                    # fp8 rows read with attention_fp8 off (the direction r04 missed)
+    with pytest.raises(ValueError, match="attention_fp8 off cannot"):
+        dec._check_memory_rows(mem16, 3 * D, True)                    # 16-bit rows read with attention_fp8 on
+    with pytest.raises(ValueError):
+        dec._check_memory_rows([torch.zeros((1, Nm, 3 * D), dtype=torch.float16)] * cfg.dec_depth, 2 * D, False)   # right dtype, wrong row width
+    # the check sits in front of BOTH the render and the update branch
     src = open(os.path.join(ROOT, "must3r_amd", "model", "decoder.py")).read()
-    i = src.index("if fp8_rows:\n                # rows are opaque bytes")
-    assert "raise ValueError" in src[i:i + 900] and "torch.uint8" in src[i:i + 900]
+    i, j, k = src.index("self._check_memory_rows(mem_vals, mem_D, fp8_rows)"), src.index("        if render:\n            # read-only"), src.index("self._writable_memory(mem_vals, Nm")
+    assert i < j < k

@@ -46,6 +46,22 @@ def _worker(rank, world, port, out_dir):
         assert g.flatten().tolist() == [0.0, 1.0, 2.0, 10.0]
         e = all_gather_varlen(torch.zeros((0, 2)) if rank == 1 else torch.ones((2, 2)))
         assert e.shape == (2, 2)
+        # r05: ranks holding DIFFERENT stored shapes with the same token count -- every gathered keyframe's positions must be those of
+        # ITS OWN shape (rebuilt from the true shape that travels with the tokens), i.e. exactly what gathering the positions themselves gives
+        from must3r_amd.parallel import _gather_keyframes, grid_positions
+        hw, nloc = ((48, 64), 2) if rank == 0 else ((64, 48), 1)
+        xk = torch.randn(nloc, 12, 8)
+        posk = grid_positions(hw[0] // 16, hw[1] // 16, torch.device("cpu")).unsqueeze(0).expand(nloc, -1, -1).contiguous()
+        tsk = torch.tensor([hw] * nloc)
+        allk = torch.ones(nloc, dtype=torch.bool)
+        _, kpos_rebuilt, kts_a = _gather_keyframes(xk, posk, tsk, allk, None, None, None, 16, False)
+        _, kpos_gathered, kts_b = _gather_keyframes(xk, posk, tsk, allk, None, None, None, None, False)
+        assert torch.equal(kpos_rebuilt, kpos_gathered) and torch.equal(kts_a, kts_b) and kts_a.tolist() == [[48, 64], [48, 64], [64, 48]]
+        assert not torch.equal(kpos_rebuilt[0], kpos_rebuilt[2])
+        with pytest.raises(ValueError, match="does not fit the keyframe payload"):   # the payload row holds two base-256 digits per extent
+            _gather_keyframes(xk, posk, torch.tensor([[65536, 16]] * nloc), allk, None, None, None, 16, False)
+        with pytest.raises(ValueError, match="does not have the 12 tokens"):        # a shape that is not this stack's token count
+            _gather_keyframes(xk, posk, torch.tensor([[64, 64]] * nloc), allk, None, None, None, 16, False)
         imgs, ts = S.make_images(V, H, W, 0)
         lo, hi = shard_range(V, rank, world)
         enc, dec = _oracle_pair()
