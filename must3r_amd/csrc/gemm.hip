@@ -24,8 +24,11 @@ namespace m3r {
 __device__ unsigned long long g_gemm_trace[64 * 8];   // scripts/probes/gemm_trace.hip: cycle stamps of block 0 / thread 0
 __device__ unsigned long long g_gemm256_trace[2][64 * 8];   // scripts/probes/gemm256_trace.hip: block 0, lane 0 of wave 0 (group 0) / wave 4 (group 1)
 #define M3R_STAMP256(slot) do { if (blockIdx.x == 0 && lane == 0 && wc == 0 && t < 64) g_gemm256_trace[wr][t * 8 + (slot)] = __builtin_readcyclecounter(); } while (0)
+// gemm256p_kernel (scripts/probes/gemm256p_trace.hip): 16 stamps per K-tile, K-tiles 0..31, s_memtime (shader cycles)
+#define M3R_STAMPP(slot) do { if (blockIdx.x == p.trace_block && lane == 0 && wc == 0 && t < 32) g_gemm256_trace[wr][t * 16 + (slot)] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define M3R_STAMP256(slot) do { } while (0)
+#define M3R_STAMPP(slot) do { } while (0)
 #endif
 
 // One output row segment of a lane: v[j][r] = C[m][n = nw0 + j*16 + fg*4 + r] before bias; nw0 = first column of the wave tile.
@@ -1368,15 +1371,34 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
             M3R_P_LOAD_END(); mma_q(I1{}, I0{}); M3R_P_MUL_END();
         } else {
             // phase 0: a0 x (b0, b1); A1 of this K-tile landed
+            M3R_STAMPP(0);
             read_a(0, bufb); read_b(I0{}, bufb); read_b(I1{}, bufb);
             if constexpr (REM >= 1) { stage(HB1{}, t + 1); stage(HA1{}, t + 1); }
+            M3R_STAMPP(1);
             M3R_VMCNT(REM >= 1 ? 8 : 0);
-            M3R_P_LOAD_END(); mma_h(I0{}); M3R_P_MUL_END();
+            M3R_STAMPP(2);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            M3R_STAMPP(3);
+            M3R_P_LOAD_END();
+            M3R_STAMPP(4);
+            mma_h(I0{});
+            M3R_STAMPP(5);
+            M3R_P_MUL_END();
             // phase 1: a1 x (b0, b1); A0, B0, B1 of the next K-tile landed
+            M3R_STAMPP(6);
             read_a(1, bufb);
             if constexpr (REM >= 2) { stage(HA0{}, t + 2); stage(HB0{}, t + 2); }
+            M3R_STAMPP(7);
             if constexpr (REM >= 1) M3R_VMCNT(REM == 2 ? 6 : 2);
-            M3R_P_LOAD_END(); mma_h(I1{}); M3R_P_MUL_END();
+            M3R_STAMPP(8);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            M3R_STAMPP(9);
+            M3R_P_LOAD_END();
+            M3R_STAMPP(10);
+            mma_h(I1{});
+            M3R_STAMPP(11);
+            M3R_P_MUL_END();
+            M3R_STAMPP(12);
         }
     };
     int t = 0;
@@ -1444,6 +1466,386 @@ static int launch_256p(const GemmArgs& a, hipStream_t s) {
         attr_set = true;
     }
     hipLaunchKernelGGL((gemm256p_kernel<T, EPI, WS, BN, NPH, SYNC>), dim3(nbm * nbn, a.batch > 1 ? a.batch : 1), dim3(512), lds, s, a);
+    return hipGetLastError() == hipSuccess ? 0 : 1;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// gemm256q_kernel (r05): the same tile and 64-deep K-tiles with ONE barrier per K-tile.
+//   What the cycle trace of gemm256p_kernel says (profiles/r05_gemm256p_trace.txt; the same numbers for ONE tile on an idle chip, so it is not
+//   the memory system): a K-tile takes ~2750 cycles where its 128 MFMAs per SIMD need 2048; the multiply intervals themselves run at ~17.2 cycles
+//   per MFMA (one wave issuing alone), and every one of the four hand-overs per K-tile costs ~120-140 cycles in which the matrix pipe is empty
+//   -- the release latency of an eight-wave s_barrier, paid with every wave of the CU parked.  A blocking barrier cannot be hidden (whoever
+//   executes it stops), so this kernel executes one per K-tile instead of four:
+//     every wave, between two barriers:  issue the 8 DMA pieces of K-tile t+1 (its buffer was last read in the previous interval)  ...  vmcnt(0)
+//     group 0:  read ALL fragments of K-tile t, then its 64 MFMAs;
+//     group 1:  its 64 MFMAs of K-tile t-1 (fragments read at the end of the last interval), then read all fragments of K-tile t.
+//   The two waves of a SIMD are half a K-tile apart by construction; who multiplies when both could is decided by priority (VAR bit 0: group 1's
+//   block outranks group 0's, so the blocks serialise without a barrier between them) or left to the arbiter.
+//   RAW  K-tile t+1 is waited for (vmcnt 0) by every wave at the end of interval t and read in interval t+1.
+//   WAR  its buffer held K-tile t-1, read in interval t-1 by both groups (group 1 at its end, lgkmcnt 0 in front of the barrier).
+// Operand addresses are 32-bit byte offsets on the wave-uniform matrix bases (8 registers instead of 16 pointers; launch_256q refuses larger matrices).
+// Same accumulation order per output as every other tile shape: identical bits.
+template <class T, int EPI, int WS, int BN, int VAR>
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) gemm256q_kernel(const GemmArgs p) {
+    typedef typename Vec<T>::v8 v8;
+    constexpr int BM = 256, BK = 64;
+    static_assert(WS * BN == 256, "the staged weight region is 256 rows");
+    constexpr int WN = BN / 4, MF = 8, NF = WN / 16;
+    constexpr unsigned BUFB = 512 * 128;                   // A [256][64] then W [256][64], 128-byte rows
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+
+    const int nbn = p.N / BN;
+    const int nbm = (p.M + BM - 1) / BM;
+    const int nwg = nbm * nbn;
+    int bid = blockIdx.x;
+    {
+        const int xcd = bid & 7, slot = bid >> 3;
+        const int q = nwg >> 3, r = nwg & 7;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+    }
+    constexpr int GM = 4;
+    const int tpg = GM * nbn;
+    const int gidx = bid / tpg;
+    const int gfirst = gidx * GM;
+    const int gsz = (nbm - gfirst < GM) ? nbm - gfirst : GM;
+    const int gin = bid - gidx * tpg;
+    const int m0 = (gfirst + gin % gsz) * BM;
+    const int n0 = (gin / gsz) * BN;
+
+    const int grp = blockIdx.y;
+    const char* __restrict__ A = reinterpret_cast<const char*>(reinterpret_cast<const T*>(p.A) + (size_t)grp * p.strideA);
+    const int wgrp = p.wdiv > 1 ? grp / p.wdiv : grp;
+    const char* __restrict__ W = reinterpret_cast<const char*>(reinterpret_cast<const T*>(p.W) + (size_t)wgrp * p.strideW);
+    const float* __restrict__ bias = p.bias ? p.bias + (size_t)wgrp * p.strideB : nullptr;
+    void* const outp = p.out_table ? p.out_table[grp] : p.out;
+
+    // ---- staging: a wave moves pieces 4 wave .. 4 wave + 3 (8 rows x 128 B each) of the A region and of the W region
+    const int srow = lane >> 3, pch = lane & 7;
+    unsigned a_off[4], w_off[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int r = (wave * 4 + q) * 8 + srow;
+        int gr = m0 + r;
+        gr = gr < p.M ? gr : p.M - 1;
+        a_off[q] = (unsigned)gr * (unsigned)(p.lda * 2) + (unsigned)(swz(r, pch) * 16);
+        const int part = r / BN, wrow = r - part * BN;
+        w_off[q] = (unsigned)(n0 + wrow) * (unsigned)(p.K * WS * 2) + (unsigned)part * (unsigned)(p.K * 2) + (unsigned)(swz(r, pch) * 16);
+    }
+    auto stage = [&](int kt) {
+        char* const base = smem + (kt & 1) * BUFB + wave * 4096;
+        const char* const Ak = A + (size_t)kt * (BK * 2);
+        const char* const Wk = W + (size_t)kt * (BK * 2);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) glds16(Ak + a_off[q], base + q * 1024);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) glds16(Wk + w_off[q], base + 32768 + q * 1024);
+    };
+
+    f32x4 acc[MF][NF];
+#pragma unroll
+    for (int i = 0; i < MF; ++i)
+#pragma unroll
+        for (int j = 0; j < NF; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int fr = lane & 15, fg = lane >> 4;
+    const int nk = p.K / BK;
+    unsigned a_lane[2], w_lane[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        const int ra = wr * 128 + fr, rw = wc * WN + fr;
+        a_lane[ks] = (unsigned)(ra * 128 + swz(ra, ks * 4 + fg) * 16);
+        w_lane[ks] = 32768u + (unsigned)(rw * 128 + swz(rw, ks * 4 + fg) * 16);
+    }
+    v8 af[2][MF], wf[2][WS][NF];
+    auto reads = [&](int t) {
+        const unsigned bufb = (t & 1) * BUFB;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+            for (int part = 0; part < WS; ++part)
+#pragma unroll
+                for (int j = 0; j < NF; ++j) wf[ks][part][j] = *reinterpret_cast<const v8*>(smem + bufb + w_lane[ks] + (part * BN + j * 16) * 128);
+#pragma unroll
+            for (int i = 0; i < MF; ++i) af[ks][i] = *reinterpret_cast<const v8*>(smem + bufb + a_lane[ks] + i * 2048);
+        }
+    };
+    auto mma = [&](auto prioc) {
+        constexpr int PRIO = decltype(prioc)::value;
+        __builtin_amdgcn_s_setprio(PRIO);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int part = 0; part < WS; ++part)
+#pragma unroll
+                for (int i = 0; i < MF; ++i)
+#pragma unroll
+                    for (int j = 0; j < NF; ++j) acc[i][j] = mfma16(wf[ks][part][j], af[ks][i], acc[i][j]);
+        __builtin_amdgcn_s_setprio(0);
+    };
+    typedef std::integral_constant<int, 1> P1;
+    typedef std::integral_constant<int, (VAR & 1) ? 2 : 1> PG1;
+#define M3R_Q_END() do { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define M3R_Q_LGKM() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+
+    stage(0);
+    M3R_Q_END();
+    if ((VAR & 4) || wr == 0) {
+        for (int t = 0; t < nk; ++t) {
+            if constexpr (!(VAR & 8)) { if (t + 1 < nk) stage(t + 1); }
+            reads(t);
+            if constexpr ((VAR & 8) != 0) { if (t + 1 < nk) stage(t + 1); }
+            M3R_Q_LGKM();
+            mma(P1{});
+            __builtin_amdgcn_sched_barrier(0);
+            M3R_Q_END();
+        }
+    } else {
+        if (nk > 1) stage(1);
+        reads(0);
+        M3R_Q_LGKM();
+        M3R_Q_END();
+        for (int t = 1; t < nk; ++t) {
+            if (t + 1 < nk) stage(t + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(PG1{});
+            __builtin_amdgcn_sched_barrier(0);
+            reads(t);
+            M3R_Q_LGKM();
+            M3R_Q_END();
+        }
+        mma(PG1{});
+    }
+#undef M3R_Q_END
+#undef M3R_Q_LGKM
+
+    epilogue_tile<T, EPI, NF, MF, 4, false>(p, outp, bias, m0 + wr * 128 + fr, n0 + wc * WN, fg, acc, NoLnFold{});
+}
+
+template <class T, int EPI, int WS, int BN, int VAR>
+static int launch_256q(const GemmArgs& a, hipStream_t s) {
+    // 32-bit operand offsets: the last byte of either matrix must be addressable from its base
+    if ((unsigned long long)a.M * (unsigned long long)a.lda * 2ull >= (1ull << 32) || (unsigned long long)a.N * (unsigned long long)a.K * WS * 2ull >= (1ull << 32)) return 2;
+    const int nbn = a.N / BN, nbm = (a.M + 255) / 256;
+    const size_t lds = (size_t)2 * 512 * 128;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256q_kernel<T, EPI, WS, BN, VAR>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return 1;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((gemm256q_kernel<T, EPI, WS, BN, VAR>), dim3(nbm * nbn, a.batch > 1 ? a.batch : 1), dim3(512), lds, s, a);
+    return hipGetLastError() == hipSuccess ? 0 : 1;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// gemm256w_kernel (r05): 256 x BN tile, FOUR waves -- one per SIMD, 512 registers each -- with 128 x (BN / 2) wave tiles: the structure of the vendor
+// library's kernel for these shapes (rocprofv3 names it Custom_Cijk_..._MT256x256x64_MI16x16x1, profiles/r05_vendor_kernel_names.txt; 1376 TF/s at
+// M = 15360, N = 3072, K = 4096 on the box where gemm256p reaches 1131 and gemm256k 1073, profiles/r05_vendor_yardstick.txt).
+//   Why one wave per SIMD: with two, every form measured in r03-r05 loses the matrix pipe somewhere -- both waves in the vector-memory front end at
+//   once (gemm256k), the eight-wave hand-over (gemm256 / gemm256p: ~2700 cycles per K-tile for 2048 of MFMA work), or two waves multiplying side by
+//   side (gemm256p SYNC = 1, gemm256q: slower still).  A single wave owns its SIMD's matrix pipe: its 128 MFMAs per K-tile go out back to back and
+//   the 32 ds_read_b128 + 16 LDS-DMA pieces it needs per K-tile are slotted between them, one every few MFMAs (an MFMA occupies the pipe for 16
+//   cycles and the issue port for 4).  128 x 128 wave tiles also read a third less from the LDS per MFMA (32 fragment reads per 128 MFMAs; 24 per
+//   64 with 128 x 64 tiles).
+// Software pipeline, skewed by half a K-tile so that there is always multiply work whose operands are already in registers when a barrier releases:
+//   two fragment sets, X = the first 32-deep step of a K-tile, Y = the second.  Iteration t:  vmcnt(0), lgkmcnt(0), barrier  (K-tile t visible; the
+//   buffer of K-tile t-1 free)  |  64 MFMAs on Y = (t-1, second step), with the 16 reads of X <- (t, first step) and the 16 DMA pieces of K-tile t+1 between
+//   them  |  64 MFMAs on X, with the 16 reads of Y <- (t, second step) between them.  Two 64 KB buffers, ONE four-wave barrier per K-tile.
+// Same accumulation order per output as every other tile shape (k ascending, hi before lo in each 32-deep step): identical bits.
+template <class T, int EPI, int WS, int BN, int PAT = 0>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) gemm256w_kernel(const GemmArgs p) {
+    typedef typename Vec<T>::v8 v8;
+    constexpr int BM = 256, BK = 64;
+    static_assert(WS * BN == 256, "the staged weight region is 256 rows");
+    constexpr int WN = BN / 2, MF = 8, NF = WN / 16;      // plain: 128 x 128 wave tiles (NF = 8); split: 128 x 64 against hi and lo (NF = 4)
+    constexpr int NWF = NF * WS;                          // weight fragments per 32-deep step: 8
+    constexpr unsigned BUFB = 512 * 128;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+
+    const int nbn = p.N / BN;
+    const int nbm = (p.M + BM - 1) / BM;
+    const int nwg = nbm * nbn;
+    int bid = blockIdx.x;
+    {
+        const int xcd = bid & 7, slot = bid >> 3;
+        const int q = nwg >> 3, r = nwg & 7;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+    }
+    constexpr int GM = 4;
+    const int tpg = GM * nbn;
+    const int gidx = bid / tpg;
+    const int gfirst = gidx * GM;
+    const int gsz = (nbm - gfirst < GM) ? nbm - gfirst : GM;
+    const int gin = bid - gidx * tpg;
+    const int m0 = (gfirst + gin % gsz) * BM;
+    const int n0 = (gin / gsz) * BN;
+
+    const int grp = blockIdx.y;
+    const char* __restrict__ A = reinterpret_cast<const char*>(reinterpret_cast<const T*>(p.A) + (size_t)grp * p.strideA);
+    const int wgrp = p.wdiv > 1 ? grp / p.wdiv : grp;
+    const char* __restrict__ W = reinterpret_cast<const char*>(reinterpret_cast<const T*>(p.W) + (size_t)wgrp * p.strideW);
+    const float* __restrict__ bias = p.bias ? p.bias + (size_t)wgrp * p.strideB : nullptr;
+    void* const outp = p.out_table ? p.out_table[grp] : p.out;
+
+    // ---- staging: a wave moves pieces 8 wave .. 8 wave + 7 (8 rows x 128 B each) of the A region and of the W region
+    const int srow = lane >> 3, pch = lane & 7;
+    unsigned a_off[8], w_off[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int r = (wave * 8 + q) * 8 + srow;
+        int gr = m0 + r;
+        gr = gr < p.M ? gr : p.M - 1;
+        a_off[q] = (unsigned)gr * (unsigned)(p.lda * 2) + (unsigned)(swz(r, pch) * 16);
+        const int part = r / BN, wrow = r - part * BN;
+        w_off[q] = (unsigned)(n0 + wrow) * (unsigned)(p.K * WS * 2) + (unsigned)part * (unsigned)(p.K * 2) + (unsigned)(swz(r, pch) * 16);
+    }
+    // (the buffer form of the LDS-DMA -- raw_ptr_buffer_load_lds, K-tile position in the scalar offset, no vector add per piece -- is a scheduling
+    // barrier to the compiler: the sched_group_barrier interleave below falls apart into [16 reads][16 pieces][64 MFMAs]; the flat form is scheduled)
+    auto stage = [&](int kt) {
+        char* const base = smem + (kt & 1) * BUFB + wave * 8192;
+        const char* const Ak = A + (size_t)kt * (BK * 2);
+        const char* const Wk = W + (size_t)kt * (BK * 2);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            glds16(Ak + a_off[q], base + q * 1024);
+            glds16(Wk + w_off[q], base + 32768 + q * 1024);
+        }
+    };
+
+    f32x4 acc[MF][NF];
+#pragma unroll
+    for (int i = 0; i < MF; ++i)
+#pragma unroll
+        for (int j = 0; j < NF; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int fr = lane & 15, fg = lane >> 4;
+    const int nk = p.K / BK;
+    unsigned a_lane[2], w_lane[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        const int ra = wr * 128 + fr, rw = wc * WN + fr;
+        a_lane[ks] = (unsigned)(ra * 128 + swz(ra, ks * 4 + fg) * 16);
+        w_lane[ks] = 32768u + (unsigned)(rw * 128 + swz(rw, ks * 4 + fg) * 16);
+    }
+    v8 fa[2][MF], fw[2][NWF];   // [set = 32-deep step of the K-tile]
+    auto read_set = [&](auto setc, int t) {
+        constexpr int set = decltype(setc)::value;
+        const unsigned bufb = (t & 1) * BUFB;
+#pragma unroll
+        for (int part = 0; part < WS; ++part)
+#pragma unroll
+            for (int j = 0; j < NF; ++j) fw[set][part * NF + j] = *reinterpret_cast<const v8*>(smem + bufb + w_lane[set] + (part * BN + j * 16) * 128);
+#pragma unroll
+        for (int i = 0; i < MF; ++i) fa[set][i] = *reinterpret_cast<const v8*>(smem + bufb + a_lane[set] + i * 2048);
+    };
+    auto mma_set = [&](auto setc) {
+        constexpr int set = decltype(setc)::value;
+#pragma unroll
+        for (int part = 0; part < WS; ++part)
+#pragma unroll
+            for (int i = 0; i < MF; ++i)
+#pragma unroll
+                for (int j = 0; j < NF; ++j) acc[i][j] = mfma16(fw[set][part * NF + j], fa[set][i], acc[i][j]);
+    };
+    typedef std::integral_constant<int, 0> SX;
+    typedef std::integral_constant<int, 1> SY;
+
+    stage(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    read_set(SX{}, 0);
+    if (nk > 1) stage(1);
+    read_set(SY{}, 0);
+    mma_set(SX{});
+    // one iteration; MORE: K-tile t + 1 exists (its DMA pieces ride in the Y block) -- a compile-time flag, a branch would cut the scheduling region
+    auto iter = [&](auto morec, int t) {
+        constexpr bool MORE = decltype(morec)::value;
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        read_set(SX{}, t);
+        if constexpr (MORE) stage(t + 1);
+        mma_set(SY{});
+        read_set(SY{}, t);
+        mma_set(SX{});
+        // the interleave.  PAT 0: Y block = 16 x [2 MFMA, 1 DS read] + 16 x [2 MFMA, 1 DMA piece]; X block = 16 x [4 MFMA, 1 DS read]
+        //                  PAT 1: the 16 reads of X under the first 16 MFMAs, then one DMA piece per 4 MFMAs over the next 64 (the last 48 of the Y block and the
+        //                         first 16 of the X block: ~70 cycles per piece and wave = the ~17 cycles per piece the CU's front end takes, times its four
+        //                         waves), then the 16 reads of Y, one per 3 MFMAs
+        if constexpr (PAT == 0) {
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                if constexpr (MORE) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            }
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+        } else {
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+                if constexpr (MORE) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            }
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    int t = 1;
+    for (; t + 1 < nk; ++t) iter(std::true_type{}, t);
+    if (t < nk) iter(std::false_type{}, t);
+    __builtin_amdgcn_sched_barrier(0);   // (or the scheduler pairs the last X block with the Y block below: back-to-back MFMAs on the same accumulator)
+    mma_set(SY{});
+
+    // ---- epilogue, 64 columns at a time (the full-line 16-bit stores and the RoPE pairs of epilogue_tile want 64-column wave tiles)
+#pragma unroll
+    for (int half = 0; half < NF / 4; ++half) {
+        f32x4 part[MF][4];
+#pragma unroll
+        for (int i = 0; i < MF; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) part[i][j] = acc[i][half * 4 + j];
+        epilogue_tile<T, EPI, 4, MF, 4, false>(p, outp, bias, m0 + wr * 128 + fr, n0 + wc * WN + half * 64, fg, part, NoLnFold{});
+    }
+}
+
+template <class T, int EPI, int WS, int BN, int PAT = 0>
+static int launch_256w(const GemmArgs& a, hipStream_t s) {
+    if ((unsigned long long)a.M * (unsigned long long)a.lda * 2ull >= (1ull << 32) || (unsigned long long)a.N * (unsigned long long)a.K * WS * 2ull >= (1ull << 32)) return 2;
+    const int nbn = a.N / BN, nbm = (a.M + 255) / 256;
+    const size_t lds = (size_t)2 * 512 * 128;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256w_kernel<T, EPI, WS, BN, PAT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return 1;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((gemm256w_kernel<T, EPI, WS, BN, PAT>), dim3(nbm * nbn, a.batch > 1 ? a.batch : 1), dim3(256), lds, s, a);
     return hipGetLastError() == hipSuccess ? 0 : 1;
 }
 
@@ -1940,13 +2342,19 @@ static int g256k_mode() {
     }
     return v;
 }
-// M3R_G256P: the phase-staggered 64-deep kernel (gemm256p_kernel) for the chip-filling launches.  plain weights: 0 never, 2 / 4 = phases per K-tile;
-// M3R_G256P_SPLIT: 0 never, 2 = the 256 x 128 split-weight form.
+// M3R_G256P (r05): the phase-staggered 64-deep kernel (gemm256p_kernel, two phases per K-tile, two barriers per phase) for the chip-filling launches.
+//   plain weights  (M3R_G256P, default 1): 0 never (gemm256k_kernel), 1 every epilogue but the RoPE one (its instantiation spills), measured on the
+//                  nine shapes of scripts/exp_gemm256.py: 2-6 % faster on each (profiles/r05_g256p_plain_ab.txt), 987 -> 1113 TF/s at K = 16384;
+//   split weights  (M3R_G256P_SPLIT, default 1): 0 never, 1 where its 256 x 128 tiles fill their rounds at least as well as the widest tile gemm256_kernel
+//                  would pick (decoder qkv N = 2304: 109 -> 103 us, K|V N = 1536: 72.6 -> 65.2 us; NOT the 256-wide encoder qkv 160 -> 162 us or the
+//                  192-wide decoder proj 44.7 -> 51.8 us, profiles/r05_g256p_split_ab.txt), 2 whenever the shape allows.
+// The other forms measured in r05 (four phases per K-tile; one barrier per phase with group 1 lagging; gemm256q: one barrier per K-tile; gemm256w: four
+// waves with 128 x 128 wave tiles) stay in this file as templates for scripts/probes/kloop_lab.hip and are not instantiated by the library.
 static int g256p_mode(bool split) {
     static int v[2] = {-1, -1};
     if (v[split] < 0) {
         const char* e = getenv(split ? "M3R_G256P_SPLIT" : "M3R_G256P");
-        v[split] = e ? atoi(e) : 0;
+        v[split] = e ? atoi(e) : 1;
     }
     return v[split];
 }
@@ -2000,8 +2408,9 @@ static int launch_epi(const GemmArgs& a, hipStream_t s, const char** err) {
             } else if (EPI == EPI_STORE16_GELU && gelu_occ2 && mode != 0 && ok128 && t128 >= 1024) { pick_name("g256o2", EPI, 2, 128); rc = launch_256<T, EPI, 2, 128, 2>(a, s); }
             else if (EPI != EPI_HEAD && use_96(a, nb)) { pick_name("g96", EPI, 2, 96); rc = launch_96<T, EPI == EPI_HEAD ? EPI_STORE16 : EPI>(a, s); }
             else if (EPI != EPI_QKV_ROPE && EPI != EPI_HEAD && use_48(a, nb)) { pick_name("g48", EPI, 2, 48); rc = launch_48<T, EPI == EPI_QKV_ROPE || EPI == EPI_HEAD ? EPI_STORE16 : EPI, 2>(a, s); }
-            else if (pick != 0 && g256p_mode(true) == 2 && ok128 && a.K % 64 == 0) { pick_name("g256p2", EPI, 2, 128); rc = launch_256p<T, EPI, 2, 128, 2>(a, s); }
-            else if (pick != 0 && g256p_mode(true) == 1 && ok128 && a.K % 64 == 0) { pick_name("g256p1", EPI, 2, 128); rc = launch_256p<T, EPI, 2, 128, 2, 1>(a, s); }
+            else if (pick != 0 && ok128 && a.K % 64 == 0 && (g256p_mode(true) == 2 || (g256p_mode(true) == 1 && (pick == 128 || (pick == 192 && t128 >= 200 && fill256(t128) >= fill256(t192) && fill256(t128) >= 90))))) {
+                pick_name("g256p", EPI, 2, 128); rc = launch_256p<T, EPI, 2, 128, 2>(a, s);
+            }
             else if (pick != 0 && g256k_mode() >= 2 && ok128) { pick_name("g256k", EPI, 2, 128); rc = launch_256k<T, EPI, 2, 128>(a, s); }
             else if (pick == 256) { pick_name("g256", EPI, 2, 256); rc = launch_256<T, EPI, 2, 256>(a, s); }
             else if (pick == 192) { pick_name("g256", EPI, 2, 192); rc = launch_256<T, EPI == EPI_QKV_ROPE ? EPI_STORE16 : EPI, 2, 192>(a, s); }
@@ -2025,10 +2434,8 @@ static int launch_epi(const GemmArgs& a, hipStream_t s, const char** err) {
         } else if (EPI != EPI_QKV_ROPE && EPI != EPI_HEAD && sizeof(T) == 2 && use_48(a, nb)) {
             pick_name("g48", EPI, 1, 48);
             rc = launch_48<T, EPI == EPI_QKV_ROPE || EPI == EPI_HEAD ? EPI_STORE16 : EPI, 1>(a, s);   // N = 768 one-view launches: 256 tiles of 48 x 48
-        } else if (ok256 && a.K % 64 == 0 && g256p_mode(false) != 0 && (mode == 2 || (mode == 1 && t256 >= 200 && fill256(t256) >= 80))) {
-            if (g256p_mode(false) == 4) { pick_name("g256p4", EPI, 1, 256); rc = launch_256p<T, EPI, 1, 256, 4>(a, s); }
-            else if (g256p_mode(false) == 1) { pick_name("g256p1", EPI, 1, 256); rc = launch_256p<T, EPI, 1, 256, 2, 1>(a, s); }
-            else { pick_name("g256p2", EPI, 1, 256); rc = launch_256p<T, EPI, 1, 256, 2>(a, s); }
+        } else if (ok256 && a.K % 64 == 0 && g256p_mode(false) != 0 && EPI != EPI_QKV_ROPE && (mode == 2 || (mode == 1 && t256 >= 200 && fill256(t256) >= 80))) {
+            pick_name("g256p", EPI, 1, 256); rc = launch_256p<T, EPI == EPI_QKV_ROPE ? EPI_STORE16 : EPI, 1, 256, 2>(a, s);
         } else if (ok256 && (mode == 2 || (mode == 1 && t256 >= 200 && fill256(t256) >= 80))) { pick_name(g256k_mode() >= 1 ? "g256k" : "g256", EPI, 1, 256); rc = g256k_mode() >= 1 ? launch_256k<T, EPI, 1, 256>(a, s) : launch_256<T, EPI, 1, 256>(a, s); }
         else if (n128 && tiles128 >= min_big(false) && !lnp) { pick_name("g128", EPI, 1, 128); rc = launch_cfg<T, 128, 128, 2, 2, EPI, 2, 1>(a, s); }
         else if (small8((long)((a.M + 63) / 64) * (a.N / 64) * nb)) { pick_name("g64p", EPI, 1, 64); rc = launch_cfg<T, 64, 64, SMALL_WGM, 2, EPI, SMALL8_NST_PLAIN, 1, 64, 1>(a, s); }

@@ -71,6 +71,9 @@ struct GemmArgs {
     //     column-0 blocks leave shift += mean(y) (= the current row mean) for the next producer.  ln_shift_init: the buffer holds nothing yet.
     float* ln_shift;
     int ln_shift_init;
+#ifdef GEMM_TRACE
+    int trace_block;         // probe builds only (scripts/probes/gemm256p_trace.hip): the block whose waves leave cycle stamps
+#endif
 };
 
 // returns 0 on success, non-zero (and sets *err) on an unsupported shape

@@ -66,6 +66,9 @@ def main(cases=None, mixed=True):
             pos=pos[:, ::tks].numpy(),
             update=upd[:, ::ps, ::ps].numpy(), update_abs=np.float64(upd.double().abs().sum().item()),
             render=ren[:, ::ps, ::ps].numpy(), render_abs=np.float64(ren.double().abs().sum().item()),
+            # r05: per-view max |value| over the FULL-resolution map (all pixels, all 7 channels): lets a test normalise the error of the stored
+            # (sub-sampled) pixels by the same per-view range bench.py's all-pixel parity figure uses, instead of by the max of the sample
+            update_vmax=upd.double().abs().amax(dim=(1, 2, 3)).numpy(), render_vmax=ren.double().abs().amax(dim=(1, 2, 3)).numpy(),
             mem_first=mem[0][0][0, ::tks, ::tks].numpy(), mem_last=mem[0][-1][0, ::tks, ::tks].numpy(),
             labels=mem[1].numpy(), tail=np.array(mem[2:], dtype=np.int64))
         print(name, "x", tuple(x.shape), "update", tuple(upd.shape), "render", tuple(ren.shape), "Nm", mem[0][0].shape[1])
@@ -182,6 +185,8 @@ if __name__ == "__main__":
         main()
     if which == "model_big":
         main(BIG_CASES, mixed=False)
+    if which in BIG_CASES or which in CASES:
+        main({which: {**CASES, **BIG_CASES}[which]}, mixed=False)
     if which in ("all", "cam"):
         make_cam()
     if which in ("all", "nn"):

@@ -168,13 +168,15 @@ def test_gemm96_tiles_same_bits_as_small_tiles(lib, shape):
     record("gemm96", shape=shape, err_f32=rel_inf(full, ref))
 
 
-@pytest.mark.parametrize("ws", [0, 2])
-def test_gemm256_tiles_same_bits_as_small_tiles(lib, ws):
-    """Chip-filling launches run on 256-row tiles (plain weights: gemm256k_kernel, 64-deep K chunks; split weights: gemm256_kernel) with the
+@pytest.mark.parametrize("ws,N", [(0, 1024), (2, 1024), (2, 1536)])
+def test_gemm256_tiles_same_bits_as_small_tiles(lib, ws, N):
+    """Chip-filling launches run on 256-row tiles (plain weights: gemm256p_kernel -- r05, phase-staggered 64-deep K-tiles; gemm256k_kernel before --;
+    split weights: gemm256_kernel, or gemm256p_kernel's 256 x 128 form where that fills its rounds better: N = 1536) with the
     batched epilogue (operands of four row fragments loaded in front of their stores, 16-byte full-line stores after two cross-lane
     exchanges).  Every row must carry the bits of the same row computed by a 64-row launch (64 x 64 tiles, per-fragment epilogue
-    path for the ragged fragment), for all four epilogues, including the ragged last row block (M = 15260: 156 rows, last fragment 12)."""
-    M, N, K = 15260, 1024, 192
+    path for the ragged fragment), for all four epilogues, including the ragged last row block (M = 15260: 156 rows, last fragment 12).
+    K = 192 = three K-tiles: the steady, the second-to-last and the last form of the K loop."""
+    M, K = 15260, 192
     g = torch.Generator(device="cuda").manual_seed(77 + ws)
     A = torch.randn((M, K), device="cuda", generator=g).half()
     Wf = torch.randn((N, K), device="cuda", generator=g) / math.sqrt(K)
@@ -201,7 +203,7 @@ def test_gemm256_tiles_same_bits_as_small_tiles(lib, ws):
             part = x0[r0:r1].clone() if epi == lib.EPI_RESID_F32 else torch.empty((r1 - r0, N), device="cuda", dtype=odt)
             go(epi, A[r0:r1], part)
             assert torch.equal(part, full[r0:r1]), (epi, r0)
-    record("gemm256_bits", ws=ws)
+    record("gemm256_bits", ws=ws, N=N)
 
 
 
