@@ -4,7 +4,7 @@
     python bench.py --gpus 1 --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
-A "step" is one pass of the hot path over one batch of synthetic input already resident in HBM: S (``--scenes``, default 20)
+A "step" is one pass of the hot path over one batch of synthetic input already resident in HBM: S (``--scenes``, default 28; 20 in r03-r04)
 independent scenes of 20 views per rank -- every scene: encode 20, memory update with the demo schedule [2,1,...,1] (20-view
 memory), render 20 against its final memory, fp32 activation (BASELINE.json configs[2]).  The S scenes
 are IN FLIGHT TOGETHER: they ride the batch dimension of the reference's decoder API (decoder.py:170-186), one native call per
@@ -92,8 +92,11 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--views", type=int, default=20)
-    ap.add_argument("--scenes", type=int, default=20, help="S: independent 20-view scenes in flight together per rank (they ride the "
-                    "decoder's batch dimension: M = S x 768 rows in the sequential memory update); 1 = one scene at a time")
+    ap.add_argument("--scenes", type=int, default=28, help="S: independent 20-view scenes in flight together per rank (they ride the "
+                    "decoder's batch dimension: M = S x 768 rows in the sequential memory update); 1 = one scene at a time.  r05 default 28 (r03-r04: "
+                    "20): at 28 every decoder GEMM of the update fills its rounds of 256-row tiles over the 256 CUs to 98 %% (84 row blocks x 9 / 12 / 3 / 6 "
+                    "column tiles; at 20: 70-94 %%) -- DESIGN.md section 3.4, profiles/r04_scenes_sweep.txt; the S = 20 figure stays in "
+                    "scenes_in_flight_sweep for continuity with BENCH_r03 / r04")
     ap.add_argument("--precision", default="fp16wa", choices=["bf16", "fp16", "fp16w2", "fp16wa"],
                     help="MFMA operand mode; fp16wa (fp16, split weights except in the Mlp Linears) and fp16w2 (all weights split) meet the "
                          "1e-3 parity target")
@@ -134,6 +137,8 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
+        # the N > 1 line must say which transport carried its collectives: RCCL ("nccl" on ROCm) unless M3R_DIST_BACKEND asked for the dry-run one
+        assert dist.get_backend() == backend and (backend == "nccl" or "M3R_DIST_BACKEND" in os.environ), (dist.get_backend(), backend)
 
     cfg, H, W, V = MUST3R_512, 384, 512, args.views
     N = (H // 16) * (W // 16)
@@ -236,13 +241,9 @@ def main():
     kern = {"attn3_kernel": (["attn_self", "attn_cross"], ("attn3_kernel", "attn4_kernel")),
             "gemm_kernel<big tile>": (["gemm128"], ("gemm256_kernel", "gemm256k_kernel", "Li128ELi64E", "Li128ELi128E")),
             "gemm_kernel<small-M>": (["gemm64"], ("Li64ELi64E", "gemm48_kernel", "gemm96_kernel", "gemms_kernel"))}
-    try:
-        import glob
-        pmc_file = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))[-1]
-        pmc_doc = json.load(open(pmc_file))
-        pmc = pmc_doc["kernels"]
-    except Exception:
-        pmc_file, pmc, pmc_doc = None, {}, {}
+    # (r05, VERDICT r04 item 3: `traffic` comes from THIS round's PMC passes at THIS run's number of scenes in flight or is null -- see the evidence
+    # block below; the r01-r03 per-class file profiles/rNN_pmc_traffic.json is no longer read)
+    pmc_file, pmc, pmc_doc = None, {}, {}
     want = "DF16b" if args.precision == "bf16" else "DF16_"
 
     def roof(name):
@@ -284,7 +285,7 @@ def main():
 
     roofline_attention = roof("attn3_kernel")
     roofline_attention["per_symbol"] = symbol_rows(("attn",))
-    roofline_gemm = [roof("gemm_kernel<big tile>"), roof("gemm_kernel<small-M>")]
+    roofline_gemm = [r for r in (roof("gemm_kernel<big tile>"), roof("gemm_kernel<small-M>")) if r["launches"] > 0]   # (no all-zero row for a class the step never launches)
     # `roofline` = the kernel CLASS that takes the most time of the step (the GEMM family, not the single top symbol)
     gemm_ms = sum(prof[c]["ms"] for c in ("gemm128", "gemm64") if c in prof)
     attn_ms = sum(prof[c]["ms"] for c in ("attn_self", "attn_cross") if c in prof)
@@ -293,7 +294,7 @@ def main():
         ach = a["flops"] / (a["ms"] * 1e-3) / 1e12 if a["ms"] > 0 else 0.0
         roofline = {"bound": "mfma", "kernel": "GEMM family (every out = epi(A W^T + b) launch of the step: gemm256k / gemm256 / gemm_kernel / gemm96 / gemm48 symbols)",
                     "achieved": round(ach, 1), "peak": PEAK_TFLOPS[args.precision], "unit": "TFLOP/s", "frac": round(ach / PEAK_TFLOPS[args.precision], 4),
-                    "traffic": roofline_gemm[0].get("traffic"), "traffic_note": "bytes per launch of the chip-filling GEMM symbols (PMC, corrected), see roofline_gemm[0]",
+                    "traffic": None,
                     "ms_per_step": round(a["ms"], 3), "share_of_step_kernel_time": round(a["ms"] / max(1e-9, sum(v["ms"] for k, v in prof.items() if k != "_kernels")), 4),
                     "launches": int(a["calls"]), "avg_launch_us": round(a["ms"] * 1e3 / max(1, a["calls"]), 2),
                     "algorithmic_flops": "2 M N K per launch, ONE pass (split-weight launches run two MFMA passes for it)",
@@ -303,9 +304,19 @@ def main():
         roofline = roofline_attention
     # fabric bytes per launch (L2 -> MALL / HBM requests by size, PMC) from the closing profile of the round, joined per symbol by
     # scripts/prof_match.py -- only when it was taken at this step size (per-launch bytes scale with the rows per launch)
+    EV = "profiles/r05_roofline_evidence.json"
     try:
-        ev = json.load(open(os.path.join(ROOT, "profiles", "r04_roofline_evidence.json")))
-        by = {r["kernel"]: r for r in ev["rows"] if r.get("fabric_bytes_per_launch_corrected")}
+        ev = json.load(open(os.path.join(ROOT, EV)))
+        # the passes must belong to this code: their commit has to be an ancestor of HEAD wherever a git checkout is there to ask (the GPU box runs a
+        # snapshot without .git: there the file's own commit stamp is what the line quotes)
+        anc = None
+        try:
+            import subprocess
+            if os.path.isdir(os.path.join(ROOT, ".git")) and ev.get("commit") not in (None, "?"):
+                anc = subprocess.run(["git", "-C", ROOT, "merge-base", "--is-ancestor", str(ev["commit"]), "HEAD"], capture_output=True, timeout=20).returncode == 0
+        except Exception:
+            anc = None
+        by = {r["kernel"]: r for r in ev["rows"] if r.get("fabric_bytes_per_launch_corrected")} if anc is not False else {}
         for rf in (roofline, roofline_attention):
             tot_b = tot_n = 0
             for row in rf.get("per_symbol", []):
@@ -317,11 +328,16 @@ def main():
             if tot_n:
                 rf["traffic"] = int(tot_b / tot_n)
                 rf["traffic_unit"] = "fabric bytes per launch (sized TCC_EA0 read / write requests, launch-weighted over the class's symbols)"
-                rf["traffic_source"] = f"profiles/r04_roofline_evidence.json (separate --pmc passes of `bench.py --step-only`, commit {ev.get('commit', '?')}; not this run)"
-            elif by:
-                rf["traffic_note"] = f"profiles/r04_roofline_evidence.json was taken at another number of scenes in flight than this run's {Sn}"
+                rf["traffic_source"] = (f"{EV} (separate --pmc passes of `bench.py --step-only --scenes {Sn}`, commit {ev.get('commit', '?')}"
+                                        + (", an ancestor of this checkout's HEAD" if anc else "") + "; not this run)")
+            else:
+                rf["traffic"] = None
+                rf["traffic_note"] = (f"{EV} is not an ancestor of HEAD" if anc is False else
+                                      f"{EV} holds no pass at this run's {Sn} scenes in flight" if by else f"{EV}: no usable rows")
     except Exception:
-        pass
+        for rf in (roofline, roofline_attention):
+            rf["traffic"] = None
+            rf["traffic_note"] = f"{EV} not found: no PMC pass of this round to quote"
 
     # postprocess(compute_cam=True) on one scene's 20 rendered pointmaps (HBM-bound:
     # 28 B read + 28 B written per pixel; the focal iteration and the registration add no HBM pass)
@@ -348,16 +364,21 @@ def main():
     # the step at another number of scenes in flight: 28 fills the rounds of every decoder GEMM of the update to 98 % (84 row blocks x 9 / 12 / 3 / 6
     # column tiles over 256 CUs; at 20: 70-94 %) -- reported beside `value`, never in it (DESIGN.md section 3.4 "round quantisation")
     sweep = None
-    if not args.no_alt and world == 1 and Sn == 20:
-        S2 = 28
-        more = torch.stack([S.make_images(V, H, W, seed=2000 + b)[0] for b in range(S2 - Sn)]).to(device)
-        scenes2 = torch.cat([scenes, more], dim=0)
+    if not args.no_alt and world == 1 and Sn in (20, 28):
+        S2 = 28 if Sn == 20 else 20   # the other of the two reported step sizes (r03-r04 headline: 20; r05: 28)
+        if S2 > Sn:
+            more = torch.stack([S.make_images(V, H, W, seed=2000 + b)[0] for b in range(S2 - Sn)]).to(device)
+            scenes2 = torch.cat([scenes, more], dim=0)
+            del more
+        else:
+            scenes2 = scenes[:S2]
         fn2 = lambda: run_scenes(enc, dec, scenes2, ts)  # noqa: E731
         fn2()
         k2 = max(2, args.steps // 2)
         d2 = timed(fn2, k2)
-        sweep = [{"scenes_in_flight": S2, "value": round(S2 * V * k2 / d2, 2), "ms_per_step": round(d2 / k2 * 1e3, 3)}]
-        del more, scenes2
+        sweep = [{"scenes_in_flight": S2, "value": round(S2 * V * k2 / d2, 2), "ms_per_step": round(d2 / k2 * 1e3, 3),
+                  "note": "the r03-r04 definition of `value`" if S2 == 20 else "the r05 definition of `value`"}]
+        del scenes2
 
     alt = None
     if not args.no_alt and world == 1:
@@ -373,6 +394,7 @@ def main():
 
     # ---- the other BASELINE.json configurations, measured in the same run (reported beside the headline, never in it)
     configs = []
+    rccl, sharded = None, None   # N > 1: what the collectives carried and the view-sharded figures, at the TOP level of the line next to the replica `value`
     if not args.no_configs:
         ksteps = max(2, min(10, args.steps))
         if world == 1:
@@ -473,6 +495,12 @@ def main():
             fnw = lambda: run_scene_sharded(enc, dec, wimgs, ts, keyframes, comm_dtype=tdt, keyframe_counts=kf_counts)  # noqa: E731
             fnw()
             d = timed(fnw, ksteps)
+            kmax = max(kf_counts)
+            esz = 2 if tdt in (torch.float16, torch.bfloat16) else 4
+            rccl = {"world_size": world, "backend": dist.get_backend(), "collective": "all_gather_into_tensor (ONE per scene: the encoded keyframe tokens + one row of true-shape digits)",
+                    "all_gather_bytes_per_step": {"weak": world * kmax * (N + 1) * cfg.enc_dim * esz}}
+            sharded = {"weak": {"value": round(V * world * ksteps / d, 2), "unit": "views/s", "ms_per_step": round(d / ksteps * 1e3, 3), "views_per_step": V * world,
+                                "keyframes": sum(kf_counts)}}
             configs.append({"config": f"configs[2] view-sharded, WEAK: every rank owns {V} views ({V * world} per scene), memory from {V} keyframes (every "
                                       f"{world}-th view): all-gather of the keyframe tokens [{backend}], replicated update, sharded encode / render",
                             "value": round(V * world * ksteps / d, 2), "unit": "views/s", "ms_per_step": round(d / ksteps * 1e3, 3),
@@ -486,6 +514,8 @@ def main():
             fns = lambda: run_scene_sharded(enc, dec, simgs, sts, kf_all, comm_dtype=tdt, keyframe_counts=kc_all)  # noqa: E731
             fns()
             d = timed(fns, ksteps)
+            rccl["all_gather_bytes_per_step"]["strong"] = world * max(kc_all) * (N + 1) * cfg.enc_dim * esz
+            sharded["strong"] = {"value": round(V * ksteps / d, 2), "unit": "views/s", "ms_per_step": round(d / ksteps * 1e3, 3), "views_per_step": V}
             configs.append({"config": f"configs[2] view-sharded, STRONG: the same {V}-view 384x512 scene sharded over {world} ranks "
                                       "(encode + render view-sharded, all-gather of the encoded tokens, sequential update replicated)",
                             "value": round(V * ksteps / d, 2), "unit": "views/s", "ms_per_step": round(d / ksteps * 1e3, 3),
@@ -499,6 +529,8 @@ def main():
             fnv = lambda: run_video_sharded(enc, dec, vimgs, vts, comm_dtype=tdt, render=False, frame_counts=fc_all)  # noqa: E731
             fnv()
             d = timed(fnv, 1)
+            rccl["all_gather_bytes_per_step"]["stream"] = world * max(fc_all) * (N + 1) * cfg.enc_dim * esz
+            sharded["stream"] = {"value": round(F / d, 2), "unit": "frames/s", "ms_per_step": round(d * 1e3, 2), "frames": F}
             configs.append({"config": f"configs[3] MUSt3R_512 {F}-frame online streaming memory, frames sharded over {world} ranks "
                                       "(encode sharded, all-gather of all frame tokens, per-frame memory update replicated)",
                             "value": round(F / d, 2), "unit": "frames/s", "ms_per_step": round(d * 1e3, 2), "frames": F,
@@ -581,14 +613,18 @@ def main():
             "value_definition": f"{Sn} independent 20-view scenes in flight per GPU ({views_per_step} views per step) / step time; value_single_scene: one scene at a time",
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": dtype_label, "data": "synthetic",
-            "config": {"workload": f"MUSt3R_512 ViT-L/ViT-B random-init, {V}-view 384x512 scenes with a {V}-view memory each (encode {V} + update[2,1..] + "
-                                   f"render {V} + activation); {Sn} independent scene(s) in flight per GPU = {views_per_step} views per step",
+            "config": {"workload": f"MUSt3R_512 {V}-view 384x512 scenes, S={Sn} independent scenes IN FLIGHT per GPU ({views_per_step} views/step); one at a time: value_single_scene",
+                       # (the driver's record keeps `config`: the definition of `value` and the like-for-like batch-1 figure travel here as well as at the top level)
+                       "value_definition": f"{Sn} independent {V}-view scenes in flight per GPU / step time (every scene: encode {V} + update [2,1,..,1] + render {V} + activation)",
+                       "value_single_scene": (single or {}).get("value") if Sn > 1 else round(value, 2),
+                       "model": "MUSt3R_512 ViT-L encoder / ViT-B memory decoder, random init, feedback single_mlp, memory_mode kv",
                        "views_per_step": views_per_step, "scenes_in_flight_per_gpu": Sn, "views_per_scene": V, "keyframes_per_scene": V,
                        "H": H, "W": W, "ms_per_scene": round(dt / args.steps / Sn * 1e3, 3),
                        "parallelism": "single GPU" if world == 1 else f"{world} replicas (independent scenes per rank, no data-path collective; "
                                                                        f"barrier + max over ranks) [{backend}]"},
             "roofline": roofline, "roofline_attention": roofline_attention, "roofline_gemm": roofline_gemm, "cpu_baseline": cpu_baseline, "parity_vs_cpu_oracle": parity,
             "kernel_classes": classes, "stages_ms": stages, "single_scene": single, "alt": alt, "scenes_in_flight_sweep": sweep, "configs": configs, "postprocess_cam": cam,
+            "rccl": rccl, "view_sharded": sharded,
             "multi_gpu": ("this line is a 1-GPU run; no RCCL run of the N > 1 paths has happened in the build environment (one GPU per box): the "
                           "view-sharded path is covered by world-size-2 gloo tests and a 2-rank gloo dry run of this script" if world == 1 else
                           f"{world} ranks, backend {backend}"),

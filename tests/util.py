@@ -32,11 +32,18 @@ def load_golden(name):
 #          scripts/emul/gemm_precision.py; measured: profiles/).
 TOL = {"fp16w2": 1.0e-3, "fp16wa": 1.0e-3, "fp16": 2.0e-3, "bf16": 1.15e-2}
 PRECISIONS = ("fp16w2", "fp16wa", "fp16", "bf16")
-# the module default (what bench.py times) against the real-reference fixture of the benched scene, worst single view: tightened with the
-# default's measured margin (tests/test_zz_r04_gpu.py::test_benched_configuration_scenes_in_flight_vs_reference_fixture).  r04, fp16wa, 8 scenes in
-# flight: worst update view 9.45e-4, worst render view 9.29e-4 (one scene at a time: 8.6e-4) -- deterministic (no atomics on the path), so the thin
-# margin does not flake; DESIGN.md section 4 says what it would cost to widen it.
-TOL_DEFAULT_FIXTURE = 1.0e-3
+# the module default (what bench.py times) against the real-reference fixture of the benched scene, worst single view.
+# r05: each view's error over the fixture's stored (every 8th) pixels is normalised by that view's max |value| over ALL its pixels
+# and channels (`update_vmax` / `render_vmax`, written by oracle/make_golden.py from the full-resolution reference output) -- the normalisation of
+# bench.py's all-pixel `parity_vs_cpu_oracle` figure (6.3-7.2e-4) -- instead of by the max of the sample (r04: 9.45e-4 against 1.0e-3, a 5 % margin that was
+# an artefact of the sub-sampled range).  Asserted at 8e-4; measured figures in profiles/r05_test_metrics.jsonl.
+TOL_DEFAULT_FIXTURE = 8.0e-4
+
+
+def rel_inf_view(a_sub, ref_sub, vmax):
+    """||a - ref||_inf over the stored pixels of one view / that view's full-resolution max |ref| (fixture key *_vmax)."""
+    a, b = torch.as_tensor(a_sub).double(), torch.as_tensor(ref_sub).double()
+    return ((a - b).abs().max() / max(float(vmax), 1e-30)).item()
 
 
 from must3r_amd.synthetic import make_cam_pointmaps as cam_scene  # noqa: E402,F401
