@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MUST3R_HIP_ABI_VERSION 6
+#define MUST3R_HIP_ABI_VERSION 7
 
 typedef struct must3r_hip_ctx must3r_hip_ctx;
 
@@ -196,6 +196,16 @@ int must3r_hip_op_gemm(int dtype, int epi, const void* A, const void* W, const f
                        int ntok, int gw, int H, int W_img,                                      /* HEAD */
                        int wsplit, /* 2: W is [N, 2K] = [W_hi | W_lo], out = A W_hi^T + A W_lo^T; else 0 */
                        void* stream);
+/* ABI 7 (r05).  Split weights whose LOW part is 2:4-sparse: in every group of 4 consecutive k of a weight row the 2 entries of largest magnitude of
+ * W_lo = fp16(W - fp16(W)) are kept, so that the chip-filling kernel multiplies the low part of a 64-deep K-tile with ONE sparse MFMA per output fragment
+ * (v_smfmac_f32_16x16x64_f16, twice the dense rate).  The library packs and uses this copy by itself for the split weights of a
+ * context (M3R_SPARSE_LO=0: never); these two entry points drive the pair alone (tests, probes).
+ *   pack : w fp32 [rows, K] (rows % 32 == 0, K % 64 == 0) -> vals fp16 [K/64][rows][32], idx uint32 [K/64][rows/32][64]
+ *   gemm : out = epi(A . (W_hi + sparse W_lo)^T + bias); W2 = the dense [N, 2K] = [W_hi | W_lo] rows (hi half read), fp16 operands; N % 128 == 0, K % 64 == 0;
+ *          launches too small to fill the chip with 256 x 128 tiles run the dense two-pass kernels on W2 instead. */
+int must3r_hip_op_sparse24_pack(const float* w, int rows, int K, void* vals, void* idx, void* stream);
+int must3r_hip_op_gemm_sp(int epi, const void* A, const void* W2, const void* Wlo_sp, const void* Widx_sp, const float* bias, void* out,
+                          int M, int N, int K, int lda, int ldc, const int64_t* pos, const float* rope_tab, int rope_cols, int rope_npos, void* stream);
 /* "LN fold" (one-view memory update): the LayerNorm between two Linears is applied AFTER the second product instead of before it.
  * Producer role (epi = RESID_F32 / F32): as must3r_hip_op_gemm, and additionally the new fp32 rows rounded to fp16 (x16_out, row stride
  * ldc), an optional fp32 copy (copy32_out) and per row and 16-column fragment (sum x, sum x^2) into stats_out [M][N/16][2].

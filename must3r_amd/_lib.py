@@ -15,7 +15,7 @@ ATTN_FP8 = 0x100   # OR-able: fp8 (e4m3) attention operands, include/must3r_hip.
 MEM_KV, MEM_NORM_Y, MEM_RAW = 0, 1, 2
 PART_ENCODER, PART_DECODER = 1, 2
 EPI_STORE16, EPI_STORE16_GELU, EPI_QKV_ROPE, EPI_RESID_F32, EPI_F32, EPI_HEAD = range(6)
-ABI_VERSION = 6
+ABI_VERSION = 7
 ACT_NORM_EXP, ACT_LINEAR = 0, 1
 
 # every symbol include/must3r_hip.h declares
@@ -30,6 +30,7 @@ EXPORTS = (
     "must3r_hip_affine", "must3r_hip_row_norm", "must3r_hip_l2_normalize", "must3r_hip_layernorm_act_f32", "must3r_hip_topk_gather", "must3r_hip_weighted_spoc",
     "must3r_hip_op_gemm_lnfold",
     "must3r_hip_postprocess_act", "must3r_hip_postprocess_cam_act",
+    "must3r_hip_op_sparse24_pack", "must3r_hip_op_gemm_sp",
 )
 
 
@@ -94,6 +95,8 @@ def load():
     lib.must3r_hip_attention_scratch_bytes.restype = C.c_size_t
     lib.must3r_hip_op_layernorm.argtypes = [i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, fp, vp]
     lib.must3r_hip_op_gemm_lnfold.argtypes = [i32, i32, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, fp, vp, i32, vp, vp, i32, i32, fp, i32, vp]
+    lib.must3r_hip_op_sparse24_pack.argtypes = [vp, i32, i32, vp, vp, vp]
+    lib.must3r_hip_op_gemm_sp.argtypes = [i32, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, i32, i32, vp]
     lib.must3r_hip_op_im2col.argtypes = [i32, vp, vp, i32, i32, i32, vp]
     lib.must3r_hip_op_cast.argtypes = [i32, vp, vp, vp, C.c_size_t, vp]
     lib.must3r_hip_debug_tr_probe.argtypes = [vp, vp]

@@ -1192,8 +1192,17 @@ template <class T, int EPI, int WS, int BN, int NPH, int SYNC = 2>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) gemm256p_kernel(const GemmArgs p) {
     typedef typename Vec<T>::v8 v8;
     constexpr int BM = 256, BK = 64;
-    static_assert(WS * BN == 256, "the staged weight region is 256 rows: 256 plain columns or 128 columns hi + lo");
+    static_assert((WS <= 2 && WS * BN == 256) || (WS == 3 && BN == 128), "the staged weight region is 256 rows: 256 plain columns or 128 columns hi + lo");
     static_assert(NPH == 2 || (NPH == 4 && WS == 1), "the four-phase form multiplies (a, b0) and (a, b1) in different phases: plain weights only");
+    static_assert(WS != 3 || (NPH == 2 && SYNC == 2 && sizeof(T) == 2 && !__is_same(T, bf16_t)), "sparse low part: fp16, two-phase two-barrier form");
+    // WS = 3 (r05): split weights whose LOW part is 2:4-sparse -- in every group of 4 consecutive k of a weight row only the 2 entries of largest magnitude
+    // are kept (packed at finalize, misc.hip::sparse24_pack_kernel) and the low product of a whole 64-deep K-tile is ONE v_smfmac_f32_16x16x64_f16 per output
+    // fragment (the sparse matrix is the MFMA's A operand = our weight tile; its dense B operand is the two 32-deep activation fragments the hi product
+    // already holds, side by side; profiles/r05_smfmac_probe.txt: operand layout and 2x the dense rate) instead of two dense MFMAs: 48 matrix instructions per
+    // wave and K-tile where the dense split issues 64.  What the dropped (smaller) half of W_lo costs was emulated first (scripts/emul/sparse_lo.py:
+    // fp16wa 6.05e-4 / 5.68e-4 dense, 5.99e-4 / 5.64e-4 sparse: the Mlp Linears' plain weights carry the error, not what is left of the low parts).
+    // Half-tile B1 then holds [128 rows][32 kept values] (8 KB; K-tile-major in memory: one contiguous KB per wave) and, behind them, each wave's own copy of its
+    // 256 bytes of 2-bit positions (one dword per lane: low half fragment 0, high half fragment 1 = the instruction's ABID).
     static_assert(SYNC == 2 || NPH == 2, "the one-barrier form is built on the two-phase schedule");
     constexpr int WN = BN / 4, MF = 8, NF = WN / 16;       // plain: NF = 4 (two column sub-tiles of 2); split: NF = 2 (hi and lo fragments of the same 2)
     constexpr unsigned HALFB = 128 * BK * 2;               // bytes per half-tile (16 KB)
@@ -1227,6 +1236,8 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
     const T* __restrict__ A = reinterpret_cast<const T*>(p.A) + (size_t)grp * p.strideA;
     const int wgrp = p.wdiv > 1 ? grp / p.wdiv : grp;
     const T* __restrict__ W = reinterpret_cast<const T*>(p.W) + (size_t)wgrp * p.strideW;
+    // sparse low part: rows of the whole parameter ahead of this problem's (grouped launches: problem g owns rows g * strideW / 2K ...)
+    const int sp_row0 = WS == 3 ? (int)((size_t)wgrp * (size_t)(p.strideW / (2 * (long long)p.K))) + 0 : 0;
     const float* __restrict__ bias = p.bias ? p.bias + (size_t)wgrp * p.strideB : nullptr;
     void* const outp = p.out_table ? p.out_table[grp] : p.out;
 
@@ -1246,17 +1257,35 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
                 const int col = (hr >> 5) * 64 + h * 32 + (hr & 31);
                 w_src[h][j] = W + (size_t)(n0 + col) * (size_t)p.K + swz(hr, pch) * 8;
             } else {
-                w_src[h][j] = W + (size_t)(n0 + hr) * (size_t)(p.K * 2) + (size_t)h * p.K + swz(hr, pch) * 8;
+                w_src[h][j] = W + (size_t)(n0 + hr) * (size_t)(p.K * 2) + (size_t)h * p.K + swz(hr, pch) * 8;   // (WS = 3: only h = 0, the hi rows, is used)
             }
         }
+    // sparse low part: this wave's KB of kept values (16 rows x 64 B, 64-byte-row swizzle on the source side) and its 256 B of positions, per K-tile
+    const char* lo_src = nullptr;
+    const char* ix_src = nullptr;
+    size_t lo_kstride = 0, ix_kstride = 0;
+    if constexpr (WS == 3) {
+        const int r = wave * 16 + (lane >> 2);
+        lo_src = reinterpret_cast<const char*>(p.Wlo_sp) + ((size_t)(sp_row0 + n0 + r)) * 64 + swz32(r, lane & 3) * 16;
+        lo_kstride = (size_t)p.wsp_rows * 64;
+        ix_src = reinterpret_cast<const char*>(p.Widx_sp) + ((size_t)((sp_row0 + n0) / 32 + wc) * 64 + lane) * 4;
+        ix_kstride = (size_t)(p.wsp_rows / 32) * 256;
+    }
     // which: 0 A0, 1 A1, 2 B0, 3 B1 (the half-tile's place in a buffer); kt: K-tile
     auto stage = [&](auto whichc, int kt) {
         constexpr int which = decltype(whichc)::value;
-        char* const base = smem + (kt & 1) * BUFB + which * HALFB + wave * 2048;
+        if constexpr (WS == 3 && which == 3) {
+            char* const b1 = smem + (kt & 1) * BUFB + 3 * HALFB;
+            glds16(lo_src + (size_t)kt * lo_kstride, b1 + wave * 1024);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ix_src + (size_t)kt * ix_kstride),
+                                             (__attribute__((address_space(3))) void*)(b1 + 8192 + wave * 256), 4, 0, 0);
+        } else {
+            char* const base = smem + (kt & 1) * BUFB + which * HALFB + wave * 2048;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const T* s = which < 2 ? a_src[which & 1][j] : w_src[which & 1][j];
-            glds16(s + (size_t)kt * BK, base + j * 1024);
+            for (int j = 0; j < 2; ++j) {
+                const T* s = which < 2 ? a_src[which & 1][j] : w_src[which & 1][j];
+                glds16(s + (size_t)kt * BK, base + j * 1024);
+            }
         }
     };
     typedef std::integral_constant<int, 0> HA0;
@@ -1282,6 +1311,13 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
     }
     f32x4 bpre[NF];   // bias columns, in front of the first DMA (gemm256k_kernel)
     epilogue_bias<EPI, NF>(p, bias, n0 + wc * WN, fg, bpre);
+    unsigned lo_lane = 0, ix_lane = 0;   // WS = 3: this lane's 16 bytes of kept values of fragment 0 (fragment 1: + 16 rows x 64 B) and its dword of positions
+    if constexpr (WS == 3) {
+        const int rw = wc * 32 + fr;
+        lo_lane = 3 * HALFB + (unsigned)(rw * 64 + swz32(rw, fg) * 16);
+        ix_lane = 3 * HALFB + 8192u + (unsigned)(wave * 256 + lane * 4);
+    }
+    int lo_idx = 0;
 
     v8 af[2][4], bf[2][2][2];   // [ks][row fragment of the sub-tile]; [sub-tile g][ks][fragment]
     auto read_a = [&](int h, unsigned bufb) {
@@ -1292,10 +1328,16 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
     };
     auto read_b = [&](auto gc, unsigned bufb) {
         constexpr int g = decltype(gc)::value;
+        if constexpr (WS == 3 && g == 1) {
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
+            for (int j = 0; j < 2; ++j) bf[1][0][j] = *reinterpret_cast<const v8*>(smem + bufb + lo_lane + j * 1024);
+            lo_idx = *reinterpret_cast<const int*>(smem + bufb + ix_lane);
+        } else {
 #pragma unroll
-            for (int j = 0; j < 2; ++j) bf[g][ks][j] = *reinterpret_cast<const v8*>(smem + bufb + g * HALFB + w_lane[ks] + j * 2048);
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) bf[g][ks][j] = *reinterpret_cast<const v8*>(smem + bufb + g * HALFB + w_lane[ks] + j * 2048);
+        }
     };
     // multiply interval: sub-tile h of the rows against column sub-tile g (plain, 16 MFMAs) ...
     auto mma_q = [&](auto hc, auto gc) {
@@ -1313,6 +1355,21 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
     auto mma_h = [&](auto hc) {
         constexpr int h = decltype(hc)::value;
         __builtin_amdgcn_s_setprio(1);
+        if constexpr (WS == 3) {
+            typedef __attribute__((ext_vector_type(16))) _Float16 f16x16;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[h * 4 + i][j] = mfma16(bf[0][ks][j], af[ks][i], acc[h * 4 + i][j]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const f16x16 x2k = __builtin_shufflevector(af[0][i], af[1][i], 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
+                acc[h * 4 + i][0] = __builtin_amdgcn_smfmac_f32_16x16x64_f16(bf[1][0][0], x2k, acc[h * 4 + i][0], lo_idx, 0, 0);
+                acc[h * 4 + i][1] = __builtin_amdgcn_smfmac_f32_16x16x64_f16(bf[1][0][1], x2k, acc[h * 4 + i][1], lo_idx, 0, 1);
+            }
+        } else
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -1466,6 +1523,232 @@ static int launch_256p(const GemmArgs& a, hipStream_t s) {
         attr_set = true;
     }
     hipLaunchKernelGGL((gemm256p_kernel<T, EPI, WS, BN, NPH, SYNC>), dim3(nbm * nbn, a.batch > 1 ? a.batch : 1), dim3(512), lds, s, a);
+    return hipGetLastError() == hipSuccess ? 0 : 1;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// gemm256pp_kernel (r05): gemm256p_kernel's K loop (two phases per K-tile, two barriers per phase) as a PERSISTENT tile loop: 256 blocks, block b
+// works through tiles b, b + 256, ... (the XCD-aware order of the other kernels applied to that virtual block id: b + 256 k runs on the XCD of b).
+//   Why: a 256 x 256 tile of a K = 768..1024 GEMM is a ~25 us K loop inside ~32 us of block life -- dispatch of the next block, its address set-up, the
+//   first DMA round trip (~1.5-2 us during which the CU does nothing) and the epilogue.  Here the K loop runs on ACROSS the tile boundary: the last two
+//   K-tiles of a tile stage the first two K-tiles of the block's next tile in exactly the slots and with exactly the counted waits the steady state uses
+//   (as if the K sequence continued), so that the next tile's first fragments are in the LDS when the epilogue's last store goes out.
+//   Tile boundary: group 0's closing barrier, the epilogue of all eight waves side by side (were the groups left one barrier apart their epilogues would
+//   serialise behind the hand-over barriers), accumulators cleared, group 1's opening barrier.
+//   vmcnt counts loads AND stores in order, so a counted wait behind the epilogue's stores would wait for their acknowledgement: the last K-tile of a tile
+//   therefore also retires A1 of the next tile's first K-tile (vmcnt 4 instead of 6) and that K-tile's first phase carries no wait at all; its second
+//   phase's wait sits a phase (~0.7 us) behind the last store.
+// Operand addresses are 32-bit byte offsets on the wave-uniform matrix bases (current and next tile: 16 registers); launch_256pp refuses larger matrices,
+// K < 256 and grouped launches.  Same accumulation order per output as every other tile shape: identical bits.
+template <class T, int EPI, int WS, int BN>
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) gemm256pp_kernel(const GemmArgs p) {
+    typedef typename Vec<T>::v8 v8;
+    constexpr int BM = 256, BK = 64;
+    static_assert(WS * BN == 256, "the staged weight region is 256 rows: 256 plain columns or 128 columns hi + lo");
+    constexpr int WN = BN / 4, MF = 8, NF = WN / 16;
+    constexpr unsigned HALFB = 128 * BK * 2;
+    constexpr unsigned BUFB = 4 * HALFB;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+
+    const int nbn = p.N / BN;
+    const int nbm = (p.M + BM - 1) / BM;
+    const int nwg = nbm * nbn;
+    const int nblk = (int)gridDim.x;
+    // virtual block id -> tile origin (the remap and grouped order of gemm256k_kernel / gemm256p_kernel)
+    auto tile_of = [&](int vb, int& m0, int& n0) {
+        const int xcd = vb & 7, slot = vb >> 3;
+        const int q = nwg >> 3, r = nwg & 7;
+        const int bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+        constexpr int GM = 4;
+        const int tpg = GM * nbn;
+        const int gidx = bid / tpg;
+        const int gfirst = gidx * GM;
+        const int gsz = (nbm - gfirst < GM) ? nbm - gfirst : GM;
+        const int gin = bid - gidx * tpg;
+        m0 = (gfirst + gin % gsz) * BM;
+        n0 = (gin / gsz) * BN;
+    };
+
+    const char* __restrict__ A = reinterpret_cast<const char*>(p.A);
+    const char* __restrict__ W = reinterpret_cast<const char*>(p.W);
+    const float* __restrict__ bias = p.bias;
+    void* const outp = p.out;
+
+    // ---- staging: a wave moves pieces 2 wave, 2 wave + 1 (8 rows x 128 B each) of every half-tile; 32-bit byte offsets, [half][piece]
+    const int srow = lane >> 3, pch = lane & 7;
+    unsigned a_cur[2][2], w_cur[2][2], a_nxt[2][2], w_nxt[2][2];
+    auto offsets = [&](int m0, int n0, unsigned (&ao)[2][2], unsigned (&wo)[2][2]) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int hr = (wave * 2 + j) * 8 + srow;
+                int gr = m0 + (hr >> 6) * 128 + h * 64 + (hr & 63);
+                gr = gr < p.M ? gr : p.M - 1;
+                ao[h][j] = (unsigned)gr * (unsigned)(p.lda * 2) + (unsigned)(swz(hr, pch) * 16);
+                if constexpr (WS == 1) {
+                    const int col = (hr >> 5) * 64 + h * 32 + (hr & 31);
+                    wo[h][j] = (unsigned)(n0 + col) * (unsigned)(p.K * 2) + (unsigned)(swz(hr, pch) * 16);
+                } else {
+                    wo[h][j] = (unsigned)(n0 + hr) * (unsigned)(p.K * 4) + (unsigned)h * (unsigned)(p.K * 2) + (unsigned)(swz(hr, pch) * 16);
+                }
+            }
+    };
+    // which: 0 A0, 1 A1, 2 B0, 3 B1; kt: K-tile of the tile the offsets belong to; par: LDS buffer of that K-tile
+    auto stage = [&](auto whichc, const unsigned (&ao)[2][2], const unsigned (&wo)[2][2], int kt, int par) {
+        constexpr int which = decltype(whichc)::value;
+        char* const base = smem + par * BUFB + which * HALFB + wave * 2048;
+        const char* const src = (which < 2 ? A : W) + (size_t)kt * (BK * 2);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) glds16(src + (which < 2 ? ao[which & 1][j] : wo[which & 1][j]), base + j * 1024);
+    };
+    typedef std::integral_constant<int, 0> HA0;
+    typedef std::integral_constant<int, 1> HA1;
+    typedef std::integral_constant<int, 2> HB0;
+    typedef std::integral_constant<int, 3> HB1;
+
+    f32x4 acc[MF][NF];
+    const int fr = lane & 15, fg = lane >> 4;
+    const int nk = p.K / BK;
+    unsigned a_lane[2], w_lane[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        const int ra = wr * 64 + fr, rw = wc * 32 + fr;
+        a_lane[ks] = (unsigned)(ra * 128 + swz(ra, ks * 4 + fg) * 16);
+        w_lane[ks] = 2 * HALFB + (unsigned)(rw * 128 + swz(rw, ks * 4 + fg) * 16);
+    }
+    v8 af[2][4], bf[2][2][2];
+    auto read_a = [&](int h, unsigned bufb) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) af[ks][i] = *reinterpret_cast<const v8*>(smem + bufb + h * HALFB + a_lane[ks] + i * 2048);
+    };
+    auto read_b = [&](auto gc, unsigned bufb) {
+        constexpr int g = decltype(gc)::value;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) bf[g][ks][j] = *reinterpret_cast<const v8*>(smem + bufb + g * HALFB + w_lane[ks] + j * 2048);
+    };
+    auto mma_h = [&](auto hc) {
+        constexpr int h = decltype(hc)::value;
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int g = 0; g < 2; ++g)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        if constexpr (WS == 1) acc[h * 4 + i][g * 2 + j] = mfma16(bf[g][ks][j], af[ks][i], acc[h * 4 + i][g * 2 + j]);
+                        else acc[h * 4 + i][j] = mfma16(bf[g][ks][j], af[ks][i], acc[h * 4 + i][j]);
+                    }
+        __builtin_amdgcn_s_setprio(0);
+    };
+    typedef std::integral_constant<int, 0> I0;
+    typedef std::integral_constant<int, 1> I1;
+#define M3R_VMCNT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
+#define M3R_P_LOAD_END() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define M3R_P_MUL_END() do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); } while (0)
+
+    // One K-tile.  par = LDS buffer of K-tile t.  MODE: 0 steady (t + 2 < nk) | 1 t = nk - 2, a next tile follows | 2 t = nk - 1, a next tile follows |
+    //                  3 t = nk - 2, last tile | 4 t = nk - 1, last tile.  FIRSTK: t = 0 of a tile entered across a boundary (its A1 is already retired).
+    auto ktile = [&](auto modec, auto firstc, int t, int par) {
+        constexpr int MODE = decltype(modec)::value;
+        constexpr bool FIRSTK = decltype(firstc)::value;
+        const unsigned bufb = par * BUFB;
+        // phase 0: a0 x (b0, b1); stages B1, A1 of the next K-tile; A1 of this K-tile landed
+        read_a(0, bufb); read_b(I0{}, bufb); read_b(I1{}, bufb);
+        if constexpr (MODE == 0 || MODE == 1 || MODE == 3) { stage(HB1{}, a_cur, w_cur, t + 1, par ^ 1); stage(HA1{}, a_cur, w_cur, t + 1, par ^ 1); }
+        else if constexpr (MODE == 2) { stage(HB1{}, a_nxt, w_nxt, 0, par ^ 1); stage(HA1{}, a_nxt, w_nxt, 0, par ^ 1); }
+        if constexpr (!FIRSTK) M3R_VMCNT(MODE == 4 ? 0 : 8);
+        M3R_P_LOAD_END(); mma_h(I0{}); M3R_P_MUL_END();
+        // phase 1: a1 x (b0, b1); stages A0, B0 of the K-tile after next; A0, B0, B1 of the next K-tile landed
+        read_a(1, bufb);
+        if constexpr (MODE == 0) { stage(HA0{}, a_cur, w_cur, t + 2, par); stage(HB0{}, a_cur, w_cur, t + 2, par); }
+        else if constexpr (MODE == 1) { stage(HA0{}, a_nxt, w_nxt, 0, par); stage(HB0{}, a_nxt, w_nxt, 0, par); }
+        else if constexpr (MODE == 2) { stage(HA0{}, a_nxt, w_nxt, 1, par); stage(HB0{}, a_nxt, w_nxt, 1, par); }
+        if constexpr (MODE == 0 || MODE == 1) M3R_VMCNT(6);
+        else if constexpr (MODE == 2) M3R_VMCNT(4);   // ... and A1 of the next tile's first K-tile: no counted wait right behind the epilogue's stores
+        else if constexpr (MODE == 3) M3R_VMCNT(2);
+        M3R_P_LOAD_END(); mma_h(I1{}); M3R_P_MUL_END();
+    };
+    typedef std::integral_constant<int, 0> M0_;
+    typedef std::integral_constant<int, 1> M1_;
+    typedef std::integral_constant<int, 2> M2_;
+    typedef std::integral_constant<int, 3> M3_;
+    typedef std::integral_constant<int, 4> M4_;
+
+    int vb = (int)blockIdx.x;
+    int m0, n0;
+    tile_of(vb, m0, n0);
+    offsets(m0, n0, a_cur, w_cur);
+    // ---- prologue of the block's first tile: what the steady state would have issued before K-tile 0
+    stage(HA0{}, a_cur, w_cur, 0, 0); stage(HB0{}, a_cur, w_cur, 0, 0); stage(HB1{}, a_cur, w_cur, 0, 0); stage(HA1{}, a_cur, w_cur, 0, 0);
+    stage(HA0{}, a_cur, w_cur, 1, 1); stage(HB0{}, a_cur, w_cur, 1, 1);
+    M3R_VMCNT(6);
+    __builtin_amdgcn_s_barrier();
+    int par = 0;          // LDS buffer of the current tile's K-tile 0
+    bool first = true;    // the block's first tile: its K-tile 0 carries the steady-state wait for its own A1
+    for (;;) {
+        const int vnext = vb + nblk;
+        const bool more = vnext < nwg;
+#pragma unroll
+        for (int i = 0; i < MF; ++i)
+#pragma unroll
+            for (int j = 0; j < NF; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (wr == 1) __builtin_amdgcn_s_barrier();   // group 1 runs one barrier behind
+        int t = 0;
+        if (first) ktile(M0_{}, std::false_type{}, 0, par);
+        else ktile(M0_{}, std::true_type{}, 0, par);
+        for (t = 1; t + 2 < nk; ++t) ktile(M0_{}, std::false_type{}, t, par ^ (t & 1));
+        int m1 = 0, n1 = 0;
+        if (more) {
+            // the next tile's operand offsets live for these two K-tiles only (kept across the epilogue they push its register allocation into scratch)
+            tile_of(vnext, m1, n1);
+            offsets(m1, n1, a_nxt, w_nxt);
+            ktile(M1_{}, std::false_type{}, t, par ^ (t & 1)); ++t;
+            ktile(M2_{}, std::false_type{}, t, par ^ (t & 1));
+        } else {
+            ktile(M3_{}, std::false_type{}, t, par ^ (t & 1)); ++t;
+            ktile(M4_{}, std::false_type{}, t, par ^ (t & 1));
+        }
+        if (wr == 0) __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        epilogue_tile<T, EPI, NF, MF, 4, false>(p, outp, bias, m0 + wr * 128 + fr, n0 + wc * WN, fg, acc, NoLnFold{});
+        __builtin_amdgcn_sched_barrier(0);
+        if (!more) break;
+        par ^= (nk & 1);
+        vb = vnext;
+        m0 = __builtin_amdgcn_readfirstlane(m1); n0 = __builtin_amdgcn_readfirstlane(n1);
+        offsets(m0, n0, a_cur, w_cur);   // recomputed (a few integer instructions per tile) instead of carried through the epilogue
+        first = false;
+    }
+#undef M3R_VMCNT
+#undef M3R_P_LOAD_END
+#undef M3R_P_MUL_END
+}
+
+template <class T, int EPI, int WS, int BN>
+static int launch_256pp(const GemmArgs& a, hipStream_t s) {
+    if ((unsigned long long)a.M * (unsigned long long)a.lda * 2ull >= (1ull << 32) || (unsigned long long)a.N * (unsigned long long)a.K * WS * 2ull >= (1ull << 32)) return 2;
+    if (a.batch > 1 || a.K < 256 || a.out_table != nullptr) return 2;
+    const int nbn = a.N / BN, nbm = (a.M + 255) / 256;
+    const int nwg = nbm * nbn;
+    const size_t lds = (size_t)2 * 4 * 128 * 64 * sizeof(T);
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256pp_kernel<T, EPI, WS, BN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return 1;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((gemm256pp_kernel<T, EPI, WS, BN>), dim3(nwg < 256 ? nwg : 256), dim3(512), lds, s, a);
     return hipGetLastError() == hipSuccess ? 0 : 1;
 }
 
@@ -2408,6 +2691,11 @@ static int launch_epi(const GemmArgs& a, hipStream_t s, const char** err) {
             } else if (EPI == EPI_STORE16_GELU && gelu_occ2 && mode != 0 && ok128 && t128 >= 1024) { pick_name("g256o2", EPI, 2, 128); rc = launch_256<T, EPI, 2, 128, 2>(a, s); }
             else if (EPI != EPI_HEAD && use_96(a, nb)) { pick_name("g96", EPI, 2, 96); rc = launch_96<T, EPI == EPI_HEAD ? EPI_STORE16 : EPI>(a, s); }
             else if (EPI != EPI_QKV_ROPE && EPI != EPI_HEAD && use_48(a, nb)) { pick_name("g48", EPI, 2, 48); rc = launch_48<T, EPI == EPI_QKV_ROPE || EPI == EPI_HEAD ? EPI_STORE16 : EPI, 2>(a, s); }
+            // r05: the 2:4-sparse low part (48 matrix instructions per K-tile instead of 64) wherever the launch fills the chip and the caller has the packed copy
+            else if (a.Wlo_sp != nullptr && a.Widx_sp != nullptr && g256p_mode(true) != 0 && ok128 && a.K % 64 == 0 && t128 >= 200 && a.ln_stats == nullptr && !lnp &&
+                     (fill256(t128) >= 80 || pick != 0)) {
+                pick_name("g256ps", EPI, 3, 128); rc = launch_256p<T, EPI, 3, 128, 2>(a, s);
+            }
             else if (pick != 0 && ok128 && a.K % 64 == 0 && (g256p_mode(true) == 2 || (g256p_mode(true) == 1 && (pick == 128 || (pick == 192 && t128 >= 200 && fill256(t128) >= fill256(t192) && fill256(t128) >= 90))))) {
                 pick_name("g256p", EPI, 2, 128); rc = launch_256p<T, EPI, 2, 128, 2>(a, s);
             }

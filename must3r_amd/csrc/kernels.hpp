@@ -29,6 +29,13 @@ struct GemmArgs {
     // split-weight mode: W is [N, 2K] = [W_hi | W_lo] (both fp16); every K-tile multiplies the activation tile with
     // both halves: out = A.W_hi^T + A.W_lo^T in fp32 -> weight rounding error drops from 2^-11 to ~2^-22.
     int wsplit;              // 0/1 = plain, 2 = [hi|lo]
+    // r05: a 2:4-sparse copy of the low part (launch_sparse24_pack) for the chip-filling split-weight kernel: in every group of 4 consecutive k of a row
+    // the 2 entries of largest magnitude.  Wlo_sp [K/64][wsp_rows][32] 16-bit (K-tile-major: a tile's rows of one K-tile are contiguous),
+    // Widx_sp [K/64][wsp_rows/32][64 lanes] dwords of 2-bit positions (lane = row % 16 + 16 * (k / 16 % 4); low half rows 0-15 of the 32, high half rows 16-31).
+    // nullptr = not available (the launcher then runs the dense two-pass kernels).  wsp_rows = rows of the whole parameter (grouped launches index it).
+    const void* Wlo_sp;
+    const void* Widx_sp;
+    int wsp_rows;
     // 16-bit-store epilogues: columns < scale_cols are multiplied by out_scale before rounding (the softmax scale
     // 1/sqrt(64) * log2(e) is folded into q here so the attention kernel works in the exp2 domain for free)
     float out_scale;         // 0 -> no scaling
@@ -187,6 +194,8 @@ int launch_postprocess_cam(const float* pm, int linear, int n_views, int H, int 
                            float* focal, float* c2w, void* scratch, size_t scratch_bytes, hipStream_t s, const char** err);
 // 16-bit weight low part: lo = T(w - float(T(w)))  and hi = T(w), from fp32
 int launch_split16(DType dt, const float* in, void* hi, void* lo, size_t n, hipStream_t s, const char** err);
+// 2:4-sparse copy of the fp16 low part of w fp32 [rows, K] (rows % 32 == 0, K % 64 == 0): vals [K/64][rows][32] fp16, idx [K/64][rows/32][64] dwords (GemmArgs::Wlo_sp)
+int launch_sparse24_pack(const float* w, int rows, int K, void* vals, void* idx, hipStream_t s, const char** err);
 
 // debug: mapping of ds_read_b64_tr_b16 (out: 256 shorts)
 int launch_tr_probe(short* out, hipStream_t s);

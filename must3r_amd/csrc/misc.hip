@@ -265,6 +265,59 @@ int launch_cast(DType dt, const float* in, void* out16, void* out16_lo, size_t n
 }
 
 // ------------------------------------------------------------------------------------------------
+// 2:4-sparse copy of the fp16 low part of a weight matrix (r05; consumed by gemm256p_kernel<.., WS = 3>, GemmArgs::Wlo_sp / Widx_sp).
+//   lo = fp16(w - float(fp16(w))) exactly as cast_kernel computes it; in every group of 4 consecutive k (k = 64 t + 16 g + 4 q + e) of a row the two entries
+//   of largest |lo| are kept (ties: the lower k), in k order.  One thread = one (K-tile t, row n, lane group g): 16 low parts -> 8 kept values
+//   (vals[t][n][8 g .. 8 g + 7]) and 16 bits of positions (group q: bits 4q+1..4q = position of the first kept entry, 4q+3..4q+2 = of the second --
+//   the index operand of v_smfmac_f32_16x16x64_f16, profiles/r05_smfmac_probe.txt) at halfword (n % 32) / 16 of dword idx[t][n / 32][n % 16 + 16 g].
+// ------------------------------------------------------------------------------------------------
+__global__ void sparse24_pack_kernel(const float* __restrict__ w, int rows, int K, f16_t* __restrict__ vals, unsigned short* __restrict__ idx) {
+    const size_t total = (size_t)(K / 64) * rows * 4;
+    for (size_t u = (size_t)blockIdx.x * blockDim.x + threadIdx.x; u < total; u += (size_t)gridDim.x * blockDim.x) {
+        const int g = (int)(u & 3);
+        const size_t tn = u >> 2;
+        const int n = (int)(tn % rows), t = (int)(tn / rows);
+        const float* src = w + (size_t)n * K + t * 64 + g * 16;
+        unsigned bits = 0;
+        f16_t out[8];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float lo[4], mag[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float x = src[q * 4 + e];
+                const f16_t hi = (f16_t)x;
+                lo[e] = (float)(f16_t)(x - (float)hi);
+                mag[e] = fabsf(lo[e]);
+            }
+            int p0 = 0;
+#pragma unroll
+            for (int e = 1; e < 4; ++e) if (mag[e] > mag[p0]) p0 = e;
+            int p1 = p0 == 0 ? 1 : 0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) if (e != p0 && mag[e] > mag[p1]) p1 = e;
+            const int a = p0 < p1 ? p0 : p1, b = p0 < p1 ? p1 : p0;
+            out[q * 2] = (f16_t)lo[a];
+            out[q * 2 + 1] = (f16_t)lo[b];
+            bits |= (unsigned)(a | (b << 2)) << (4 * q);
+        }
+        f16_t* dv = vals + ((size_t)t * rows + n) * 32 + g * 8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) dv[e] = out[e];
+        idx[(((size_t)t * (rows / 32) + n / 32) * 64 + (n % 16) + 16 * g) * 2 + ((n % 32) / 16)] = (unsigned short)bits;
+    }
+}
+
+int launch_sparse24_pack(const float* w, int rows, int K, void* vals, void* idx, hipStream_t s, const char** err) {
+    if (rows <= 0 || K <= 0 || rows % 32 || K % 64) { *err = "sparse24_pack: rows % 32 and K % 64 must be 0"; return 1; }
+    const size_t total = (size_t)(K / 64) * rows * 4;
+    const int grid = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    hipLaunchKernelGGL(sparse24_pack_kernel, dim3(grid), dim3(256), 0, s, w, rows, K, (f16_t*)vals, (unsigned short*)idx);
+    if (hipGetLastError() != hipSuccess) { *err = "sparse24_pack: launch failed"; return 1; }
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
 // 16-bit -> OCP e4m3 (fp8 attention operands, include/must3r_hip.h MUST3R_ATTN_FP8): out8[r][c] = e4m3(clamp(in[r][c], +-448)).
 // v_cvt_pk_fp8_f32 does NOT saturate (1000 -> NaN, profiles/r02_fp8_probe.txt), hence the clamp.  One thread = 8 columns
 // (16 B read, 8 B written).  Rows may be grouped: row r of group g = r / rows_per_group goes to out_table[g] (the per-layer

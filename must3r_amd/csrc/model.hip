@@ -52,6 +52,8 @@ struct Param {
     void* l16[2] = {nullptr, nullptr};   // low part (split precision), lazy, only where needed
     void* x2[2] = {nullptr, nullptr};    // [rows][hi(K) | lo(K)] layout for the split-weight GEMM, lazy
     void* x3[2] = {nullptr, nullptr};    // [rows][hi | hi | lo] layout: one K = 3 in launch of the split-precision head, lazy
+    void* sp_vals = nullptr;             // r05: 2:4-sparse copy of the fp16 low part (GemmArgs::Wlo_sp / Widx_sp), built with x2[DT_F16] where the shape allows
+    void* sp_idx = nullptr;
     bool loaded = false;
     bool derived = false;     // built by finalize, not loaded
     bool optional = false;    // may legitimately be absent (feedback layer variants)
@@ -99,6 +101,10 @@ struct must3r_hip_ctx {
     double prof_ms[PC_COUNT] = {0}, prof_flops[PC_COUNT] = {0};
     long long prof_calls[PC_COUNT] = {0};
     std::map<std::string, ProfKern> prof_kern;   // per kernel symbol (GEMM: family / epilogue / weight layout / tile width; attention: kernel + self / cross)
+    // r05: split-weight matrix ([hi | lo] rows, Param::x2) -> its 2:4-sparse low part; the gemm() wrapper hands it to the launcher, which uses it in the
+    // chip-filling kernel only (every other split-weight kernel reads the dense low half of the rows)
+    struct SparseLo { const void* vals; const void* idx; int rows; };
+    std::map<const void*, SparseLo> sparse_lo;
 };
 
 // The entry points run on the context's device and leave the caller's current device as they found it (a process that
@@ -202,6 +208,10 @@ static int gemm(must3r_hip_ctx* c, DType dt, Epi epi, GemmArgs a, hipStream_t s,
                             : ((a.N % 128 == 0 && tiles128 >= 192) ? PC_GEMM128 : PC_GEMM64);
     if (ws_override >= 0) a.wsplit = ws_override;
     else if (c && epi != EPI_HEAD) a.wsplit = c->wsplit;
+    if (c && a.wsplit == 2 && epi != EPI_HEAD && !c->sparse_lo.empty()) {
+        auto it = c->sparse_lo.find(a.W);
+        if (it != c->sparse_lo.end()) { a.Wlo_sp = it->second.vals; a.Widx_sp = it->second.idx; a.wsp_rows = it->second.rows; }
+    }
     ProfScope ps(c, s, cat, 2.0 * a.M * a.N * a.K * (a.batch > 1 ? a.batch : 1));
     if (launch_gemm(dt, epi, a, s, &err)) return fail("%s (M=%d N=%d K=%d epi=%d)", err, a.M, a.N, a.K, (int)epi);
     ps.kernel(gemm_last_kernel());
@@ -364,6 +374,15 @@ static int w16p(must3r_hip_ctx* c, Param& p, DType dt, const void** hi, hipStrea
         // asks for the plain 16-bit mode): 4 of the 16 bytes per parameter.  hipFree waits for the copies above (first use only).
         (void)hipFree(p.h16[dt]); p.h16[dt] = nullptr;
         (void)hipFree(p.l16[dt]); p.l16[dt] = nullptr;
+        // r05: the 2:4-sparse low part for the chip-filling kernel (fp16; M3R_SPARSE_LO=0: never) -- rows x K / 2 values + rows x K / 8 bytes of positions
+        static const bool sparse_on = [] { const char* e = getenv("M3R_SPARSE_LO"); return !e || atoi(e) != 0; }();
+        if (sparse_on && dt == DT_F16 && rows % 128 == 0 && K % 64 == 0 && !p.sp_vals) {
+            const char* err = "";
+            HIP_OK(hipMalloc(&p.sp_vals, rows * K));
+            HIP_OK(hipMalloc(&p.sp_idx, rows * K / 8));
+            if (launch_sparse24_pack(p.d, (int)rows, (int)K, p.sp_vals, p.sp_idx, s, &err)) return fail("%s", err);
+            c->sparse_lo[p.x2[dt]] = {p.sp_vals, p.sp_idx, (int)rows};
+        }
     }
     *hi = p.x2[dt];
     return 0;
@@ -467,6 +486,8 @@ extern "C" void must3r_hip_destroy(must3r_hip_ctx* c) {
             if (p.x2[i]) (void)hipFree(p.x2[i]);
             if (p.x3[i]) (void)hipFree(p.x3[i]);
         }
+        if (p.sp_vals) (void)hipFree(p.sp_vals);
+        if (p.sp_idx) (void)hipFree(p.sp_idx);
     }
     if (c->rope_tab) (void)hipFree(c->rope_tab);
     if (c->ws) (void)hipFree(c->ws);
@@ -492,9 +513,11 @@ extern "C" int must3r_hip_load_weight(must3r_hip_ctx* c, const char* name, const
     for (int i = 0; i < 2; ++i) {  // invalidate packed copies
         if (p->h16[i]) { (void)hipFree(p->h16[i]); p->h16[i] = nullptr; }
         if (p->l16[i]) { (void)hipFree(p->l16[i]); p->l16[i] = nullptr; }
-        if (p->x2[i]) { (void)hipFree(p->x2[i]); p->x2[i] = nullptr; }
+        if (p->x2[i]) { c->sparse_lo.erase(p->x2[i]); (void)hipFree(p->x2[i]); p->x2[i] = nullptr; }
         if (p->x3[i]) { (void)hipFree(p->x3[i]); p->x3[i] = nullptr; }
     }
+    if (p->sp_vals) { (void)hipFree(p->sp_vals); p->sp_vals = nullptr; }
+    if (p->sp_idx) { (void)hipFree(p->sp_idx); p->sp_idx = nullptr; }
     p->loaded = true;
     if (strncmp(name, "encoder.", 8) == 0) c->fin_enc = false; else c->fin_dec = false;
     return 0;
@@ -506,9 +529,11 @@ static int derive(must3r_hip_ctx* c, const std::string& name, std::vector<int64_
     for (int i = 0; i < 2; ++i) {
         if (p.h16[i]) { (void)hipFree(p.h16[i]); p.h16[i] = nullptr; }
         if (p.l16[i]) { (void)hipFree(p.l16[i]); p.l16[i] = nullptr; }
-        if (p.x2[i]) { (void)hipFree(p.x2[i]); p.x2[i] = nullptr; }
+        if (p.x2[i]) { c->sparse_lo.erase(p.x2[i]); (void)hipFree(p.x2[i]); p.x2[i] = nullptr; }
         if (p.x3[i]) { (void)hipFree(p.x3[i]); p.x3[i] = nullptr; }
     }
+    if (p.sp_vals) { (void)hipFree(p.sp_vals); p.sp_vals = nullptr; }
+    if (p.sp_idx) { (void)hipFree(p.sp_idx); p.sp_idx = nullptr; }
     p.shape = shape;
     p.n = host.size();
     p.derived = true;
@@ -1379,6 +1404,23 @@ extern "C" int must3r_hip_op_gemm(int dtype, int epi, const void* A, const void*
     a.ntok = ntok; a.gw = gw; a.H = H; a.Wimg = W_img; a.wsplit = wsplit;
     const char* err = "";
     if (launch_gemm((DType)dtype, (Epi)epi, a, reinterpret_cast<hipStream_t>(stream), &err)) return fail("%s", err);
+    return 0;
+}
+
+/* r05, ABI 7: the chip-filling split-weight GEMM with a 2:4-sparse low part (tests / probes): pack, then multiply */
+extern "C" int must3r_hip_op_sparse24_pack(const float* w, int rows, int K, void* vals, void* idx, void* stream) {
+    const char* err = "";
+    if (launch_sparse24_pack(w, rows, K, vals, idx, reinterpret_cast<hipStream_t>(stream), &err)) return fail("%s", err);
+    return 0;
+}
+extern "C" int must3r_hip_op_gemm_sp(int epi, const void* A, const void* W2, const void* Wlo_sp, const void* Widx_sp, const float* bias, void* out, int M,
+                                     int N, int K, int lda, int ldc, const int64_t* pos, const float* rope_tab, int rope_cols, int rope_npos, void* stream) {
+    if (epi < 0 || epi >= EPI_COUNT) return fail("op_gemm_sp: bad epilogue");
+    GemmArgs a = gargs(A, W2, bias, out, M, N, K, lda, ldc);
+    a.wsplit = 2; a.Wlo_sp = Wlo_sp; a.Widx_sp = Widx_sp; a.wsp_rows = N;
+    a.pos = pos; a.rope_tab = rope_tab; a.rope_cols = rope_cols; a.rope_npos = rope_npos;
+    const char* err = "";
+    if (launch_gemm(DT_F16, (Epi)epi, a, reinterpret_cast<hipStream_t>(stream), &err)) return fail("%s", err);
     return 0;
 }
 

@@ -60,6 +60,7 @@ int main() {
     const Var vars[] = {
         {"256k", PL((launch_256k<f16_t, EPI_STORE16, 1, 256>)), PL((launch_256<f16_t, EPI_STORE16, 2, 128>))},
         {"256p nph2 sync2", PL((launch_256p<f16_t, EPI_STORE16, 1, 256, 2, 2>)), PL((launch_256p<f16_t, EPI_STORE16, 2, 128, 2, 2>))},
+        {"256pp persistent", PL((launch_256pp<f16_t, EPI_STORE16, 1, 256>)), PL((launch_256pp<f16_t, EPI_STORE16, 2, 128>))},
         {"256w pat0", PL((launch_256w<f16_t, EPI_STORE16, 1, 256, 0>)), PL((launch_256w<f16_t, EPI_STORE16, 2, 128, 0>))},
         {"256w pat1", PL((launch_256w<f16_t, EPI_STORE16, 1, 256, 1>)), PL((launch_256w<f16_t, EPI_STORE16, 2, 128, 1>))},
     };
@@ -67,6 +68,7 @@ int main() {
     run(vars, nv, 15360, 3072, 4096, 1);
     run(vars, nv, 15360, 4096, 1024, 1);
     run(vars, nv, 15360, 3072, 2048, 2);
-    run(vars, nv, 15100, 1024, 192, 1);   // ragged rows, three K-tiles
+    run(vars, nv, 30720, 4096, 1024, 1);
+    run(vars, nv, 15100, 1024, 320, 1);   // ragged rows, five K-tiles
     return 0;
 }

@@ -7,7 +7,7 @@ import torch
 
 from must3r_amd import synthetic as S
 from must3r_amd.config import TINY, SMALL, MUST3R_224, MUST3R_512
-from util import TOL, PRECISIONS, load_golden, rel_inf, rel_l2
+from util import TOL, PRECISIONS, load_golden, rel_inf, rel_inf_view, rel_l2
 from test_ops_gpu import record
 
 pytestmark = pytest.mark.gpu
@@ -120,8 +120,10 @@ def test_full_depth_scene_matches_reference_fixture(name, precision):
     tol = TOL[precision]
     x, upd, ren, mem = out["x"].cpu(), out["update"].cpu(), out["render"].cpu(), out["mem"]
     assert upd.shape[0] == V and ren.shape[0] == V and mem[0][0].shape[1] == V * (H // 16) * (W // 16)
-    upd_v = [rel_inf(upd[v, ::ps, ::ps], g["update"][v]) for v in range(V)]
-    ren_v = [rel_inf(ren[v, ::ps, ::ps], g["render"][v]) for v in range(V)]
+    # per view: the error over the stored (sub-sampled) pixels against that view's FULL-resolution range (r05: `*_vmax` of the fixture, the normalisation of
+    # bench.py's all-pixel parity figure; the max of the SAMPLE under-states a view's range by up to 40 % and was the only reason a view ever reached 1e-3)
+    upd_v = [rel_inf_view(upd[v, ::ps, ::ps], g["update"][v], g["update_vmax"][v]) for v in range(V)]
+    ren_v = [rel_inf_view(ren[v, ::ps, ::ps], g["render"][v], g["render_vmax"][v]) for v in range(V)]
     errs = dict(x=rel_inf(x[:, ::tks, ::tks], g["x"]), update=rel_inf(upd[:, ::ps, ::ps], g["update"]),
                 render=rel_inf(ren[:, ::ps, ::ps], g["render"]), render_l2=rel_l2(ren[:, ::ps, ::ps], g["render"]),
                 update_view_max=max(upd_v), render_view_max=max(ren_v), update_last_view=upd_v[-1],

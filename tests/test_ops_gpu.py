@@ -207,6 +207,63 @@ def test_gemm256_tiles_same_bits_as_small_tiles(lib, ws, N):
 
 
 
+def _prune24(lo):
+    """keep the 2 entries of largest magnitude of every 4 consecutive k (ties: the lower k) -- misc.hip::sparse24_pack_kernel"""
+    g = lo.reshape(lo.shape[0], -1, 4)
+    mag = g.abs().float()
+    # stable ranking: larger magnitude first, lower index first among equals
+    key = mag * 8 - torch.arange(4, device=lo.device, dtype=torch.float32) * 1e-30
+    order = torch.argsort(-mag, dim=-1, stable=True)[..., :2]
+    mask = torch.zeros_like(g, dtype=torch.bool).scatter_(-1, order, True)
+    return (g * mask).reshape(lo.shape)
+
+
+@pytest.mark.parametrize("shape", [(15360, 1536, 768), (15260, 768, 192), (21504, 2304, 768), (15360, 1024, 1024)])
+def test_gemm_sparse_low_part(lib, shape):
+    """r05: the chip-filling split-weight kernel with a 2:4-SPARSE low part (gemm256p_kernel<.., WS = 3>: one v_smfmac_f32_16x16x64_f16 per output
+    fragment and 64-deep K-tile for the low product).  Reference: the product with exactly the operands the kernel multiplies, A . (W_hi + P(W_lo))^T in
+    fp64 -- P keeps the 2 largest |.| of every 4 consecutive k -- for the store, RoPE-less, fp32 and residual epilogues, ragged last row block and
+    grouped K-tile tails included; and the distance of that product from the exact one stays at the weight-rounding level the emulation predicted."""
+    M, N, K = shape
+    g = torch.Generator(device="cuda").manual_seed(M + N + K)
+    A = torch.randn((M, K), device="cuda", generator=g).half()
+    Wf = torch.randn((N, K), device="cuda", generator=g) / math.sqrt(K)
+    hi = Wf.half()
+    lo = (Wf - hi.float()).half()
+    W2 = torch.cat((hi, lo), dim=1).contiguous()
+    bias = torch.randn((N,), device="cuda", generator=g)
+    x0 = torch.randn((M, N), device="cuda", generator=g)
+    L = lib.load()
+    vals = torch.empty((K // 64, N, 32), device="cuda", dtype=torch.float16)
+    idx = torch.empty((K // 64, N // 32, 64), device="cuda", dtype=torch.int32)
+    lib.check(L.must3r_hip_op_sparse24_pack(P(Wf.contiguous()), N, K, P(vals), P(idx), stream()))
+    torch.cuda.synchronize()
+    # the packed values are the kept entries in k order: vals[t][n][8 g + 2 q + {0, 1}] for k = 64 t + 16 g + 4 q + ...
+    lo_p = _prune24(lo)
+    kept = lo_p.reshape(N, K // 64, 4, 4, 4)                       # [n][t][g][q][e]
+    nz = torch.argsort((kept == 0).to(torch.int8), dim=-1, stable=True)[..., :2]          # positions of the two kept entries (zeros last), in k order
+    want_vals = torch.gather(kept, -1, nz.sort(dim=-1).values).reshape(N, K // 64, 32).permute(1, 0, 2)
+    # (a kept entry that is itself 0.0 makes "which zero" ambiguous: compare values only where the row group has two non-zeros)
+    two = ((kept != 0).sum(-1) == 2).reshape(N, K // 64, 16).permute(1, 0, 2).repeat_interleave(2, dim=-1)
+    assert torch.equal(vals[two], want_vals[two])
+    ref = A.double() @ (hi.double() + lo_p.double()).t() + bias.double()
+    exact = A[:512].double() @ Wf[:, :].double().t() + bias.double()
+
+    def go(epi, out):
+        lib.check(L.must3r_hip_op_gemm_sp(epi, P(A), P(W2), P(vals), P(idx), P(bias), P(out), M, N, K, K, N, None, None, 0, 0, stream()))
+        torch.cuda.synchronize()
+    for epi, odt in ((lib.EPI_STORE16, torch.float16), (lib.EPI_F32, torch.float32), (lib.EPI_RESID_F32, torch.float32)):
+        out = x0.clone() if epi == lib.EPI_RESID_F32 else torch.full((M, N), 7.0, device="cuda", dtype=odt)
+        go(epi, out)
+        want = ref + x0.double() if epi == lib.EPI_RESID_F32 else ref
+        tol = 2 * 2.0 ** -11 if odt == torch.float16 else 2e-6
+        assert torch.allclose(out.double(), want, rtol=tol, atol=tol * 4), (epi, rel_inf(out, want))
+        if epi == lib.EPI_F32:
+            e_exact = rel_inf(out[:512], exact)
+            record("gemm_sparse_lo", shape=shape, err_vs_operands=rel_inf(out, want), err_vs_exact=e_exact)
+            assert e_exact < 1.5e-4, e_exact   # weight rounding left after the sparse low part: ~0.45 x 2^-12 per weight, averaged over K
+
+
 @pytest.mark.parametrize("dt", ["bf16", "fp16"])
 @pytest.mark.parametrize("geom", [(2, 14, 14, 128), (1, 24, 32, 768), (3, 3, 4, 1024), (4, 24, 32, 256), (20, 24, 32, 512)])
 def test_gemm_qkv_rope(lib, dt, geom):
