@@ -1527,6 +1527,222 @@ static int launch_256p(const GemmArgs& a, hipStream_t s) {
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// gemm256s_kernel (r05): split weights with a 2:4-sparse low part on 256 x 256 tiles -- gemm256p_kernel's two-phase K loop with FIVE half-tiles per K-tile.
+//   Why another tile: with the sparse low part a 256 x 128 tile (gemm256p_kernel<.., WS = 3>) issues 24 matrix instructions per phase (~410 cycles) against a
+//   load interval of ~500-600 (its 15 fragment reads, 4 DMA pieces and their waits): the K-tile takes the ~2600 cycles of the dense form and only 1.7 % of the
+//   step came back (profiles/r05_sparse_lo_ab.txt).  256 columns double the matrix work per staged byte: 48 instructions per phase (32 dense hi + 16 sparse lo).
+//   LDS per K-tile: A 32 KB + W_hi 32 KB + kept W_lo values 16 KB = 80 KB, two buffers = ALL 160 KB of the CU -- the 2-bit positions (2 dwords per lane and
+//   K-tile) therefore come straight from L2 into registers (inline-asm loads on the same in-order vmcnt queue as the DMA pieces, issued a K-tile ahead).
+//   Half-tiles: A0 A1 (rows, as gemm256p) | H0 H1 (hi weight rows of every wave's column sub-tile g) | LO (the kept low values of all 256 weight rows, 64 B each).
+//   Schedule per K-tile t (lag-1 restaging as gemm256p; every wave issues 2 pieces per half-tile):
+//     phase 0: read a0, h0, h1, lo | stage H1, LO, A1 of t+1 | vmcnt(6): A1(t) and the positions of t landed | 48 matrix instructions
+//     phase 1: read a1            | stage A0, H0 of t+2, load the positions of t+1 | vmcnt(8): H1, LO, A0, H0 of t+1 landed | 48 matrix instructions
+// Numerics: those of gemm256p_kernel<.., WS = 3> (hi products in k order, then the sparse low product of the K-tile): identical bits between the two.
+template <class T, int EPI>
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) gemm256s_kernel(const GemmArgs p) {
+    static_assert(sizeof(T) == 2 && !__is_same(T, bf16_t), "fp16 only");
+    typedef typename Vec<T>::v8 v8;
+    typedef __attribute__((ext_vector_type(16))) _Float16 f16x16;
+    constexpr int BM = 256, BN = 256, BK = 64;
+    constexpr int WN = 64, MF = 8, NF = 4;
+    constexpr unsigned HALFB = 128 * BK * 2;               // 16 KB
+    constexpr unsigned BUFB = 5 * HALFB;                   // A0 A1 H0 H1 LO
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+
+    const int nbn = p.N / BN;
+    const int nbm = (p.M + BM - 1) / BM;
+    const int nwg = nbm * nbn;
+    int bid = blockIdx.x;
+    {
+        const int xcd = bid & 7, slot = bid >> 3;
+        const int q = nwg >> 3, r = nwg & 7;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+    }
+    constexpr int GM = 4;
+    const int tpg = GM * nbn;
+    const int gidx = bid / tpg;
+    const int gfirst = gidx * GM;
+    const int gsz = (nbm - gfirst < GM) ? nbm - gfirst : GM;
+    const int gin = bid - gidx * tpg;
+    const int m0 = (gfirst + gin % gsz) * BM;
+    const int n0 = (gin / gsz) * BN;
+
+    const int grp = blockIdx.y;
+    const T* __restrict__ A = reinterpret_cast<const T*>(p.A) + (size_t)grp * p.strideA;
+    const int wgrp = p.wdiv > 1 ? grp / p.wdiv : grp;
+    const T* __restrict__ W = reinterpret_cast<const T*>(p.W) + (size_t)wgrp * p.strideW;
+    const float* __restrict__ bias = p.bias ? p.bias + (size_t)wgrp * p.strideB : nullptr;
+    void* const outp = p.out_table ? p.out_table[grp] : p.out;
+    const int sp_row0 = (int)((size_t)wgrp * (size_t)(p.strideW / (2 * (long long)p.K)));
+
+    // ---- staging sources: pieces 2 wave, 2 wave + 1 of every half-tile
+    const int srow = lane >> 3, pch = lane & 7;
+    const T* a_src[2][2];
+    const T* h_src[2][2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int hr = (wave * 2 + j) * 8 + srow;
+            int gr = m0 + (hr >> 6) * 128 + h * 64 + (hr & 63);
+            gr = gr < p.M ? gr : p.M - 1;
+            a_src[h][j] = A + (size_t)gr * p.lda + swz(hr, pch) * 8;
+            const int col = (hr >> 5) * 64 + h * 32 + (hr & 31);
+            h_src[h][j] = W + (size_t)(n0 + col) * (size_t)(p.K * 2) + swz(hr, pch) * 8;
+        }
+    const char* lo_src[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int r = (wave * 2 + j) * 16 + (lane >> 2);
+        lo_src[j] = reinterpret_cast<const char*>(p.Wlo_sp) + ((size_t)(sp_row0 + n0 + r)) * 64 + swz32(r, lane & 3) * 16;
+    }
+    const size_t lo_kstride = (size_t)p.wsp_rows * 64;
+    const size_t ix_kstride = (size_t)(p.wsp_rows / 32) * 256;
+    const char* const ix_base = reinterpret_cast<const char*>(p.Widx_sp) + ((size_t)((sp_row0 + n0) / 32 + 2 * wc)) * 256;   // this wave's two 32-row blocks
+    const unsigned ix_lane = (unsigned)(lane * 4);
+
+    // which: 0 A0, 1 A1, 2 H0, 3 H1, 4 LO
+    auto stage = [&](auto whichc, int kt) {
+        constexpr int which = decltype(whichc)::value;
+        char* const base = smem + (kt & 1) * BUFB + which * HALFB + wave * 2048;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            if constexpr (which == 4) glds16(lo_src[j] + (size_t)kt * lo_kstride, base + j * 1024);
+            else glds16((which < 2 ? a_src[which & 1][j] : h_src[which & 1][j]) + (size_t)kt * BK, base + j * 1024);
+        }
+    };
+    typedef std::integral_constant<int, 0> HA0;
+    typedef std::integral_constant<int, 1> HA1;
+    typedef std::integral_constant<int, 2> HH0;
+    typedef std::integral_constant<int, 3> HH1;
+    typedef std::integral_constant<int, 4> HLO;
+
+    f32x4 acc[MF][NF];
+#pragma unroll
+    for (int i = 0; i < MF; ++i)
+#pragma unroll
+        for (int j = 0; j < NF; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int fr = lane & 15, fg = lane >> 4;
+    const int nk = p.K / BK;
+    unsigned a_lane[2], w_lane[2], lo_lane;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        const int ra = wr * 64 + fr, rw = wc * 32 + fr;
+        a_lane[ks] = (unsigned)(ra * 128 + swz(ra, ks * 4 + fg) * 16);
+        w_lane[ks] = 2 * HALFB + (unsigned)(rw * 128 + swz(rw, ks * 4 + fg) * 16);
+    }
+    {
+        const int rl = wc * 64 + fr;
+        lo_lane = 4 * HALFB + (unsigned)(rl * 64 + swz32(rl, fg) * 16);
+    }
+    v8 af[2][4], bh[2][2][2], bl[4];
+    int ix_nxt[2], ix_cur[2] = {0, 0};
+    auto read_a = [&](int h, unsigned bufb) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) af[ks][i] = *reinterpret_cast<const v8*>(smem + bufb + h * HALFB + a_lane[ks] + i * 2048);
+    };
+    auto read_w = [&](unsigned bufb) {
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) bh[g][ks][j] = *reinterpret_cast<const v8*>(smem + bufb + g * HALFB + w_lane[ks] + j * 2048);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bl[j] = *reinterpret_cast<const v8*>(smem + bufb + lo_lane + j * 1024);
+    };
+    // the positions of K-tile kt: two dwords per lane, straight from L2 (scalar base + 32-bit lane offset); their registers are unprotected until the counted
+    // wait that covers them (the volatile statements below keep their order: load ... wait ... move)
+    auto load_ix = [&](int kt) {
+        const char* const b0 = ix_base + (size_t)kt * ix_kstride;
+        asm volatile("global_load_dword %0, %2, %3\n\tglobal_load_dword %1, %2, %3 offset:256" : "=&v"(ix_nxt[0]), "=&v"(ix_nxt[1]) : "v"(ix_lane), "s"(b0) : "memory");
+    };
+    auto take_ix = [&]() {
+        asm volatile("v_mov_b32 %0, %2\n\tv_mov_b32 %1, %3" : "=v"(ix_cur[0]), "=v"(ix_cur[1]) : "v"(ix_nxt[0]), "v"(ix_nxt[1]));
+    };
+    auto mma_h = [&](auto hc) {
+        constexpr int h = decltype(hc)::value;
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int g = 0; g < 2; ++g)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[h * 4 + i][g * 2 + j] = mfma16(bh[g][ks][j], af[ks][i], acc[h * 4 + i][g * 2 + j]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const f16x16 x2k = __builtin_shufflevector(af[0][i], af[1][i], 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
+            acc[h * 4 + i][0] = __builtin_amdgcn_smfmac_f32_16x16x64_f16(bl[0], x2k, acc[h * 4 + i][0], ix_cur[0], 0, 0);
+            acc[h * 4 + i][1] = __builtin_amdgcn_smfmac_f32_16x16x64_f16(bl[1], x2k, acc[h * 4 + i][1], ix_cur[0], 0, 1);
+            acc[h * 4 + i][2] = __builtin_amdgcn_smfmac_f32_16x16x64_f16(bl[2], x2k, acc[h * 4 + i][2], ix_cur[1], 0, 0);
+            acc[h * 4 + i][3] = __builtin_amdgcn_smfmac_f32_16x16x64_f16(bl[3], x2k, acc[h * 4 + i][3], ix_cur[1], 0, 1);
+        }
+        __builtin_amdgcn_s_setprio(0);
+    };
+    typedef std::integral_constant<int, 0> I0;
+    typedef std::integral_constant<int, 1> I1;
+#define M3R_VMCNT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
+#define M3R_P_LOAD_END() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define M3R_P_MUL_END() do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); } while (0)
+
+    // ---- prologue: what the steady state would have issued before K-tile 0 (in its order)
+    stage(HA0{}, 0); stage(HH0{}, 0); stage(HH1{}, 0); stage(HLO{}, 0); stage(HA1{}, 0);
+    if (nk > 1) { stage(HA0{}, 1); stage(HH0{}, 1); load_ix(0); M3R_VMCNT(8); }
+    else { load_ix(0); M3R_VMCNT(4); }
+    __builtin_amdgcn_s_barrier();
+    if (wr == 1) __builtin_amdgcn_s_barrier();   // group 1 runs one barrier behind
+
+    auto ktile = [&](auto remc, int t) {
+        constexpr int REM = decltype(remc)::value;   // min(2, K-tiles behind this one)
+        const unsigned bufb = (t & 1) * BUFB;
+        // phase 0
+        read_a(0, bufb); read_w(bufb);
+        if constexpr (REM >= 1) { stage(HH1{}, t + 1); stage(HLO{}, t + 1); stage(HA1{}, t + 1); }
+        M3R_VMCNT(REM >= 1 ? 6 : 0);
+        take_ix();
+        M3R_P_LOAD_END(); mma_h(I0{}); M3R_P_MUL_END();
+        // phase 1
+        read_a(1, bufb);
+        if constexpr (REM >= 2) { stage(HA0{}, t + 2); stage(HH0{}, t + 2); }
+        if constexpr (REM >= 1) { load_ix(t + 1); M3R_VMCNT(REM == 2 ? 8 : 4); }
+        M3R_P_LOAD_END(); mma_h(I1{}); M3R_P_MUL_END();
+    };
+    int t = 0;
+    for (; t + 2 < nk; ++t) ktile(std::integral_constant<int, 2>{}, t);
+    if (t + 1 < nk) { ktile(std::integral_constant<int, 1>{}, t); ++t; }
+    ktile(std::integral_constant<int, 0>{}, t);
+    if (wr == 0) __builtin_amdgcn_s_barrier();
+#undef M3R_VMCNT
+#undef M3R_P_LOAD_END
+#undef M3R_P_MUL_END
+
+    epilogue_tile<T, EPI, NF, MF, 4, false>(p, outp, bias, m0 + wr * 128 + fr, n0 + wc * WN, fg, acc, NoLnFold{});
+}
+
+template <class T, int EPI>
+static int launch_256s(const GemmArgs& a, hipStream_t s) {
+    const int nbn = a.N / 256, nbm = (a.M + 255) / 256;
+    const size_t lds = (size_t)2 * 5 * 128 * 64 * sizeof(T);   // 163840 B: the CU's whole LDS
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256s_kernel<T, EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return 1;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((gemm256s_kernel<T, EPI>), dim3(nbm * nbn, a.batch > 1 ? a.batch : 1), dim3(512), lds, s, a);
+    return hipGetLastError() == hipSuccess ? 0 : 1;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // gemm256pp_kernel (r05): gemm256p_kernel's K loop (two phases per K-tile, two barriers per phase) as a PERSISTENT tile loop: 256 blocks, block b
 // works through tiles b, b + 256, ... (the XCD-aware order of the other kernels applied to that virtual block id: b + 256 k runs on the XCD of b).
 //   Why: a 256 x 256 tile of a K = 768..1024 GEMM is a ~25 us K loop inside ~32 us of block life -- dispatch of the next block, its address set-up, the
@@ -2694,7 +2910,10 @@ static int launch_epi(const GemmArgs& a, hipStream_t s, const char** err) {
             // r05: the 2:4-sparse low part (48 matrix instructions per K-tile instead of 64) wherever the launch fills the chip and the caller has the packed copy
             else if (a.Wlo_sp != nullptr && a.Widx_sp != nullptr && g256p_mode(true) != 0 && ok128 && a.K % 64 == 0 && t128 >= 200 && a.ln_stats == nullptr && !lnp &&
                      (fill256(t128) >= 80 || pick != 0)) {
-                pick_name("g256ps", EPI, 3, 128); rc = launch_256p<T, EPI, 3, 128, 2>(a, s);
+                // 256 x 256 sparse tiles (48 matrix instructions per phase) where they fill their rounds about as well as the 256 x 128 ones (24 per phase, load-bound)
+                static const int s256 = [] { const char* e = getenv("M3R_SPARSE_256"); return e ? atoi(e) : 1; }();
+                if (s256 && ok256 && a.K % 64 == 0 && t256 >= 200 && fill256(t256) + 12 >= fill256(t128)) { pick_name("g256s", EPI, 3, 256); rc = launch_256s<T, EPI>(a, s); }
+                else { pick_name("g256ps", EPI, 3, 128); rc = launch_256p<T, EPI, 3, 128, 2>(a, s); }
             }
             else if (pick != 0 && ok128 && a.K % 64 == 0 && (g256p_mode(true) == 2 || (g256p_mode(true) == 1 && (pick == 128 || (pick == 192 && t128 >= 200 && fill256(t128) >= fill256(t192) && fill256(t128) >= 90))))) {
                 pick_name("g256p", EPI, 2, 128); rc = launch_256p<T, EPI, 2, 128, 2>(a, s);
