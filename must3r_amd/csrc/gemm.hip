@@ -1527,6 +1527,156 @@ static int launch_256p(const GemmArgs& a, hipStream_t s) {
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// gemm256n_kernel (r05): plain weights, 256 x 256 tile, ONE phase per K-tile: the two wave groups alternate between a load interval (all 24 fragment reads of a
+// K-tile + the 8 DMA pieces of the next one) and a multiply interval of 64 MFMAs -- half the hand-overs of gemm256p_kernel's two phases per K-tile (each costs
+// ~135 cycles with the matrix pipe empty, profiles/r05_gemm256p_trace.txt) and multiply intervals twice as long as the load intervals need.
+//   Two 64 KB buffers are enough although a K-tile is read and its buffer restaged within one phase, because the groups wait at different points:
+//     group 0 (load interval of K-tile t between barriers #2t-1 and #2t):  stage t+1, read t | #2t | 64 MFMAs, vmcnt(0) | #2t+1
+//     group 1 (one barrier behind):                                       stage t+1, read t, vmcnt(0) | #2t+1 | 64 MFMAs | #2t+2
+//   RAW  K-tile t+1 is read by group 0 after #2t+1: group 0 waited for its pieces at the end of its multiply interval (issued a whole interval earlier), group 1
+//        at the end of its load interval (issued at its start; the interval lasts as long as group 0's 64 MFMAs, ~1100 cycles).
+//   WAR  the buffer of K-tile t+1 held K-tile t-1, read by both groups one phase earlier and retired (lgkmcnt 0) in front of the barriers that end those intervals.
+// Same accumulation order per output as every other tile shape: identical bits.
+template <class T, int EPI>
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) gemm256n_kernel(const GemmArgs p) {
+    typedef typename Vec<T>::v8 v8;
+    constexpr int BM = 256, BN = 256, BK = 64;
+    constexpr int WN = 64, MF = 8, NF = 4;
+    constexpr unsigned BUFB = 512 * 128;                   // A [256][64] then W [256][64], 128-byte rows
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+
+    const int nbn = p.N / BN;
+    const int nbm = (p.M + BM - 1) / BM;
+    const int nwg = nbm * nbn;
+    int bid = blockIdx.x;
+    {
+        const int xcd = bid & 7, slot = bid >> 3;
+        const int q = nwg >> 3, r = nwg & 7;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+    }
+    constexpr int GM = 4;
+    const int tpg = GM * nbn;
+    const int gidx = bid / tpg;
+    const int gfirst = gidx * GM;
+    const int gsz = (nbm - gfirst < GM) ? nbm - gfirst : GM;
+    const int gin = bid - gidx * tpg;
+    const int m0 = (gfirst + gin % gsz) * BM;
+    const int n0 = (gin / gsz) * BN;
+
+    const int grp = blockIdx.y;
+    const T* __restrict__ A = reinterpret_cast<const T*>(p.A) + (size_t)grp * p.strideA;
+    const int wgrp = p.wdiv > 1 ? grp / p.wdiv : grp;
+    const T* __restrict__ W = reinterpret_cast<const T*>(p.W) + (size_t)wgrp * p.strideW;
+    const float* __restrict__ bias = p.bias ? p.bias + (size_t)wgrp * p.strideB : nullptr;
+    void* const outp = p.out_table ? p.out_table[grp] : p.out;
+
+    const int srow = lane >> 3, pch = lane & 7;
+    const T* a_src[4];
+    const T* w_src[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int r = (wave * 4 + q) * 8 + srow;
+        int gr = m0 + r;
+        gr = gr < p.M ? gr : p.M - 1;
+        a_src[q] = A + (size_t)gr * p.lda + swz(r, pch) * 8;
+        w_src[q] = W + (size_t)(n0 + r) * (size_t)p.K + swz(r, pch) * 8;
+    }
+    auto stage = [&](int kt) {
+        char* const base = smem + (kt & 1) * BUFB + wave * 4096;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) glds16(a_src[q] + (size_t)kt * BK, base + q * 1024);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) glds16(w_src[q] + (size_t)kt * BK, base + 32768 + q * 1024);
+    };
+
+    f32x4 acc[MF][NF];
+#pragma unroll
+    for (int i = 0; i < MF; ++i)
+#pragma unroll
+        for (int j = 0; j < NF; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int fr = lane & 15, fg = lane >> 4;
+    const int nk = p.K / BK;
+    unsigned a_lane[2], w_lane[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        const int ra = wr * 128 + fr, rw = wc * WN + fr;
+        a_lane[ks] = (unsigned)(ra * 128 + swz(ra, ks * 4 + fg) * 16);
+        w_lane[ks] = 32768u + (unsigned)(rw * 128 + swz(rw, ks * 4 + fg) * 16);
+    }
+    v8 af[2][MF], wf[2][NF];
+    auto reads = [&](int t) {
+        const unsigned bufb = (t & 1) * BUFB;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+            for (int j = 0; j < NF; ++j) wf[ks][j] = *reinterpret_cast<const v8*>(smem + bufb + w_lane[ks] + j * 2048);
+#pragma unroll
+            for (int i = 0; i < MF; ++i) af[ks][i] = *reinterpret_cast<const v8*>(smem + bufb + a_lane[ks] + i * 2048);
+        }
+    };
+    auto mma = [&]() {
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < MF; ++i)
+#pragma unroll
+                for (int j = 0; j < NF; ++j) acc[i][j] = mfma16(wf[ks][j], af[ks][i], acc[i][j]);
+        __builtin_amdgcn_s_setprio(0);
+    };
+#define M3R_N_BAR() do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); } while (0)
+
+    stage(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (wr == 0) {
+        for (int t = 0; t < nk; ++t) {
+            if (t + 1 < nk) stage(t + 1);
+            reads(t);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            M3R_N_BAR();
+            mma();
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            M3R_N_BAR();
+        }
+        __builtin_amdgcn_s_barrier();
+    } else {
+        __builtin_amdgcn_s_barrier();   // one barrier behind
+        for (int t = 0; t < nk; ++t) {
+            if (t + 1 < nk) stage(t + 1);
+            reads(t);
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            M3R_N_BAR();
+            mma();
+            M3R_N_BAR();
+        }
+    }
+#undef M3R_N_BAR
+
+    epilogue_tile<T, EPI, NF, MF, 4, false>(p, outp, bias, m0 + wr * 128 + fr, n0 + wc * WN, fg, acc, NoLnFold{});
+}
+
+template <class T, int EPI>
+static int launch_256n(const GemmArgs& a, hipStream_t s) {
+    const int nbn = a.N / 256, nbm = (a.M + 255) / 256;
+    const size_t lds = (size_t)2 * 512 * 128;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256n_kernel<T, EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return 1;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((gemm256n_kernel<T, EPI>), dim3(nbm * nbn, a.batch > 1 ? a.batch : 1), dim3(512), lds, s, a);
+    return hipGetLastError() == hipSuccess ? 0 : 1;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // gemm256s_kernel (r05): split weights with a 2:4-sparse low part on 256 x 256 tiles -- gemm256p_kernel's two-phase K loop with FIVE half-tiles per K-tile.
 //   Why another tile: with the sparse low part a 256 x 128 tile (gemm256p_kernel<.., WS = 3>) issues 24 matrix instructions per phase (~410 cycles) against a
 //   load interval of ~500-600 (its 15 fragment reads, 4 DMA pieces and their waits): the K-tile takes the ~2600 cycles of the dense form and only 1.7 % of the
@@ -2488,6 +2638,7 @@ __global__ void __launch_bounds__(576) gemm48_kernel(const GemmArgs p) {
     }
 }
 
+static thread_local int g_gemm48_bk = 64;   // K-tile depth of this thread's last gemm48 launch: the two depths are two symbols of a kernel trace (pick_name48)
 template <class T, int EPI, int WS, int BK>
 static int launch_48k(const GemmArgs& a, hipStream_t s) {
     constexpr int NST = BK == 128 ? (WS == 2 ? 4 : 6) : 6;   // 4 x 36 KB (split) / 6 x 24 KB (plain) of 128-deep stages; 6 x 18 / 12 KB at 64
@@ -2495,9 +2646,13 @@ static int launch_48k(const GemmArgs& a, hipStream_t s) {
     const size_t lds = (size_t)NST * (48 + WS * 48) * BK * sizeof(T) + ln_fold_lds_bytes<48, 576>();
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm48_kernel<T, EPI, WS, NST, BK>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm48_kernel<T, EPI, WS, NST, BK>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+            fprintf(stderr, "must3r_hip: gemm48 (K-tile %d): %zu bytes of dynamic LDS refused\n", BK, lds);
+            return 1;
+        }
         attr_set = true;
     }
+    g_gemm48_bk = BK;
     hipLaunchKernelGGL((gemm48_kernel<T, EPI, WS, NST, BK>), dim3(nbm * nbn, a.batch > 1 ? a.batch : 1), dim3(576), lds, s, a);
     return hipGetLastError() == hipSuccess ? 0 : 1;
 }
@@ -2901,12 +3056,12 @@ static int launch_epi(const GemmArgs& a, hipStream_t s, const char** err) {
             if (a.ln_stats != nullptr) {
                 // LN-fold consumers: the kernels that carry the row-statistics prologue, whatever the tile count
                 if constexpr (EPI == EPI_STORE16_GELU) { pick_name("g96", EPI, 2, 96); rc = a.N % 96 == 0 ? launch_96<T, EPI>(a, s) : 1; }
-                else if constexpr (EPI == EPI_STORE16) { pick_name("g48", EPI, 2, 48); rc = a.N % 48 == 0 ? launch_48<T, EPI, 2>(a, s) : 1; }
+                else if constexpr (EPI == EPI_STORE16) { rc = a.N % 48 == 0 ? launch_48<T, EPI, 2>(a, s) : 1; pick_name(g_gemm48_bk == 128 ? "g48k128" : "g48", EPI, 2, 48); }
                 else if constexpr (EPI == EPI_QKV_ROPE) { pick_name("g64", EPI, 2, 64); rc = launch_cfg<T, 64, 64, 2, 2, EPI, 3, 2>(a, s); }
                 else rc = 1;
             } else if (EPI == EPI_STORE16_GELU && gelu_occ2 && mode != 0 && ok128 && t128 >= 1024) { pick_name("g256o2", EPI, 2, 128); rc = launch_256<T, EPI, 2, 128, 2>(a, s); }
             else if (EPI != EPI_HEAD && use_96(a, nb)) { pick_name("g96", EPI, 2, 96); rc = launch_96<T, EPI == EPI_HEAD ? EPI_STORE16 : EPI>(a, s); }
-            else if (EPI != EPI_QKV_ROPE && EPI != EPI_HEAD && use_48(a, nb)) { pick_name("g48", EPI, 2, 48); rc = launch_48<T, EPI == EPI_QKV_ROPE || EPI == EPI_HEAD ? EPI_STORE16 : EPI, 2>(a, s); }
+            else if (EPI != EPI_QKV_ROPE && EPI != EPI_HEAD && use_48(a, nb)) { rc = launch_48<T, EPI == EPI_QKV_ROPE || EPI == EPI_HEAD ? EPI_STORE16 : EPI, 2>(a, s); pick_name(g_gemm48_bk == 128 ? "g48k128" : "g48", EPI, 2, 48); }
             // r05: the 2:4-sparse low part (48 matrix instructions per K-tile instead of 64) wherever the launch fills the chip and the caller has the packed copy
             else if (a.Wlo_sp != nullptr && a.Widx_sp != nullptr && g256p_mode(true) != 0 && ok128 && a.K % 64 == 0 && t128 >= 200 && a.ln_stats == nullptr && !lnp &&
                      (fill256(t128) >= 80 || pick != 0)) {
@@ -2939,8 +3094,8 @@ static int launch_epi(const GemmArgs& a, hipStream_t s, const char** err) {
             if constexpr (EPI == EPI_STORE16_GELU || EPI == EPI_STORE16 || EPI == EPI_QKV_ROPE) { pick_name("g64", EPI, 1, 64); rc = launch_cfg<T, 64, 64, 2, 2, EPI, 4, 1>(a, s); }
             else rc = 1;
         } else if (EPI != EPI_QKV_ROPE && EPI != EPI_HEAD && sizeof(T) == 2 && use_48(a, nb)) {
-            pick_name("g48", EPI, 1, 48);
-            rc = launch_48<T, EPI == EPI_QKV_ROPE || EPI == EPI_HEAD ? EPI_STORE16 : EPI, 1>(a, s);   // N = 768 one-view launches: 256 tiles of 48 x 48
+            rc = launch_48<T, EPI == EPI_QKV_ROPE || EPI == EPI_HEAD ? EPI_STORE16 : EPI, 1>(a, s);
+            pick_name(g_gemm48_bk == 128 ? "g48k128" : "g48", EPI, 1, 48);   // N = 768 one-view launches: 256 tiles of 48 x 48
         } else if (ok256 && a.K % 64 == 0 && g256p_mode(false) != 0 && EPI != EPI_QKV_ROPE && (mode == 2 || (mode == 1 && t256 >= 200 && fill256(t256) >= 80))) {
             pick_name("g256p", EPI, 1, 256); rc = launch_256p<T, EPI == EPI_QKV_ROPE ? EPI_STORE16 : EPI, 1, 256, 2>(a, s);
         } else if (ok256 && (mode == 2 || (mode == 1 && t256 >= 200 && fill256(t256) >= 80))) { pick_name(g256k_mode() >= 1 ? "g256k" : "g256", EPI, 1, 256); rc = g256k_mode() >= 1 ? launch_256k<T, EPI, 1, 256>(a, s) : launch_256<T, EPI, 1, 256>(a, s); }

@@ -12,7 +12,7 @@ import re
 import sys
 
 G = "gpurun_out"
-FAM = {"g256p": "gemm256p_kernel", "g256k": "gemm256k_kernel", "g256": "gemm256_kernel", "g256o2": "gemm256_kernel", "g256x": "gemm256x_kernel", "g128": "gemm_kernel", "g64": "gemm_kernel",
+FAM = {"g256p": "gemm256p_kernel", "g256ps": "gemm256p_kernel", "g256s": "gemm256s_kernel", "g48k128": "gemm48_kernel", "g256k": "gemm256k_kernel", "g256": "gemm256_kernel", "g256o2": "gemm256_kernel", "g256x": "gemm256x_kernel", "g128": "gemm_kernel", "g64": "gemm_kernel",
        "g64p": "gemm_kernel", "g96": "gemm96_kernel", "g48": "gemm48_kernel", "attn3": "attn3_kernel", "attn4f8": "attn4_kernel"}
 
 
@@ -28,6 +28,10 @@ def symbol_matches(row_name, sym):
     if parts[0] == "attn4f8":
         return True
     e, w, n = int(parts[1][1:]), int(parts[2][1:]), int(parts[3][1:])
+    if parts[0] == "g256s":                              # <T, EPI>: 256 x 256 tiles, sparse low part
+        return ints[:1] == [e]
+    if parts[0] == "g256ps":                             # gemm256p_kernel<T, EPI, 3, 128, 2, 2>
+        return ints[:3] == [e, 3, 128]
     if parts[0] in ("g256p", "g256k", "g256", "g256o2", "g256x"):      # <T, EPI, WS, BN, OCC|ABL|NPH, SYNC>
         ok = ints[:3] == [e, w, n]
         if parts[0] == "g256o2":
@@ -40,8 +44,8 @@ def symbol_matches(row_name, sym):
         return len(ints) >= 9 and ints[0] == bm and ints[1] == n and ints[4] == e and ints[6] == w and ints[8] == (1 if parts[0] == "g64p" else 0)
     if parts[0] == "g96":                               # <T, EPI, NST, PF>
         return ints[:1] == [e]
-    if parts[0] == "g48":                               # <T, EPI, WS, NST>
-        return ints[:2] == [e, w]
+    if parts[0] in ("g48", "g48k128"):                  # <T, EPI, WS, NST, BK>
+        return ints[:2] == [e, w] and ints[3:4] == [128 if parts[0] == "g48k128" else 64]
     return False
 
 
