@@ -336,6 +336,97 @@ __device__ __forceinline__ void epilogue_tile(const GemmArgs& p, void* const out
             return;
         }
     }
+    if constexpr (EPI == EPI_QKV_ROPE && !LN && MF % 2 == 0 && NF == 4 && sizeof(T) == 2) {
+        // r05.  Whole wave tile inside the matrix (wave-uniform), 64-column wave tiles: straight-line code like the residual path above, so that the compiler
+        // counts vmcnt exactly -- the (cos, sin) entries of the NEXT pair of row fragments are requested in front of this pair's stores and waited for with
+        // those stores still in flight (the batched form below waits vmcnt(0) per batch: for the previous batch's store acknowledgements, ~1-2 us each;
+        // the RoPE epilogue cost a 256 x 256 qkv tile 6.5 us more than the plain 16-bit store, profiles/r05_sparse_gemm_shapes.txt).  Rotating columns
+        // only (nw0 < rope_cols, wave-uniform); the value columns take the batched path, which no longer waits per batch for loads it does not issue.
+        // Same arithmetic and rounding as epilogue_row.
+        const int lane = (int)__lane_id();
+        const int lane16 = lane & 15;
+        if (m_first - lane16 + MF * 16 - 1 < p.M && nw0 < p.rope_cols) {
+            typedef typename Vec<T>::v4 v4;
+            int pq[MF][2];   // clamped table row of every row fragment, per 32-column half
+#pragma unroll
+            for (int i = 0; i < MF; ++i) {
+                const int m = m_first + i * 16;
+                const long long y = p.pos[(size_t)m * 2 + 0], x = p.pos[(size_t)m * 2 + 1];
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    int pp = (int)((((nw0 + q * 32) >> 5) & 1) ? x : y);
+                    pq[i][q] = pp < 0 ? 0 : (pp >= p.rope_npos ? p.rope_npos - 1 : pp);
+                }
+            }
+            f32x4 t0[2][2][2], t1[2][2][2];   // [slot][row fragment of the pair][half]
+            auto ld = [&](int pair, int slot) {
+#pragma unroll
+                for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        const float* tb = p.rope_tab + ((size_t)pq[2 * pair + ii][q] * 16 + fg * 4) * 2;
+                        t0[slot][ii][q] = ld_global<f32x4>(tb);
+                        t1[slot][ii][q] = ld_global<f32x4>(tb + 4);
+                    }
+            };
+            const bool scale = p.out_scale != 0.f && nw0 < p.scale_cols;
+            const int nq = nw0 + ((lane >> 5) & 1) * 16 + ((lane >> 4) & 1) * 8;
+            ld(0, 0);
+#pragma unroll
+            for (int pair = 0; pair < MF / 2; ++pair) {
+                if (pair + 1 < MF / 2) ld(pair + 1, (pair + 1) & 1);
+#pragma unroll
+                for (int ii = 0; ii < 2; ++ii) {
+                    const int i = 2 * pair + ii;
+                    f32x4 v[NF];
+#pragma unroll
+                    for (int j = 0; j < NF; ++j) v[j] = acc[i][j] + b[j];
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        const f32x4 a0 = t0[pair & 1][ii][q], a1 = t1[pair & 1][ii][q];
+                        const float cs[4] = {a0[0], a0[2], a1[0], a1[2]};
+                        const float sn[4] = {a0[1], a0[3], a1[1], a1[3]};
+                        const f32x4 x0 = v[2 * q], x1 = v[2 * q + 1];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            v[2 * q][r] = x0[r] * cs[r] - x1[r] * sn[r];
+                            v[2 * q + 1][r] = x1[r] * cs[r] + x0[r] * sn[r];
+                        }
+                    }
+                    if (scale) {
+#pragma unroll
+                        for (int j = 0; j < NF; ++j) v[j] *= p.out_scale;
+                    }
+                    u32x4 o[2];
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        const v4 h0 = cvt4_sat<T>(v[2 * q]), h1 = cvt4_sat<T>(v[2 * q + 1]);
+                        unsigned a[2], c[2];
+                        __builtin_memcpy(a, &h0, 8);
+                        __builtin_memcpy(c, &h1, 8);
+#pragma unroll
+                        for (int d = 0; d < 2; ++d) {
+                            auto s1 = __builtin_amdgcn_permlane32_swap(a[d], c[d], false, false);
+                            auto s2 = __builtin_amdgcn_permlane16_swap(s1[0], s1[1], false, false);
+                            o[q][d] = s2[0];
+                            o[q][2 + d] = s2[1];
+                        }
+                    }
+                    u32x4 x, y;
+#pragma unroll
+                    for (int d = 0; d < 4; ++d) {
+                        x[d] = (unsigned)__builtin_amdgcn_update_dpp((int)o[0][d], (int)o[1][d], 0x128, 0xf, 0xc, false);
+                        y[d] = (unsigned)__builtin_amdgcn_update_dpp((int)o[1][d], (int)o[0][d], 0x128, 0xf, 0x3, false);
+                    }
+                    const int row0 = m_first + i * 16 - lane16;
+                    T* const dst = reinterpret_cast<T*>(outp) + (size_t)(row0 + (lane & 7)) * p.ldc + nq + ((lane >> 3) & 1) * 32;
+                    st_global<u32x4>(dst, x);
+                    st_global<u32x4>(dst + (size_t)8 * p.ldc, y);
+                }
+            }
+            return;
+        }
+    }
     // RoPE: the positions of ALL the wave tile's rows in one go (16 bytes per row), so that a batch costs one round trip (its table entries), not two
     long long py[MF], px[MF];
     if constexpr (EPI == EPI_QKV_ROPE) {
@@ -369,7 +460,7 @@ __device__ __forceinline__ void epilogue_tile(const GemmArgs& p, void* const out
         }
         // Explicit waits (the compiler's own would sit behind each fragment's row-validity branch, where only vmcnt(0) can express "the
         // loads of this batch" -- and that also waits for the previous fragment's stores): ONE wait per batch, in front of its stores.
-        const bool row_loads = EPI == EPI_RESID_F32 || (EPI == EPI_F32 && p.accumulate) || EPI == EPI_QKV_ROPE;
+        const bool row_loads = EPI == EPI_RESID_F32 || (EPI == EPI_F32 && p.accumulate) || (EPI == EPI_QKV_ROPE && nw0 < p.rope_cols);
         if (i0 == 0 || row_loads) __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0)
         if constexpr (EPI == EPI_QKV_ROPE) {
             if (nw0 < p.rope_cols) {
