@@ -93,6 +93,10 @@ typedef struct must3r_hip_group {
     const int64_t* pos;   /* int64 [n_views, n_tokens, 2] */
     int32_t n_views, n_tokens, H, W;
     float* pointmaps;     /* out fp32 [n_views, H, W, 7] raw head output (decoder.py:149-156) */
+    /* ABI 7: elements between the pointmaps of consecutive SCENES of this group; 0 = n_views*H*W*7 (the contiguous [B, n_views, H, W, 7] of the
+     * reference).  A caller that walks a scene's views over several calls (the sequential memory update) can hand every call the slice
+     * [:, i:i+n] of ONE [B, V, H, W, 7] buffer instead of concatenating the calls' outputs afterwards (must3r_amd.engine.run_scenes). */
+    int64_t pointmaps_scene_stride;
 } must3r_hip_group;
 
 typedef struct must3r_hip_decode_args {

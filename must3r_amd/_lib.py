@@ -44,7 +44,7 @@ class Config(C.Structure):
 class Group(C.Structure):
     _fields_ = [("tokens", C.c_void_p), ("pos", C.c_void_p),
                 ("n_views", C.c_int32), ("n_tokens", C.c_int32), ("H", C.c_int32), ("W", C.c_int32),
-                ("pointmaps", C.c_void_p)]
+                ("pointmaps", C.c_void_p), ("pointmaps_scene_stride", C.c_int64)]
 
 
 class DecodeArgs(C.Structure):

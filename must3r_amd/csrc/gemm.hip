@@ -274,7 +274,8 @@ __device__ __forceinline__ void epilogue_row(const GemmArgs& p, void* const outp
             const int vv = m / p.ntok, t = m - vv * p.ntok;
             const int gy = t / p.gw, gx = t - gy * p.gw;
             const int pi = n / 112, rem = n - pi * 112;
-            const size_t off = ((size_t)(vv * p.H + gy * 16 + pi) * p.Wimg + gx * 16) * 7 + rem;
+            size_t off = ((size_t)(vv * p.H + gy * 16 + pi) * p.Wimg + gx * 16) * 7 + rem;
+            if (p.head_views > 0) off += (size_t)(vv / p.head_views) * (size_t)p.head_scene_skip;
             f32x4* o = reinterpret_cast<f32x4*>(reinterpret_cast<float*>(outp) + off);
             f32x4 x = v[j];
             if (p.accumulate) x += *o;

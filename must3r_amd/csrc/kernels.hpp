@@ -60,6 +60,10 @@ struct GemmArgs {
     int accumulate;          // EPI_F32 / EPI_HEAD: add into out, skip bias
     // EPI_HEAD: rows are `ntok`-token views of one aspect ratio
     int ntok, gw, H, Wimg;
+    // r05: the views of the launch belong to scenes of `head_views` views each whose pointmaps are `head_scene_skip` elements further apart than contiguous
+    // (must3r_hip_group::pointmaps_scene_stride); 0 / 0 = one contiguous [views, H, W, 7] block
+    int head_views;
+    long long head_scene_skip;
     // LayerNorm folded into the GEMMs around it (one-view memory update; DESIGN.md section 3, "LN fold"):
     //   producer (EPI_RESID_F32 / EPI_F32): besides `out` it writes the new fp32 rows rounded to the 16-bit type (x16_out, row stride ldc),
     //     an optional second fp32 copy (copy32_out) and, per row and 16-column fragment, (sum x, sum x^2) into stats_out [M][N/16][2];

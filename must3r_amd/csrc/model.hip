@@ -208,7 +208,7 @@ static int gemm(must3r_hip_ctx* c, DType dt, Epi epi, GemmArgs a, hipStream_t s,
                             : ((a.N % 128 == 0 && tiles128 >= 192) ? PC_GEMM128 : PC_GEMM64);
     if (ws_override >= 0) a.wsplit = ws_override;
     else if (c && epi != EPI_HEAD) a.wsplit = c->wsplit;
-    if (c && a.wsplit == 2 && epi != EPI_HEAD && !c->sparse_lo.empty()) {
+    if (c && a.wsplit == 2 && c->mlp_plain && epi != EPI_HEAD && !c->sparse_lo.empty()) {   // (the sparse copies of an earlier MUST3R_F16_WA forward are not for MUST3R_F16_W2)
         auto it = c->sparse_lo.find(a.W);
         if (it != c->sparse_lo.end()) { a.Wlo_sp = it->second.vals; a.Widx_sp = it->second.idx; a.wsp_rows = it->second.rows; }
     }
@@ -374,9 +374,14 @@ static int w16p(must3r_hip_ctx* c, Param& p, DType dt, const void** hi, hipStrea
         // asks for the plain 16-bit mode): 4 of the 16 bytes per parameter.  hipFree waits for the copies above (first use only).
         (void)hipFree(p.h16[dt]); p.h16[dt] = nullptr;
         (void)hipFree(p.l16[dt]); p.l16[dt] = nullptr;
-        // r05: the 2:4-sparse low part for the chip-filling kernel (fp16; M3R_SPARSE_LO=0: never) -- rows x K / 2 values + rows x K / 8 bytes of positions
-        static const bool sparse_on = [] { const char* e = getenv("M3R_SPARSE_LO"); return !e || atoi(e) != 0; }();
-        if (sparse_on && dt == DT_F16 && rows % 128 == 0 && K % 64 == 0 && !p.sp_vals) {
+    }
+    // r05: the 2:4-sparse low part for the chip-filling kernels -- MUST3R_F16_WA only (mlp_plain): there the error budget is the plain Mlp weights' and the
+    // dropped half of W_lo is invisible (scripts/emul/sparse_lo.py: 5.99e-4 vs 6.05e-4); MUST3R_F16_W2 exists for its 4e-4 and keeps the dense low part
+    // (all-sparse would be 4.4e-4 against 3.4e-4).  fp16; M3R_SPARSE_LO=0: never.  rows x K / 2 values + rows x K / 8 bytes of positions, built on first use.
+    static const bool sparse_on = [] { const char* e = getenv("M3R_SPARSE_LO"); return !e || atoi(e) != 0; }();
+    if (sparse_on && c->mlp_plain && dt == DT_F16 && !p.sp_vals) {
+        const size_t rows = (size_t)p.shape[0], K = p.n / rows;
+        if (rows % 128 == 0 && K % 64 == 0) {
             const char* err = "";
             HIP_OK(hipMalloc(&p.sp_vals, rows * K));
             HIP_OK(hipMalloc(&p.sp_idx, rows * K / 8));
@@ -1135,9 +1140,12 @@ static int decode_impl(must3r_hip_ctx* c, const must3r_hip_decode_args* A, void*
                 const must3r_hip_group& G = A->groups[gi];
                 const int rg = G.n_views * G.n_tokens;                       // rows of this group per scene
                 const int Rg = one_block ? S * rg : rg;                      // one group: all scenes in one launch ([S, n, H, W, 7] is contiguous)
+                const size_t scene_elems = (size_t)G.n_views * G.H * G.W * 7;
+                const size_t scene_stride = G.pointmaps_scene_stride > 0 ? (size_t)G.pointmaps_scene_stride : scene_elems;
                 GemmArgs ga = gargs(hcat + ((size_t)b * Rs + grow0[gi]) * 3 * D, wcat, p32(c, "decoder.head_dec.proj_ps.bias"),
-                                    G.pointmaps + (size_t)b * G.n_views * G.H * G.W * 7, Rg, OUT, 3 * D, 3 * D, 0);
+                                    G.pointmaps + (size_t)b * scene_stride, Rg, OUT, 3 * D, 3 * D, 0);
                 ga.ntok = G.n_tokens; ga.gw = G.W / 16; ga.H = G.H; ga.Wimg = G.W;
+                if (one_block && scene_stride != scene_elems) { ga.head_views = G.n_views; ga.head_scene_skip = (long long)(scene_stride - scene_elems); }
                 M3R_OK(gemm(c, dt, EPI_HEAD, ga, hs_));
             }
     }
@@ -1208,6 +1216,8 @@ extern "C" int must3r_hip_decode(must3r_hip_ctx* c, const must3r_hip_decode_args
         const must3r_hip_group& G = A->groups[gi];
         if (!G.tokens || !G.pos || !G.pointmaps) return fail("decode: null buffer in group %d", gi);
         if (G.n_views <= 0 || G.n_tokens <= 0) return fail("decode: empty group %d", gi);
+        if (G.pointmaps_scene_stride != 0 && G.pointmaps_scene_stride < (long long)G.n_views * G.H * G.W * 7)
+            return fail("decode: group %d: pointmaps_scene_stride %lld is smaller than one scene's pointmaps", gi, (long long)G.pointmaps_scene_stride);
         if (G.H % 16 || G.W % 16 || (G.H / 16) * (G.W / 16) != G.n_tokens)
             return fail("decode: group %d: %dx%d does not give %d tokens", gi, G.H, G.W, G.n_tokens);
         if (G.H / 16 > c->rope_npos || G.W / 16 > c->rope_npos) return fail("decode: group %d: image too large for the RoPE table", gi);
@@ -1255,7 +1265,8 @@ extern "C" int must3r_hip_decode(must3r_hip_ctx* c, const must3r_hip_decode_args
                 const size_t rg = (size_t)gs[gi].n_views * gs[gi].n_tokens;
                 gs[gi].tokens += (size_t)b0 * rg * c->cfg.enc_dim;
                 gs[gi].pos += (size_t)b0 * rg * 2;
-                gs[gi].pointmaps += (size_t)b0 * gs[gi].n_views * gs[gi].H * gs[gi].W * 7;
+                gs[gi].pointmaps += (size_t)b0 * (gs[gi].pointmaps_scene_stride > 0 ? (size_t)gs[gi].pointmaps_scene_stride
+                                                                                       : (size_t)gs[gi].n_views * gs[gi].H * gs[gi].W * 7);
             }
             for (int l = 0; l < c->cfg.dec_depth; ++l)
                 mems[l] = reinterpret_cast<char*>(A->mem[l]) + (size_t)b0 * A->mem_scene_stride * memRB;

@@ -185,13 +185,16 @@ class MUSt3R(HipModule):
 
     # -- forward -------------------------------------------------------------------------------
     @torch.no_grad()
-    def forward(self, x, pos, true_shape, current_mem=None, render=False, return_feats=False):
+    def forward(self, x, pos, true_shape, current_mem=None, render=False, return_feats=False, pointmaps_out=None):
+        """``pointmaps_out`` (extension, r05): where to write the raw pointmaps -- a fp32 cuda tensor [B, n, H, W, 7] (a list of them for list inputs) whose last four
+        dimensions are contiguous; its batch stride is free, so a caller walking a scene's views over several calls can pass the slice ``buf[:, i:i+n]`` of one
+        [B, V, H, W, 7] buffer (engine.run_scenes) instead of concatenating the calls' outputs.  Returned in place of a fresh tensor."""
         is_list = isinstance(x, (list, tuple))
         if is_list:
             return_feats = False   # the reference's list dispatch drops the flag (decoder.py:270); forward_list honours it
-        return self._forward(x, pos, true_shape, current_mem, render, return_feats)
+        return self._forward(x, pos, true_shape, current_mem, render, return_feats, pointmaps_out)
 
-    def _forward(self, x, pos, true_shape, current_mem, render, return_feats):
+    def _forward(self, x, pos, true_shape, current_mem, render, return_feats, pointmaps_out=None):
         is_list = isinstance(x, (list, tuple))
         xs = list(x) if is_list else [x]
         poss = list(pos) if is_list else [pos]
@@ -201,12 +204,13 @@ class MUSt3R(HipModule):
         # B > 1 (the reference's batch dimension, decoder.py:170-186): the scenes of a batch never interact -- memory, labels and
         # attention are all per batch element -- and are decoded by ONE native call (must3r_hip_decode_args.n_scenes): every GEMM
         # sees M = B x rows, the attention tables B x views, each scene its own rows of the [B, capacity, mem_D] memory buffers.
-        out, outs, feats = self._forward_scene(xs, poss, shapes, current_mem, render, return_feats)
+        pouts = None if pointmaps_out is None else (list(pointmaps_out) if isinstance(pointmaps_out, (list, tuple)) else [pointmaps_out])
+        out, outs, feats = self._forward_scene(xs, poss, shapes, current_mem, render, return_feats, pouts)
         if return_feats:
             return out, (outs if is_list else outs[0]), (feats if is_list else feats[0])
         return out, (outs if is_list else outs[0])
 
-    def _forward_scene(self, xs, poss, shapes, current_mem, render, return_feats):
+    def _forward_scene(self, xs, poss, shapes, current_mem, render, return_feats, pouts=None):
         """B scenes of identical shapes: ONE native decode call.  Returns (memory, [pointmaps per group], [feats per group] | None)."""
         # (The per-call view tables travel through a 64 KiB staging slot, 1365 views; the reference renders every view of an aspect
         # ratio in ONE call when the caller sets no max_bs (engine/inference.py:489-522), so the LIBRARY cuts larger render calls
@@ -252,10 +256,20 @@ class MUSt3R(HipModule):
             assert bool((ts[0:1] == ts).all()), "true_shape must be all identical"  # head.py:31
             H, W = (int(v) for v in ts[0].tolist())
             assert (H // 16) * (W // 16) == N, (H, W, N)
-            pm = torch.empty((B, n, H, W, 7), dtype=torch.float32, device=device)
+            sstride = 0
+            if pouts is not None:
+                pm = pouts[i]
+                inner = n * H * W * 7
+                if (not pm.is_cuda or pm.dtype != torch.float32 or tuple(pm.shape) != (B, n, H, W, 7) or pm.device != device
+                        or tuple(pm.stride()[1:]) != (H * W * 7, W * 7, 7, 1) or (B > 1 and pm.stride(0) < inner)):
+                    raise ValueError(f"pointmaps_out[{i}]: need a fp32 cuda tensor [{B}, {n}, {H}, {W}, 7] with contiguous views, got {tuple(pm.shape)} "
+                                     f"{pm.dtype} strides {tuple(pm.stride())}")
+                sstride = int(pm.stride(0)) if B > 1 and int(pm.stride(0)) != inner else 0
+            else:
+                pm = torch.empty((B, n, H, W, 7), dtype=torch.float32, device=device)
             keep += [xi, pi]
             outs.append(pm)
-            groups[i] = _lib.Group(xi.data_ptr(), pi.data_ptr(), n, N, H, W, pm.data_ptr())
+            groups[i] = _lib.Group(xi.data_ptr(), pi.data_ptr(), n, N, H, W, pm.data_ptr(), sstride)
             R += n * N
             nimgs.append(n)
             Ns.append(N)

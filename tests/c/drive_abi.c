@@ -68,6 +68,7 @@ int main(int argc, char** argv) {
     for (int l = 0; l < L; ++l) HIP(hipMalloc(&mem[l], (size_t)B * cap * 2 * D * 2));
     must3r_hip_group g;
     must3r_hip_decode_args a;
+    memset(&g, 0, sizeof(g));   /* (pointmaps_scene_stride = 0: contiguous outputs) */
     memset(&a, 0, sizeof(a));
     a.dtype = dtype; a.mem_mode = MUST3R_MEM_KV; a.n_groups = 1; a.groups = &g; a.mem = mem;
     a.mem_capacity = cap; a.n_scenes = B; a.mem_scene_stride = cap;
