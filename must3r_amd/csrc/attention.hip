@@ -22,6 +22,7 @@ constexpr int ATT_QW = 32;               // query rows per wave (template defaul
 constexpr int ATT_QB = 4 * ATT_QW;       // per block (default geometry, used by the split heuristic)
 constexpr int ATT_KT = 64;               // keys per tile
 constexpr float ATT_THR = 6.0f;          // lazy-rescale threshold in log2 units (P <= 64)
+constexpr float ATT_LIM = 4096.0f;       // LZ = 1: largest row sum of ONE 64-key tile that does not move the references (64 keys x 2^ATT_THR)
 
 // blockIdx -> (group = view x head, key split, query block).  The blocks that share K/V tiles are the query blocks of one
 // (group, split) PAIR; a pair stays on one XCD (blockIdx % 8: observed placement, speed only) so its tiles are L2 hits, and the
@@ -66,6 +67,14 @@ __device__ __forceinline__ bool attn_block_coords(int nqb_signed, int ngrp, int 
 //     (no second register version of the accumulators, no copies at a join).
 // Arithmetic: S - m from the accumulator init, exp2, P rounded to T, row sums from the ones MFMA; the slow path subtracts the
 // shift before the exp2.
+//   * r05 (LZ = 1, the default): the fast path computes NO maxima.  The `ones` MFMAs run on a fresh accumulator BEFORE the P.V products, so the tile's
+//     row sums are in hand when the products start: a sum <= ATT_LIM = 4096 proves that no score of the tile is more than 12 log2 units above its row's
+//     reference (P <= 4096 is exact business for a 16-bit P and an fp32 accumulator); a larger sum, an infinity (a score 16+ above the reference overflows
+//     fp16, 128+ the exp2 itself) or a NaN sends the wave through the slow block, which reads the K tile again (it is still in LDS) and moves the
+//     references as before.  The 19 max3 / max instructions per tile become 2 compares + 2 adds; 75 -> 52 VALU instructions per 36 MFMAs.  Measured
+//     (profiles/r05_attn_*): render cross attention +1-3 %, the 28-scene step +1.1 %.  (The per-pair exp2 on packed fp16 that VERDICT r04 proposed was
+//     costed first: there is no packed transcendental, and a 2^x on v_pk_fma_f16 -- split, degree-3 polynomial, exponent insertion, clamp -- is >= 9 packed
+//     instructions per PAIR against 2 v_exp_f32 + 1 v_cvt_pk: more issue slots, not fewer.  DESIGN.md section 3.2.)
 template <int O0, int O1>
 __device__ __forceinline__ void lds_tr_x8_imm(unsigned a0, unsigned a1, unsigned a2, unsigned a3, u32x2 (&r)[8]) {
     asm volatile(
@@ -101,7 +110,9 @@ __device__ __forceinline__ float max16f(const f32x4& a, const f32x4& b, const f3
     return r;
 }
 
-template <class T, int QW, int ABL = 0>   // ABL: timing ablations for experiments (1 no exp2, 2 no max / slow path, 3 no P.V MFMAs, 4 no cvt, 5 no DMA in the loop,
+template <int V> __device__ __forceinline__ std::integral_constant<int, V> to_constant(std::integral_constant<int, V>) { return {}; }
+__device__ __forceinline__ std::integral_constant<int, 0> to_constant(int) { return {}; }
+template <class T, int QW, int ABL = 0, int LZ = 0, int NB = 2, int PR = 0>   // PR: s_setprio experiment (1: MFMA clusters raised, 2: the exp2 cluster raised); ABL: timing ablations for experiments (1 no exp2, 2 no max / slow path, 3 no P.V MFMAs, 4 no cvt, 5 no DMA in the loop,
                                          // 6 no barrier / vmcnt wait, 7 = 5 + 6, 8 = 7 + no LDS reads, 9 = 8 + no softmax VALU: MFMAs only)
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(QW == 32 ? 3 : 2))) attn3_kernel(const AttnArgs p, const int nqb, const int ngrp, const int nsplit) {
     typedef typename Vec<T>::v8 v8;
@@ -109,7 +120,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(QW == 
     constexpr int QF = QW / 16;
     constexpr int QB = 4 * QW;
     constexpr int TILE = ATT_KT * 64;                                    // elements of one K (or V) tile
-    __shared__ __attribute__((aligned(16))) T smem_kv[2][2][TILE];       // [buffer][K|V][64 keys x 64]
+    __shared__ __attribute__((aligned(16))) T smem_kv[NB][2][TILE];      // [buffer][K|V][64 keys x 64]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -168,8 +179,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(QW == 
         }
     }
     const int tstride_k = ATT_KT * p.ldk * 2, tstride_v = ATT_KT * p.ldv * 2;
+    // bufc: the buffer as a compile-time constant (NB = 2: the loop is unrolled over the two buffers and the buffer is part of every LDS immediate) or as a
+    // wave-uniform run-time index (NB = 3: one loop body, six address additions per tile)
     auto stage = [&](int t, auto bufc) {
-        constexpr int buf = decltype(bufc)::value;
+        const int buf = bufc;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rk, (__attribute__((address_space(3))) void*)&smem_kv[buf][0][(wave * 2 + i) * 8 * 64], 16, vok[i],
@@ -216,12 +229,12 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(QW == 
     v8 ones;
 #pragma unroll
     for (int e = 0; e < 8; ++e) ones[e] = (T)1.0f;
+    if constexpr (LZ != 0) asm volatile("" : "+v"(ones));   // kept in four VGPRs (rebuilt from scalar registers on every tile otherwise: two v_mov_b64)
 
-    auto compute = [&](int t, auto bufc) {
-        constexpr int buf = decltype(bufc)::value;
+    // ---- S^T = K Q^T - m (C operand of the first MFMA), scaled, masked
+    auto scores = [&](f32x4 (&s_)[4][QF], int t, auto bufc) {
+        const int buf = bufc;
         const T* k_ = smem_kv[buf][0];
-        // ---- S^T = K Q^T - m
-        f32x4 s_[4][QF];
 #pragma unroll
         for (int kf = 0; kf < 4; ++kf) {
             const v8 kfrag = ABL >= 8 ? qf_[0][1] : *reinterpret_cast<const v8*>(k_ + koff[0] + kf * 16 * 64);
@@ -254,51 +267,45 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(QW == 
                     for (int f = 0; f < QF; ++f) s_[kf][f][r] += pen;
                 }
         }
-        // ---- does any reference have to move?  decided from ONE per-lane maximum over all the lane's scores
-        float mxa = -INFINITY;
-        if (ABL != 2 && ABL != 9) {
+    };
+    // the wave-uniform slow block: every reference that has to move moves, S, O, the row sums and m updated IN PLACE
+    auto move_references = [&](f32x4 (&s_)[4][QF]) {
+        bool fst = false;
 #pragma unroll
-            for (int f = 0; f < QF; ++f) {
-                const float mf = max16f(s_[0][f], s_[1][f], s_[2][f], s_[3][f]);
-                mxa = f == 0 ? mf : fmaxf(mxa, mf);
-            }
+        for (int f = 0; f < QF; ++f) {
+            float mx = fmaxf(s_[0][f][0], s_[0][f][1]);
+#pragma unroll
+            for (int kf = 0; kf < 4; ++kf)
+#pragma unroll
+                for (int r = (kf == 0 ? 2 : 0); r < 4; ++r) mx = fmaxf(mx, s_[kf][f][r]);
+            mx = quad_row_max(mx);
+            const bool first = (m_[f] == -INFINITY);
+            float d = first ? mx : fmaxf(mx, 0.f);
+            d = (d == -INFINITY) ? 0.f : d;                       // row still has no valid key
+            const float alpha = first ? 1.0f : __builtin_amdgcn_exp2f(-d);
+#pragma unroll
+            for (int kf = 0; kf < 4; ++kf) s_[kf][f] -= d;
+#pragma unroll
+            for (int dd = 0; dd < 4; ++dd) o_[dd][f] *= alpha;
+            if constexpr (LZ == 0) ol_[f] *= alpha; else ol_[f][0] *= alpha;
+            m_[f] = first ? ((mx == -INFINITY) ? -INFINITY : d) : m_[f] + d;
+            const float nm = (m_[f] == -INFINITY) ? 0.f : -m_[f] * inv_c;
+            nm_[f] = f32x4{nm, nm, nm, nm};
+            fst |= (m_[f] == -INFINITY);
         }
-        if (ABL != 2 && ABL != 9 && (any_first || __any(mxa > ATT_THR))) {   // wave-uniform, rare after the first tile: everything updated in place
-            bool fst = false;
-#pragma unroll
-            for (int f = 0; f < QF; ++f) {
-                float mx = fmaxf(s_[0][f][0], s_[0][f][1]);
-#pragma unroll
-                for (int kf = 0; kf < 4; ++kf)
-#pragma unroll
-                    for (int r = (kf == 0 ? 2 : 0); r < 4; ++r) mx = fmaxf(mx, s_[kf][f][r]);
-                mx = quad_row_max(mx);
-                const bool first = (m_[f] == -INFINITY);
-                float d = first ? mx : fmaxf(mx, 0.f);
-                d = (d == -INFINITY) ? 0.f : d;                       // row still has no valid key
-                const float alpha = first ? 1.0f : __builtin_amdgcn_exp2f(-d);
-#pragma unroll
-                for (int kf = 0; kf < 4; ++kf) s_[kf][f] -= d;
-#pragma unroll
-                for (int dd = 0; dd < 4; ++dd) o_[dd][f] *= alpha;
-                ol_[f] *= alpha;
-                m_[f] = first ? ((mx == -INFINITY) ? -INFINITY : d) : m_[f] + d;
-                const float nm = (m_[f] == -INFINITY) ? 0.f : -m_[f] * inv_c;
-                nm_[f] = f32x4{nm, nm, nm, nm};
-                fst |= (m_[f] == -INFINITY);
-            }
-            any_first = __any(fst);
-        }
+        any_first = __any(fst);
+    };
+    // P^T = exp2(S^T - m) rounded to T, as the B fragments of the second product: k-slot e of lane group g <-> keys {4g+e (e<4), 16+4g+e-4 (e>=4)}
+    // of the 32-key slot ks
+    auto probabilities = [&](f32x4 (&s_)[4][QF], v8 (&pb)[2][QF]) {
 #pragma unroll
         for (int kf = 0; kf < 4; ++kf)
 #pragma unroll
             for (int f = 0; f < QF; ++f)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) s_[kf][f][r] = ABL == 9 ? s_[kf][f][r] : (ABL == 1 ? s_[kf][f][r] * 0.001f : __builtin_amdgcn_exp2f(s_[kf][f][r]));
-        // ---- O^T += V^T P^T ; k-slot e of lane group g <-> keys {4g+e (e<4), 16+4g+e-4 (e>=4)} of the 32-key slot
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            v8 pb[QF];
+        for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
             for (int f = 0; f < QF; ++f) {
                 f32x8 pv;
@@ -307,18 +314,25 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(QW == 
                     pv[r] = s_[2 * ks][f][r];
                     pv[4 + r] = s_[2 * ks + 1][f][r];
                 }
-                if (ABL == 4 || ABL == 9) __builtin_memcpy(&pb[f], &pv, 16);   // first four fp32 words as the fragment: no conversion
-                else pb[f] = cvt8<T>(pv);
-                if (ABL == 3) { asm volatile("" ::"v"(pb[f])); continue; }
-                ol_[f] = mfma16(ones, pb[f], ol_[f]);
+                if (ABL == 4 || ABL == 9) __builtin_memcpy(&pb[ks][f], &pv, 16);   // first four fp32 words as the fragment: no conversion
+                else pb[ks][f] = cvt8<T>(pv);
             }
-            if (ABL == 3) continue;
+    };
+    auto value_product = [&](const v8 (&pb)[2][QF], auto bufc) {
+        constexpr bool rt = std::is_same<decltype(bufc), int>::value;
+        constexpr int buf = rt ? 0 : (int)decltype(to_constant(bufc))::value;
+        unsigned va[4];
+#pragma unroll
+        for (int d = 0; d < 4; ++d) va[d] = rt ? vaddr[d] + (unsigned)((int)bufc * 4 * TILE) : vaddr[d];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            if (ABL == 3) { asm volatile("" ::"v"(pb[ks][0])); continue; }
             u32x2 tr[8];
             if (ABL >= 8) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) __builtin_memcpy(&tr[e], &qf_[0][e & 1], 8);
-            } else if (ks == 0) lds_tr_x8_imm<buf * 4 * TILE, buf * 4 * TILE + 16 * 128>(vaddr[0], vaddr[1], vaddr[2], vaddr[3], tr);
-            else lds_tr_x8_imm<buf * 4 * TILE + 32 * 128, buf * 4 * TILE + 48 * 128>(vaddr[0], vaddr[1], vaddr[2], vaddr[3], tr);
+            } else if (ks == 0) lds_tr_x8_imm<buf * 4 * TILE, buf * 4 * TILE + 16 * 128>(va[0], va[1], va[2], va[3], tr);
+            else lds_tr_x8_imm<buf * 4 * TILE + 32 * 128, buf * 4 * TILE + 48 * 128>(va[0], va[1], va[2], va[3], tr);
 #pragma unroll
             for (int d = 0; d < 4; ++d) {
                 v4 lo, hi;
@@ -326,36 +340,129 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(QW == 
                 __builtin_memcpy(&hi, &tr[2 * d + 1], 8);
                 const v8 vfrag = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
 #pragma unroll
-                for (int f = 0; f < QF; ++f) o_[d][f] = mfma16(vfrag, pb[f], o_[d][f]);
+                for (int f = 0; f < QF; ++f) o_[d][f] = mfma16(vfrag, pb[ks][f], o_[d][f]);
             }
         }
     };
 
-    int t = advance(t_begin - 1);
-    if (t < t_end) stage(t, std::integral_constant<int, 0>{});
-    while (t < t_end) {
-        constexpr bool no_dma = ABL == 5 || ABL >= 7, no_bar = ABL >= 6;
-        {
-            if (!no_bar) {
-                __builtin_amdgcn_s_waitcnt(0x0f70);
-                __syncthreads();
+    auto compute = [&](int t, auto bufc) {
+        f32x4 s_[4][QF];
+        if constexpr (LZ == 0) {
+            scores(s_, t, bufc);
+            // ---- does any reference have to move?  decided from ONE per-lane maximum over all the lane's scores
+            float mxa = -INFINITY;
+            if (ABL != 2 && ABL != 9) {
+#pragma unroll
+                for (int f = 0; f < QF; ++f) {
+                    const float mf = max16f(s_[0][f], s_[1][f], s_[2][f], s_[3][f]);
+                    mxa = f == 0 ? mf : fmaxf(mxa, mf);
+                }
             }
-            const int tn = advance(t);
-            if (tn < t_end && !no_dma) stage(tn, std::integral_constant<int, 1>{});
-            compute(t, std::integral_constant<int, 0>{});
-            t = tn;
-        }
-        if (t >= t_end) break;
-        {
-            if (!no_bar) {
-                __builtin_amdgcn_s_waitcnt(0x0f70);
-                __syncthreads();
+            if (ABL != 2 && ABL != 9 && (any_first || __any(mxa > ATT_THR))) move_references(s_);   // wave-uniform, rare after the first tile
+            v8 pb[2][QF];
+            probabilities(s_, pb);
+            if (ABL != 3) {
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                    for (int f = 0; f < QF; ++f) ol_[f] = mfma16(ones, pb[ks][f], ol_[f]);
             }
-            const int tn = advance(t);
-            if (tn < t_end && !no_dma) stage(tn, std::integral_constant<int, 0>{});
-            compute(t, std::integral_constant<int, 1>{});
-            t = tn;
+            value_product(pb, bufc);
+        } else {
+            // ---- r05: no maxima in the fast path.  The tile's row sums (the `ones` MFMA on a fresh accumulator) bound every P of the tile: a sum
+            // <= ATT_LIM means no score is more than log2(ATT_LIM) above its row's reference, P fits T and the products carry on; a larger one
+            // (or an infinity / NaN out of the exp2 or the rounding) sends the wave through the slow block, which rebuilds S from the K tile that is still
+            // in LDS.  19 VALU instructions per tile (the max3 trees) become 4.
+            v8 pb[2][QF];
+            f32x4 lt[QF];
+            auto tile_sums = [&]() {
+#pragma unroll
+                for (int f = 0; f < QF; ++f) lt[f] = mfma16(ones, pb[0][f], f32x4{0.f, 0.f, 0.f, 0.f});
+#pragma unroll
+                for (int f = 0; f < QF; ++f) lt[f] = mfma16(ones, pb[1][f], lt[f]);
+            };
+            if constexpr (PR == 1) __builtin_amdgcn_s_setprio(1);
+            scores(s_, t, bufc);
+            if constexpr (PR == 1) __builtin_amdgcn_s_setprio(0);
+            bool slow = any_first;
+            if (!slow) {
+                if constexpr (PR == 2) __builtin_amdgcn_s_setprio(1);
+                probabilities(s_, pb);
+                if constexpr (PR == 2) __builtin_amdgcn_s_setprio(0);
+                tile_sums();
+                bool over = false;
+#pragma unroll
+                for (int f = 0; f < QF; ++f) over |= !(lt[f][0] <= ATT_LIM);
+                slow = __any(over);
+                if (slow) {
+                    asm volatile("" ::: "memory");   // the K fragments are READ AGAIN (kept in registers across the fast path they would cost it 32 VGPRs)
+                    scores(s_, t, bufc);
+                }
+            }
+            if (slow) {
+                move_references(s_);
+                probabilities(s_, pb);
+                tile_sums();
+            }
+#pragma unroll
+            for (int f = 0; f < QF; ++f) ol_[f][0] += lt[f][0];
+            if constexpr (PR == 1) __builtin_amdgcn_s_setprio(1);
+            value_product(pb, bufc);
+            if constexpr (PR == 1) __builtin_amdgcn_s_setprio(0);
         }
+    };
+
+    if constexpr (NB == 3) {
+        // r05: three buffers, the DMA of a tile issued TWO tiles ahead of its use (one tile ahead, a block's ~1.5 us tile period does not cover the latency of a
+        // tile fetched under load and every wave of the block waits it out at the barrier).  Loads return in order: four pieces per wave and tile, so
+        // vmcnt(4) = "tile t has landed, tile t + 1 may still be in flight".  The buffer restaged behind the barrier of tile t is the one tile t - 1 was read from.
+        int t = advance(t_begin - 1), tn = t_end;
+        if (t < t_end) {
+            stage(t, 0);
+            tn = advance(t);
+            if (tn < t_end) stage(tn, 1);
+        }
+        int b = 0;
+#pragma clang loop unroll(disable)
+        while (t < t_end) {
+            if (tn < t_end) asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+            const int tnn = tn < t_end ? advance(tn) : t_end;
+            const int b2 = b == 0 ? 2 : b - 1;
+            if (tnn < t_end) stage(tnn, b2);
+            compute(t, b);
+            t = tn;
+            tn = tnn;
+            b = b == 2 ? 0 : b + 1;
+        }
+    } else {
+        int t = advance(t_begin - 1);
+        if (t < t_end) stage(t, std::integral_constant<int, 0>{});
+        while (t < t_end) {
+            constexpr bool no_dma = ABL == 5 || ABL >= 7, no_bar = ABL >= 6;
+            {
+                if (!no_bar) {
+                    __builtin_amdgcn_s_waitcnt(0x0f70);
+                    __syncthreads();
+                }
+                const int tn = advance(t);
+                if (tn < t_end && !no_dma) stage(tn, std::integral_constant<int, 1>{});
+                compute(t, std::integral_constant<int, 0>{});
+                t = tn;
+            }
+            if (t >= t_end) break;
+            {
+                if (!no_bar) {
+                    __builtin_amdgcn_s_waitcnt(0x0f70);
+                    __syncthreads();
+                }
+                const int tn = advance(t);
+                if (tn < t_end && !no_dma) stage(tn, std::integral_constant<int, 0>{});
+                compute(t, std::integral_constant<int, 1>{});
+                t = tn;
+            }
+        }
+
     }
 
     // ---- normalise and store: lane (q = fr, g) holds O[q][d = 16 dd + 4 g + r]
@@ -1024,8 +1131,29 @@ int launch_attention_phase(DType dt, const AttnArgs& a_in, int phase, hipStream_
             else if (!small && dt == DT_F16 && qw_big == 64) M3R_LAUNCH_ATTN((attn3_kernel<f16_t, 64>));
             else
 #endif
-            if (small) { if (dt == DT_BF16) M3R_LAUNCH_ATTN((attn3_kernel<bf16_t, 16>)); else M3R_LAUNCH_ATTN((attn3_kernel<f16_t, 16>)); }
-            else { if (dt == DT_BF16) M3R_LAUNCH_ATTN((attn3_kernel<bf16_t, 32>)); else M3R_LAUNCH_ATTN((attn3_kernel<f16_t, 32>)); }
+            {
+                // M3R_ATTN_LZ (A/B instrument): 1 (default) = references move on the tile's row sums, 0 = on the per-lane score maxima (r02-r04)
+                static const int lz = getenv("M3R_ATTN_LZ") ? atoi(getenv("M3R_ATTN_LZ")) : 1;
+#ifdef M3R_ATTN_EXPERIMENTS
+                // measured and not kept (profiles/r05_attn_step_ab.txt): M3R_ATTN_NB=3 K/V tiles staged two tiles ahead through three buffers (-1.9 % on the step),
+                // M3R_ATTN_PR=1 / 2 s_setprio 1 around the MFMA clusters / the exp2 cluster (+3 % on random operands, 0 / -0.9 % on the step)
+                static const int nb = getenv("M3R_ATTN_NB") ? atoi(getenv("M3R_ATTN_NB")) : 2;
+                static const int pr = getenv("M3R_ATTN_PR") ? atoi(getenv("M3R_ATTN_PR")) : 0;
+                if (lz && pr == 1 && !small && dt == DT_F16) M3R_LAUNCH_ATTN((attn3_kernel<f16_t, 32, 0, 1, 2, 1>));
+                else if (lz && pr == 2 && !small && dt == DT_F16) M3R_LAUNCH_ATTN((attn3_kernel<f16_t, 32, 0, 1, 2, 2>));
+                else if (lz && nb == 3) {
+                    if (small) { if (dt == DT_BF16) M3R_LAUNCH_ATTN((attn3_kernel<bf16_t, 16, 0, 1, 3>)); else M3R_LAUNCH_ATTN((attn3_kernel<f16_t, 16, 0, 1, 3>)); }
+                    else { if (dt == DT_BF16) M3R_LAUNCH_ATTN((attn3_kernel<bf16_t, 32, 0, 1, 3>)); else M3R_LAUNCH_ATTN((attn3_kernel<f16_t, 32, 0, 1, 3>)); }
+                } else
+#endif
+                if (lz) {
+                    if (small) { if (dt == DT_BF16) M3R_LAUNCH_ATTN((attn3_kernel<bf16_t, 16, 0, 1>)); else M3R_LAUNCH_ATTN((attn3_kernel<f16_t, 16, 0, 1>)); }
+                    else { if (dt == DT_BF16) M3R_LAUNCH_ATTN((attn3_kernel<bf16_t, 32, 0, 1>)); else M3R_LAUNCH_ATTN((attn3_kernel<f16_t, 32, 0, 1>)); }
+                } else {
+                    if (small) { if (dt == DT_BF16) M3R_LAUNCH_ATTN((attn3_kernel<bf16_t, 16>)); else M3R_LAUNCH_ATTN((attn3_kernel<f16_t, 16>)); }
+                    else { if (dt == DT_BF16) M3R_LAUNCH_ATTN((attn3_kernel<bf16_t, 32>)); else M3R_LAUNCH_ATTN((attn3_kernel<f16_t, 32>)); }
+                }
+            }
         }
 #undef M3R_LAUNCH_ATTN
     } else if (nsplit > 1) {
