@@ -345,9 +345,142 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(QW == 
         }
     };
 
+    // ---- LZ = 2 (r05, experiment builds only: measured SLOWER, profiles/r05_attn_halves_*.txt): the two 16-query halves of the wave one stage apart, so that every exp2 / cvt cluster has an INDEPENDENT MFMA cluster next to it in the
+    // same basic block (the S product of the other half, or the P.V product of the other half) -- inside a wave, behind in-order issue, softmax VALU work only
+    // overlaps matrix work that does not depend on it:
+    //     [K fragments]  S(0)  |  S(1) || P(0), sums(0), check(0)  |  [V fragments]  O(0) += V P(0) || P(1), sums(1), check(1)  |  O(1) += V P(1)
+    // K and V fragments are read once per tile and serve both halves from registers.  The row-sum rule of LZ = 1 applies per half.
+    bool first_h[QF];
+#pragma unroll
+    for (int f = 0; f < QF; ++f) first_h[f] = true;
+    auto scores_half = [&](f32x4 (&sh)[4], const v8 (&kfr)[2][4], int f) {
+#pragma unroll
+        for (int kf = 0; kf < 4; ++kf) sh[kf] = mfma16(kfr[0][kf], qf_[f][0], nm_[f]);
+#pragma unroll
+        for (int kf = 0; kf < 4; ++kf) sh[kf] = mfma16(kfr[1][kf], qf_[f][1], sh[kf]);
+    };
+    auto read_k = [&](v8 (&kfr)[2][4], auto bufc) {
+        const int buf = bufc;
+        const T* k_ = smem_kv[buf][0];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int kf = 0; kf < 4; ++kf) kfr[ks][kf] = *reinterpret_cast<const v8*>(k_ + koff[ks] + kf * 16 * 64);
+    };
+    auto scale_mask_half = [&](f32x4 (&sh)[4], int t) {   // the rare part of a score tile: unscaled q (op entry), partial / excluded key tiles
+        if (!p.q_prescaled) {
+#pragma unroll
+            for (int kf = 0; kf < 4; ++kf) sh[kf] *= c;
+        }
+        const int k0 = t * ATT_KT;
+        if ((k0 + ATT_KT > nk) || (has_skip && k0 < shi && k0 + ATT_KT > slo)) {
+#pragma unroll
+            for (int kf = 0; kf < 4; ++kf)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int key = k0 + kf * 16 + fg * 4 + r;
+                    const bool bad = (key >= nk) | ((key >= slo) & (key < shi));
+                    sh[kf][r] += bad ? -INFINITY : 0.f;
+                }
+        }
+    };
+    auto probs_half = [&](f32x4 (&sh)[4], v8 (&pbh)[2], f32x4& lth) {
+#pragma unroll
+        for (int kf = 0; kf < 4; ++kf)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sh[kf][r] = __builtin_amdgcn_exp2f(sh[kf][r]);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            f32x8 pv;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                pv[r] = sh[2 * ks][r];
+                pv[4 + r] = sh[2 * ks + 1][r];
+            }
+            pbh[ks] = cvt8<T>(pv);
+        }
+        lth = mfma16(ones, pbh[0], f32x4{0.f, 0.f, 0.f, 0.f});
+        lth = mfma16(ones, pbh[1], lth);
+    };
+    auto move_half = [&](f32x4 (&sh)[4], int f) {
+        float mx = fmaxf(sh[0][0], sh[0][1]);
+#pragma unroll
+        for (int kf = 0; kf < 4; ++kf)
+#pragma unroll
+            for (int r = (kf == 0 ? 2 : 0); r < 4; ++r) mx = fmaxf(mx, sh[kf][r]);
+        mx = quad_row_max(mx);
+        const bool first = (m_[f] == -INFINITY);
+        float d = first ? mx : fmaxf(mx, 0.f);
+        d = (d == -INFINITY) ? 0.f : d;                       // row still has no valid key
+        const float alpha = first ? 1.0f : __builtin_amdgcn_exp2f(-d);
+#pragma unroll
+        for (int kf = 0; kf < 4; ++kf) sh[kf] -= d;
+#pragma unroll
+        for (int dd = 0; dd < 4; ++dd) o_[dd][f] *= alpha;
+        ol_[f][0] *= alpha;
+        m_[f] = first ? ((mx == -INFINITY) ? -INFINITY : d) : m_[f] + d;
+        const float nm = (m_[f] == -INFINITY) ? 0.f : -m_[f] * inv_c;
+        nm_[f] = f32x4{nm, nm, nm, nm};
+        first_h[f] = __any(m_[f] == -INFINITY);
+    };
+    // the half's P fragments stand, or the wave goes through the slow block: S of this half again from the K tile in LDS, references moved, P and sums again
+    auto settle_half = [&](f32x4 (&sh)[4], v8 (&pbh)[2], f32x4& lth, int f, int t, auto bufc) {
+        if (first_h[f] || __any(!(lth[0] <= ATT_LIM))) {
+            asm volatile("" ::: "memory");
+            v8 kfr[2][4];
+            read_k(kfr, bufc);
+            scores_half(sh, kfr, f);
+            scale_mask_half(sh, t);
+            move_half(sh, f);
+            probs_half(sh, pbh, lth);
+        }
+        ol_[f][0] += lth[0];
+    };
+
     auto compute = [&](int t, auto bufc) {
         f32x4 s_[4][QF];
-        if constexpr (LZ == 0) {
+        if constexpr (LZ == 2) {
+            static_assert(LZ != 2 || QF == 2, "skewed halves: 32 query rows per wave");
+            constexpr bool rt = std::is_same<decltype(bufc), int>::value;
+            constexpr int buf = rt ? 0 : (int)decltype(to_constant(bufc))::value;
+            const int k0 = t * ATT_KT;
+            const bool rare = !p.q_prescaled || (k0 + ATT_KT > nk) || (has_skip && k0 < shi && k0 + ATT_KT > slo);
+            f32x4 s0[4], s1[4], lt0, lt1;
+            v8 pb0[2], pb1[2];
+            {
+                v8 kfr[2][4];
+                read_k(kfr, bufc);
+                scores_half(s0, kfr, 0);
+                if (rare) scale_mask_half(s0, t);
+                scores_half(s1, kfr, 1);            // || the exp2 / cvt of half 0
+                probs_half(s0, pb0, lt0);
+            }
+            settle_half(s0, pb0, lt0, 0, t, bufc);
+            if (rare) scale_mask_half(s1, t);
+            u32x2 tr[2][8];
+            lds_tr_x8_imm<buf * 4 * TILE, buf * 4 * TILE + 16 * 128>(vaddr[0], vaddr[1], vaddr[2], vaddr[3], tr[0]);
+            lds_tr_x8_imm<buf * 4 * TILE + 32 * 128, buf * 4 * TILE + 48 * 128>(vaddr[0], vaddr[1], vaddr[2], vaddr[3], tr[1]);
+            v8 vfr[2][4];
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    v4 lo, hi;
+                    __builtin_memcpy(&lo, &tr[ks][2 * d], 8);
+                    __builtin_memcpy(&hi, &tr[ks][2 * d + 1], 8);
+                    vfr[ks][d] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                }
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int d = 0; d < 4; ++d) o_[d][0] = mfma16(vfr[ks][d], pb0[ks], o_[d][0]);      // || the exp2 / cvt of half 1
+            probs_half(s1, pb1, lt1);
+            settle_half(s1, pb1, lt1, 1, t, bufc);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int d = 0; d < 4; ++d) o_[d][1] = mfma16(vfr[ks][d], pb1[ks], o_[d][1]);
+        } else if constexpr (LZ == 0) {
             scores(s_, t, bufc);
             // ---- does any reference have to move?  decided from ONE per-lane maximum over all the lane's scores
             float mxa = -INFINITY;
@@ -1144,6 +1277,8 @@ int launch_attention_phase(DType dt, const AttnArgs& a_in, int phase, hipStream_
                 else if (lz && nb == 3) {
                     if (small) { if (dt == DT_BF16) M3R_LAUNCH_ATTN((attn3_kernel<bf16_t, 16, 0, 1, 3>)); else M3R_LAUNCH_ATTN((attn3_kernel<f16_t, 16, 0, 1, 3>)); }
                     else { if (dt == DT_BF16) M3R_LAUNCH_ATTN((attn3_kernel<bf16_t, 32, 0, 1, 3>)); else M3R_LAUNCH_ATTN((attn3_kernel<f16_t, 32, 0, 1, 3>)); }
+                } else if (lz == 2 && !small) {   // M3R_ATTN_LZ=2: the two 16-query halves of a wave one stage apart (32-row form only): -3.5 % on the render launch, -1 % on the step
+                    if (dt == DT_BF16) M3R_LAUNCH_ATTN((attn3_kernel<bf16_t, 32, 0, 2>)); else M3R_LAUNCH_ATTN((attn3_kernel<f16_t, 32, 0, 2>));
                 } else
 #endif
                 if (lz) {
