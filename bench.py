@@ -292,7 +292,7 @@ def main():
     if gemm_ms >= attn_ms:
         a = {f: sum(prof[c][f] for c in ("gemm128", "gemm64") if c in prof) for f in ("ms", "flops", "calls")}
         ach = a["flops"] / (a["ms"] * 1e-3) / 1e12 if a["ms"] > 0 else 0.0
-        roofline = {"bound": "mfma", "kernel": "GEMM family (every out = epi(A W^T + b) launch of the step: gemm256k / gemm256 / gemm_kernel / gemm96 / gemm48 symbols)",
+        roofline = {"bound": "mfma", "kernel": "GEMM family (every out = epi(A W^T + b) launch of the step: gemm256p / gemm256s / gemm256k / gemm256 / gemm_kernel / gemm96 / gemm48 symbols)",
                     "achieved": round(ach, 1), "peak": PEAK_TFLOPS[args.precision], "unit": "TFLOP/s", "frac": round(ach / PEAK_TFLOPS[args.precision], 4),
                     "traffic": None,
                     "ms_per_step": round(a["ms"], 3), "share_of_step_kernel_time": round(a["ms"] / max(1e-9, sum(v["ms"] for k, v in prof.items() if k != "_kernels")), 4),
