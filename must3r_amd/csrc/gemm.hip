@@ -1618,155 +1618,9 @@ static int launch_256p(const GemmArgs& a, hipStream_t s) {
     return hipGetLastError() == hipSuccess ? 0 : 1;
 }
 
-// ------------------------------------------------------------------------------------------------------------------
-// gemm256n_kernel (r05): plain weights, 256 x 256 tile, ONE phase per K-tile: the two wave groups alternate between a load interval (all 24 fragment reads of a
-// K-tile + the 8 DMA pieces of the next one) and a multiply interval of 64 MFMAs -- half the hand-overs of gemm256p_kernel's two phases per K-tile (each costs
-// ~135 cycles with the matrix pipe empty, profiles/r05_gemm256p_trace.txt) and multiply intervals twice as long as the load intervals need.
-//   Two 64 KB buffers are enough although a K-tile is read and its buffer restaged within one phase, because the groups wait at different points:
-//     group 0 (load interval of K-tile t between barriers #2t-1 and #2t):  stage t+1, read t | #2t | 64 MFMAs, vmcnt(0) | #2t+1
-//     group 1 (one barrier behind):                                       stage t+1, read t, vmcnt(0) | #2t+1 | 64 MFMAs | #2t+2
-//   RAW  K-tile t+1 is read by group 0 after #2t+1: group 0 waited for its pieces at the end of its multiply interval (issued a whole interval earlier), group 1
-//        at the end of its load interval (issued at its start; the interval lasts as long as group 0's 64 MFMAs, ~1100 cycles).
-//   WAR  the buffer of K-tile t+1 held K-tile t-1, read by both groups one phase earlier and retired (lgkmcnt 0) in front of the barriers that end those intervals.
-// Same accumulation order per output as every other tile shape: identical bits.
-template <class T, int EPI>
-__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) gemm256n_kernel(const GemmArgs p) {
-    typedef typename Vec<T>::v8 v8;
-    constexpr int BM = 256, BN = 256, BK = 64;
-    constexpr int WN = 64, MF = 8, NF = 4;
-    constexpr unsigned BUFB = 512 * 128;                   // A [256][64] then W [256][64], 128-byte rows
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wave >> 2, wc = wave & 3;
-
-    const int nbn = p.N / BN;
-    const int nbm = (p.M + BM - 1) / BM;
-    const int nwg = nbm * nbn;
-    int bid = blockIdx.x;
-    {
-        const int xcd = bid & 7, slot = bid >> 3;
-        const int q = nwg >> 3, r = nwg & 7;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
-    }
-    constexpr int GM = 4;
-    const int tpg = GM * nbn;
-    const int gidx = bid / tpg;
-    const int gfirst = gidx * GM;
-    const int gsz = (nbm - gfirst < GM) ? nbm - gfirst : GM;
-    const int gin = bid - gidx * tpg;
-    const int m0 = (gfirst + gin % gsz) * BM;
-    const int n0 = (gin / gsz) * BN;
-
-    const int grp = blockIdx.y;
-    const T* __restrict__ A = reinterpret_cast<const T*>(p.A) + (size_t)grp * p.strideA;
-    const int wgrp = p.wdiv > 1 ? grp / p.wdiv : grp;
-    const T* __restrict__ W = reinterpret_cast<const T*>(p.W) + (size_t)wgrp * p.strideW;
-    const float* __restrict__ bias = p.bias ? p.bias + (size_t)wgrp * p.strideB : nullptr;
-    void* const outp = p.out_table ? p.out_table[grp] : p.out;
-
-    const int srow = lane >> 3, pch = lane & 7;
-    const T* a_src[4];
-    const T* w_src[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int r = (wave * 4 + q) * 8 + srow;
-        int gr = m0 + r;
-        gr = gr < p.M ? gr : p.M - 1;
-        a_src[q] = A + (size_t)gr * p.lda + swz(r, pch) * 8;
-        w_src[q] = W + (size_t)(n0 + r) * (size_t)p.K + swz(r, pch) * 8;
-    }
-    auto stage = [&](int kt) {
-        char* const base = smem + (kt & 1) * BUFB + wave * 4096;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) glds16(a_src[q] + (size_t)kt * BK, base + q * 1024);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) glds16(w_src[q] + (size_t)kt * BK, base + 32768 + q * 1024);
-    };
-
-    f32x4 acc[MF][NF];
-#pragma unroll
-    for (int i = 0; i < MF; ++i)
-#pragma unroll
-        for (int j = 0; j < NF; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    const int fr = lane & 15, fg = lane >> 4;
-    const int nk = p.K / BK;
-    unsigned a_lane[2], w_lane[2];
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-        const int ra = wr * 128 + fr, rw = wc * WN + fr;
-        a_lane[ks] = (unsigned)(ra * 128 + swz(ra, ks * 4 + fg) * 16);
-        w_lane[ks] = 32768u + (unsigned)(rw * 128 + swz(rw, ks * 4 + fg) * 16);
-    }
-    v8 af[2][MF], wf[2][NF];
-    auto reads = [&](int t) {
-        const unsigned bufb = (t & 1) * BUFB;
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-#pragma unroll
-            for (int j = 0; j < NF; ++j) wf[ks][j] = *reinterpret_cast<const v8*>(smem + bufb + w_lane[ks] + j * 2048);
-#pragma unroll
-            for (int i = 0; i < MF; ++i) af[ks][i] = *reinterpret_cast<const v8*>(smem + bufb + a_lane[ks] + i * 2048);
-        }
-    };
-    auto mma = [&]() {
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-            for (int i = 0; i < MF; ++i)
-#pragma unroll
-                for (int j = 0; j < NF; ++j) acc[i][j] = mfma16(wf[ks][j], af[ks][i], acc[i][j]);
-        __builtin_amdgcn_s_setprio(0);
-    };
-#define M3R_N_BAR() do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); } while (0)
-
-    stage(0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    if (wr == 0) {
-        for (int t = 0; t < nk; ++t) {
-            if (t + 1 < nk) stage(t + 1);
-            reads(t);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            M3R_N_BAR();
-            mma();
-            __builtin_amdgcn_sched_barrier(0);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            M3R_N_BAR();
-        }
-        __builtin_amdgcn_s_barrier();
-    } else {
-        __builtin_amdgcn_s_barrier();   // one barrier behind
-        for (int t = 0; t < nk; ++t) {
-            if (t + 1 < nk) stage(t + 1);
-            reads(t);
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-            M3R_N_BAR();
-            mma();
-            M3R_N_BAR();
-        }
-    }
-#undef M3R_N_BAR
-
-    epilogue_tile<T, EPI, NF, MF, 4, false>(p, outp, bias, m0 + wr * 128 + fr, n0 + wc * WN, fg, acc, NoLnFold{});
-}
-
-template <class T, int EPI>
-static int launch_256n(const GemmArgs& a, hipStream_t s) {
-    const int nbn = a.N / 256, nbm = (a.M + 255) / 256;
-    const size_t lds = (size_t)2 * 512 * 128;
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256n_kernel<T, EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return 1;
-        attr_set = true;
-    }
-    hipLaunchKernelGGL((gemm256n_kernel<T, EPI>), dim3(nbm * nbn, a.batch > 1 ? a.batch : 1), dim3(512), lds, s, a);
-    return hipGetLastError() == hipSuccess ? 0 : 1;
-}
+#ifdef M3R_GEMM_LAB   // gemm256n_kernel: one phase per K-tile (measured equal; scripts/probes/kloop_lab.hip)
+#include "lab/gemm256n.inc"
+#endif
 
 // ------------------------------------------------------------------------------------------------------------------
 // gemm256s_kernel (r05): split weights with a 2:4-sparse low part on 256 x 256 tiles -- gemm256p_kernel's two-phase K loop with FIVE half-tiles per K-tile.
@@ -1984,611 +1838,9 @@ static int launch_256s(const GemmArgs& a, hipStream_t s) {
     return hipGetLastError() == hipSuccess ? 0 : 1;
 }
 
-// ------------------------------------------------------------------------------------------------------------------
-// gemm256pp_kernel (r05): gemm256p_kernel's K loop (two phases per K-tile, two barriers per phase) as a PERSISTENT tile loop: 256 blocks, block b
-// works through tiles b, b + 256, ... (the XCD-aware order of the other kernels applied to that virtual block id: b + 256 k runs on the XCD of b).
-//   Why: a 256 x 256 tile of a K = 768..1024 GEMM is a ~25 us K loop inside ~32 us of block life -- dispatch of the next block, its address set-up, the
-//   first DMA round trip (~1.5-2 us during which the CU does nothing) and the epilogue.  Here the K loop runs on ACROSS the tile boundary: the last two
-//   K-tiles of a tile stage the first two K-tiles of the block's next tile in exactly the slots and with exactly the counted waits the steady state uses
-//   (as if the K sequence continued), so that the next tile's first fragments are in the LDS when the epilogue's last store goes out.
-//   Tile boundary: group 0's closing barrier, the epilogue of all eight waves side by side (were the groups left one barrier apart their epilogues would
-//   serialise behind the hand-over barriers), accumulators cleared, group 1's opening barrier.
-//   vmcnt counts loads AND stores in order, so a counted wait behind the epilogue's stores would wait for their acknowledgement: the last K-tile of a tile
-//   therefore also retires A1 of the next tile's first K-tile (vmcnt 4 instead of 6) and that K-tile's first phase carries no wait at all; its second
-//   phase's wait sits a phase (~0.7 us) behind the last store.
-// Operand addresses are 32-bit byte offsets on the wave-uniform matrix bases (current and next tile: 16 registers); launch_256pp refuses larger matrices,
-// K < 256 and grouped launches.  Same accumulation order per output as every other tile shape: identical bits.
-template <class T, int EPI, int WS, int BN>
-__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) gemm256pp_kernel(const GemmArgs p) {
-    typedef typename Vec<T>::v8 v8;
-    constexpr int BM = 256, BK = 64;
-    static_assert(WS * BN == 256, "the staged weight region is 256 rows: 256 plain columns or 128 columns hi + lo");
-    constexpr int WN = BN / 4, MF = 8, NF = WN / 16;
-    constexpr unsigned HALFB = 128 * BK * 2;
-    constexpr unsigned BUFB = 4 * HALFB;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wave >> 2, wc = wave & 3;
-
-    const int nbn = p.N / BN;
-    const int nbm = (p.M + BM - 1) / BM;
-    const int nwg = nbm * nbn;
-    const int nblk = (int)gridDim.x;
-    // virtual block id -> tile origin (the remap and grouped order of gemm256k_kernel / gemm256p_kernel)
-    auto tile_of = [&](int vb, int& m0, int& n0) {
-        const int xcd = vb & 7, slot = vb >> 3;
-        const int q = nwg >> 3, r = nwg & 7;
-        const int bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
-        constexpr int GM = 4;
-        const int tpg = GM * nbn;
-        const int gidx = bid / tpg;
-        const int gfirst = gidx * GM;
-        const int gsz = (nbm - gfirst < GM) ? nbm - gfirst : GM;
-        const int gin = bid - gidx * tpg;
-        m0 = (gfirst + gin % gsz) * BM;
-        n0 = (gin / gsz) * BN;
-    };
-
-    const char* __restrict__ A = reinterpret_cast<const char*>(p.A);
-    const char* __restrict__ W = reinterpret_cast<const char*>(p.W);
-    const float* __restrict__ bias = p.bias;
-    void* const outp = p.out;
-
-    // ---- staging: a wave moves pieces 2 wave, 2 wave + 1 (8 rows x 128 B each) of every half-tile; 32-bit byte offsets, [half][piece]
-    const int srow = lane >> 3, pch = lane & 7;
-    unsigned a_cur[2][2], w_cur[2][2], a_nxt[2][2], w_nxt[2][2];
-    auto offsets = [&](int m0, int n0, unsigned (&ao)[2][2], unsigned (&wo)[2][2]) {
-#pragma unroll
-        for (int h = 0; h < 2; ++h)
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int hr = (wave * 2 + j) * 8 + srow;
-                int gr = m0 + (hr >> 6) * 128 + h * 64 + (hr & 63);
-                gr = gr < p.M ? gr : p.M - 1;
-                ao[h][j] = (unsigned)gr * (unsigned)(p.lda * 2) + (unsigned)(swz(hr, pch) * 16);
-                if constexpr (WS == 1) {
-                    const int col = (hr >> 5) * 64 + h * 32 + (hr & 31);
-                    wo[h][j] = (unsigned)(n0 + col) * (unsigned)(p.K * 2) + (unsigned)(swz(hr, pch) * 16);
-                } else {
-                    wo[h][j] = (unsigned)(n0 + hr) * (unsigned)(p.K * 4) + (unsigned)h * (unsigned)(p.K * 2) + (unsigned)(swz(hr, pch) * 16);
-                }
-            }
-    };
-    // which: 0 A0, 1 A1, 2 B0, 3 B1; kt: K-tile of the tile the offsets belong to; par: LDS buffer of that K-tile
-    auto stage = [&](auto whichc, const unsigned (&ao)[2][2], const unsigned (&wo)[2][2], int kt, int par) {
-        constexpr int which = decltype(whichc)::value;
-        char* const base = smem + par * BUFB + which * HALFB + wave * 2048;
-        const char* const src = (which < 2 ? A : W) + (size_t)kt * (BK * 2);
-#pragma unroll
-        for (int j = 0; j < 2; ++j) glds16(src + (which < 2 ? ao[which & 1][j] : wo[which & 1][j]), base + j * 1024);
-    };
-    typedef std::integral_constant<int, 0> HA0;
-    typedef std::integral_constant<int, 1> HA1;
-    typedef std::integral_constant<int, 2> HB0;
-    typedef std::integral_constant<int, 3> HB1;
-
-    f32x4 acc[MF][NF];
-    const int fr = lane & 15, fg = lane >> 4;
-    const int nk = p.K / BK;
-    unsigned a_lane[2], w_lane[2];
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-        const int ra = wr * 64 + fr, rw = wc * 32 + fr;
-        a_lane[ks] = (unsigned)(ra * 128 + swz(ra, ks * 4 + fg) * 16);
-        w_lane[ks] = 2 * HALFB + (unsigned)(rw * 128 + swz(rw, ks * 4 + fg) * 16);
-    }
-    v8 af[2][4], bf[2][2][2];
-    auto read_a = [&](int h, unsigned bufb) {
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) af[ks][i] = *reinterpret_cast<const v8*>(smem + bufb + h * HALFB + a_lane[ks] + i * 2048);
-    };
-    auto read_b = [&](auto gc, unsigned bufb) {
-        constexpr int g = decltype(gc)::value;
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-            for (int j = 0; j < 2; ++j) bf[g][ks][j] = *reinterpret_cast<const v8*>(smem + bufb + g * HALFB + w_lane[ks] + j * 2048);
-    };
-    auto mma_h = [&](auto hc) {
-        constexpr int h = decltype(hc)::value;
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-            for (int g = 0; g < 2; ++g)
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) {
-                        if constexpr (WS == 1) acc[h * 4 + i][g * 2 + j] = mfma16(bf[g][ks][j], af[ks][i], acc[h * 4 + i][g * 2 + j]);
-                        else acc[h * 4 + i][j] = mfma16(bf[g][ks][j], af[ks][i], acc[h * 4 + i][j]);
-                    }
-        __builtin_amdgcn_s_setprio(0);
-    };
-    typedef std::integral_constant<int, 0> I0;
-    typedef std::integral_constant<int, 1> I1;
-#define M3R_VMCNT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
-#define M3R_P_LOAD_END() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); } while (0)
-#define M3R_P_MUL_END() do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); } while (0)
-
-    // One K-tile.  par = LDS buffer of K-tile t.  MODE: 0 steady (t + 2 < nk) | 1 t = nk - 2, a next tile follows | 2 t = nk - 1, a next tile follows |
-    //                  3 t = nk - 2, last tile | 4 t = nk - 1, last tile.  FIRSTK: t = 0 of a tile entered across a boundary (its A1 is already retired).
-    auto ktile = [&](auto modec, auto firstc, int t, int par) {
-        constexpr int MODE = decltype(modec)::value;
-        constexpr bool FIRSTK = decltype(firstc)::value;
-        const unsigned bufb = par * BUFB;
-        // phase 0: a0 x (b0, b1); stages B1, A1 of the next K-tile; A1 of this K-tile landed
-        read_a(0, bufb); read_b(I0{}, bufb); read_b(I1{}, bufb);
-        if constexpr (MODE == 0 || MODE == 1 || MODE == 3) { stage(HB1{}, a_cur, w_cur, t + 1, par ^ 1); stage(HA1{}, a_cur, w_cur, t + 1, par ^ 1); }
-        else if constexpr (MODE == 2) { stage(HB1{}, a_nxt, w_nxt, 0, par ^ 1); stage(HA1{}, a_nxt, w_nxt, 0, par ^ 1); }
-        if constexpr (!FIRSTK) M3R_VMCNT(MODE == 4 ? 0 : 8);
-        M3R_P_LOAD_END(); mma_h(I0{}); M3R_P_MUL_END();
-        // phase 1: a1 x (b0, b1); stages A0, B0 of the K-tile after next; A0, B0, B1 of the next K-tile landed
-        read_a(1, bufb);
-        if constexpr (MODE == 0) { stage(HA0{}, a_cur, w_cur, t + 2, par); stage(HB0{}, a_cur, w_cur, t + 2, par); }
-        else if constexpr (MODE == 1) { stage(HA0{}, a_nxt, w_nxt, 0, par); stage(HB0{}, a_nxt, w_nxt, 0, par); }
-        else if constexpr (MODE == 2) { stage(HA0{}, a_nxt, w_nxt, 1, par); stage(HB0{}, a_nxt, w_nxt, 1, par); }
-        if constexpr (MODE == 0 || MODE == 1) M3R_VMCNT(6);
-        else if constexpr (MODE == 2) M3R_VMCNT(4);   // ... and A1 of the next tile's first K-tile: no counted wait right behind the epilogue's stores
-        else if constexpr (MODE == 3) M3R_VMCNT(2);
-        M3R_P_LOAD_END(); mma_h(I1{}); M3R_P_MUL_END();
-    };
-    typedef std::integral_constant<int, 0> M0_;
-    typedef std::integral_constant<int, 1> M1_;
-    typedef std::integral_constant<int, 2> M2_;
-    typedef std::integral_constant<int, 3> M3_;
-    typedef std::integral_constant<int, 4> M4_;
-
-    int vb = (int)blockIdx.x;
-    int m0, n0;
-    tile_of(vb, m0, n0);
-    offsets(m0, n0, a_cur, w_cur);
-    // ---- prologue of the block's first tile: what the steady state would have issued before K-tile 0
-    stage(HA0{}, a_cur, w_cur, 0, 0); stage(HB0{}, a_cur, w_cur, 0, 0); stage(HB1{}, a_cur, w_cur, 0, 0); stage(HA1{}, a_cur, w_cur, 0, 0);
-    stage(HA0{}, a_cur, w_cur, 1, 1); stage(HB0{}, a_cur, w_cur, 1, 1);
-    M3R_VMCNT(6);
-    __builtin_amdgcn_s_barrier();
-    int par = 0;          // LDS buffer of the current tile's K-tile 0
-    bool first = true;    // the block's first tile: its K-tile 0 carries the steady-state wait for its own A1
-    for (;;) {
-        const int vnext = vb + nblk;
-        const bool more = vnext < nwg;
-#pragma unroll
-        for (int i = 0; i < MF; ++i)
-#pragma unroll
-            for (int j = 0; j < NF; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (wr == 1) __builtin_amdgcn_s_barrier();   // group 1 runs one barrier behind
-        int t = 0;
-        if (first) ktile(M0_{}, std::false_type{}, 0, par);
-        else ktile(M0_{}, std::true_type{}, 0, par);
-        for (t = 1; t + 2 < nk; ++t) ktile(M0_{}, std::false_type{}, t, par ^ (t & 1));
-        int m1 = 0, n1 = 0;
-        if (more) {
-            // the next tile's operand offsets live for these two K-tiles only (kept across the epilogue they push its register allocation into scratch)
-            tile_of(vnext, m1, n1);
-            offsets(m1, n1, a_nxt, w_nxt);
-            ktile(M1_{}, std::false_type{}, t, par ^ (t & 1)); ++t;
-            ktile(M2_{}, std::false_type{}, t, par ^ (t & 1));
-        } else {
-            ktile(M3_{}, std::false_type{}, t, par ^ (t & 1)); ++t;
-            ktile(M4_{}, std::false_type{}, t, par ^ (t & 1));
-        }
-        if (wr == 0) __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-        epilogue_tile<T, EPI, NF, MF, 4, false>(p, outp, bias, m0 + wr * 128 + fr, n0 + wc * WN, fg, acc, NoLnFold{});
-        __builtin_amdgcn_sched_barrier(0);
-        if (!more) break;
-        par ^= (nk & 1);
-        vb = vnext;
-        m0 = __builtin_amdgcn_readfirstlane(m1); n0 = __builtin_amdgcn_readfirstlane(n1);
-        offsets(m0, n0, a_cur, w_cur);   // recomputed (a few integer instructions per tile) instead of carried through the epilogue
-        first = false;
-    }
-#undef M3R_VMCNT
-#undef M3R_P_LOAD_END
-#undef M3R_P_MUL_END
-}
-
-template <class T, int EPI, int WS, int BN>
-static int launch_256pp(const GemmArgs& a, hipStream_t s) {
-    if ((unsigned long long)a.M * (unsigned long long)a.lda * 2ull >= (1ull << 32) || (unsigned long long)a.N * (unsigned long long)a.K * WS * 2ull >= (1ull << 32)) return 2;
-    if (a.batch > 1 || a.K < 256 || a.out_table != nullptr) return 2;
-    const int nbn = a.N / BN, nbm = (a.M + 255) / 256;
-    const int nwg = nbm * nbn;
-    const size_t lds = (size_t)2 * 4 * 128 * 64 * sizeof(T);
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256pp_kernel<T, EPI, WS, BN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return 1;
-        attr_set = true;
-    }
-    hipLaunchKernelGGL((gemm256pp_kernel<T, EPI, WS, BN>), dim3(nwg < 256 ? nwg : 256), dim3(512), lds, s, a);
-    return hipGetLastError() == hipSuccess ? 0 : 1;
-}
-
-// ------------------------------------------------------------------------------------------------------------------
-// gemm256q_kernel (r05): the same tile and 64-deep K-tiles with ONE barrier per K-tile.
-//   What the cycle trace of gemm256p_kernel says (profiles/r05_gemm256p_trace.txt; the same numbers for ONE tile on an idle chip, so it is not
-//   the memory system): a K-tile takes ~2750 cycles where its 128 MFMAs per SIMD need 2048; the multiply intervals themselves run at ~17.2 cycles
-//   per MFMA (one wave issuing alone), and every one of the four hand-overs per K-tile costs ~120-140 cycles in which the matrix pipe is empty
-//   -- the release latency of an eight-wave s_barrier, paid with every wave of the CU parked.  A blocking barrier cannot be hidden (whoever
-//   executes it stops), so this kernel executes one per K-tile instead of four:
-//     every wave, between two barriers:  issue the 8 DMA pieces of K-tile t+1 (its buffer was last read in the previous interval)  ...  vmcnt(0)
-//     group 0:  read ALL fragments of K-tile t, then its 64 MFMAs;
-//     group 1:  its 64 MFMAs of K-tile t-1 (fragments read at the end of the last interval), then read all fragments of K-tile t.
-//   The two waves of a SIMD are half a K-tile apart by construction; who multiplies when both could is decided by priority (VAR bit 0: group 1's
-//   block outranks group 0's, so the blocks serialise without a barrier between them) or left to the arbiter.
-//   RAW  K-tile t+1 is waited for (vmcnt 0) by every wave at the end of interval t and read in interval t+1.
-//   WAR  its buffer held K-tile t-1, read in interval t-1 by both groups (group 1 at its end, lgkmcnt 0 in front of the barrier).
-// Operand addresses are 32-bit byte offsets on the wave-uniform matrix bases (8 registers instead of 16 pointers; launch_256q refuses larger matrices).
-// Same accumulation order per output as every other tile shape: identical bits.
-template <class T, int EPI, int WS, int BN, int VAR>
-__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) gemm256q_kernel(const GemmArgs p) {
-    typedef typename Vec<T>::v8 v8;
-    constexpr int BM = 256, BK = 64;
-    static_assert(WS * BN == 256, "the staged weight region is 256 rows");
-    constexpr int WN = BN / 4, MF = 8, NF = WN / 16;
-    constexpr unsigned BUFB = 512 * 128;                   // A [256][64] then W [256][64], 128-byte rows
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wave >> 2, wc = wave & 3;
-
-    const int nbn = p.N / BN;
-    const int nbm = (p.M + BM - 1) / BM;
-    const int nwg = nbm * nbn;
-    int bid = blockIdx.x;
-    {
-        const int xcd = bid & 7, slot = bid >> 3;
-        const int q = nwg >> 3, r = nwg & 7;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
-    }
-    constexpr int GM = 4;
-    const int tpg = GM * nbn;
-    const int gidx = bid / tpg;
-    const int gfirst = gidx * GM;
-    const int gsz = (nbm - gfirst < GM) ? nbm - gfirst : GM;
-    const int gin = bid - gidx * tpg;
-    const int m0 = (gfirst + gin % gsz) * BM;
-    const int n0 = (gin / gsz) * BN;
-
-    const int grp = blockIdx.y;
-    const char* __restrict__ A = reinterpret_cast<const char*>(reinterpret_cast<const T*>(p.A) + (size_t)grp * p.strideA);
-    const int wgrp = p.wdiv > 1 ? grp / p.wdiv : grp;
-    const char* __restrict__ W = reinterpret_cast<const char*>(reinterpret_cast<const T*>(p.W) + (size_t)wgrp * p.strideW);
-    const float* __restrict__ bias = p.bias ? p.bias + (size_t)wgrp * p.strideB : nullptr;
-    void* const outp = p.out_table ? p.out_table[grp] : p.out;
-
-    // ---- staging: a wave moves pieces 4 wave .. 4 wave + 3 (8 rows x 128 B each) of the A region and of the W region
-    const int srow = lane >> 3, pch = lane & 7;
-    unsigned a_off[4], w_off[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int r = (wave * 4 + q) * 8 + srow;
-        int gr = m0 + r;
-        gr = gr < p.M ? gr : p.M - 1;
-        a_off[q] = (unsigned)gr * (unsigned)(p.lda * 2) + (unsigned)(swz(r, pch) * 16);
-        const int part = r / BN, wrow = r - part * BN;
-        w_off[q] = (unsigned)(n0 + wrow) * (unsigned)(p.K * WS * 2) + (unsigned)part * (unsigned)(p.K * 2) + (unsigned)(swz(r, pch) * 16);
-    }
-    auto stage = [&](int kt) {
-        char* const base = smem + (kt & 1) * BUFB + wave * 4096;
-        const char* const Ak = A + (size_t)kt * (BK * 2);
-        const char* const Wk = W + (size_t)kt * (BK * 2);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) glds16(Ak + a_off[q], base + q * 1024);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) glds16(Wk + w_off[q], base + 32768 + q * 1024);
-    };
-
-    f32x4 acc[MF][NF];
-#pragma unroll
-    for (int i = 0; i < MF; ++i)
-#pragma unroll
-        for (int j = 0; j < NF; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    const int fr = lane & 15, fg = lane >> 4;
-    const int nk = p.K / BK;
-    unsigned a_lane[2], w_lane[2];
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-        const int ra = wr * 128 + fr, rw = wc * WN + fr;
-        a_lane[ks] = (unsigned)(ra * 128 + swz(ra, ks * 4 + fg) * 16);
-        w_lane[ks] = 32768u + (unsigned)(rw * 128 + swz(rw, ks * 4 + fg) * 16);
-    }
-    v8 af[2][MF], wf[2][WS][NF];
-    auto reads = [&](int t) {
-        const unsigned bufb = (t & 1) * BUFB;
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-#pragma unroll
-            for (int part = 0; part < WS; ++part)
-#pragma unroll
-                for (int j = 0; j < NF; ++j) wf[ks][part][j] = *reinterpret_cast<const v8*>(smem + bufb + w_lane[ks] + (part * BN + j * 16) * 128);
-#pragma unroll
-            for (int i = 0; i < MF; ++i) af[ks][i] = *reinterpret_cast<const v8*>(smem + bufb + a_lane[ks] + i * 2048);
-        }
-    };
-    auto mma = [&](auto prioc) {
-        constexpr int PRIO = decltype(prioc)::value;
-        __builtin_amdgcn_s_setprio(PRIO);
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-            for (int part = 0; part < WS; ++part)
-#pragma unroll
-                for (int i = 0; i < MF; ++i)
-#pragma unroll
-                    for (int j = 0; j < NF; ++j) acc[i][j] = mfma16(wf[ks][part][j], af[ks][i], acc[i][j]);
-        __builtin_amdgcn_s_setprio(0);
-    };
-    typedef std::integral_constant<int, 1> P1;
-    typedef std::integral_constant<int, (VAR & 1) ? 2 : 1> PG1;
-#define M3R_Q_END() do { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); } while (0)
-#define M3R_Q_LGKM() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
-
-    stage(0);
-    M3R_Q_END();
-    if ((VAR & 4) || wr == 0) {
-        for (int t = 0; t < nk; ++t) {
-            if constexpr (!(VAR & 8)) { if (t + 1 < nk) stage(t + 1); }
-            reads(t);
-            if constexpr ((VAR & 8) != 0) { if (t + 1 < nk) stage(t + 1); }
-            M3R_Q_LGKM();
-            mma(P1{});
-            __builtin_amdgcn_sched_barrier(0);
-            M3R_Q_END();
-        }
-    } else {
-        if (nk > 1) stage(1);
-        reads(0);
-        M3R_Q_LGKM();
-        M3R_Q_END();
-        for (int t = 1; t < nk; ++t) {
-            if (t + 1 < nk) stage(t + 1);
-            __builtin_amdgcn_sched_barrier(0);
-            mma(PG1{});
-            __builtin_amdgcn_sched_barrier(0);
-            reads(t);
-            M3R_Q_LGKM();
-            M3R_Q_END();
-        }
-        mma(PG1{});
-    }
-#undef M3R_Q_END
-#undef M3R_Q_LGKM
-
-    epilogue_tile<T, EPI, NF, MF, 4, false>(p, outp, bias, m0 + wr * 128 + fr, n0 + wc * WN, fg, acc, NoLnFold{});
-}
-
-template <class T, int EPI, int WS, int BN, int VAR>
-static int launch_256q(const GemmArgs& a, hipStream_t s) {
-    // 32-bit operand offsets: the last byte of either matrix must be addressable from its base
-    if ((unsigned long long)a.M * (unsigned long long)a.lda * 2ull >= (1ull << 32) || (unsigned long long)a.N * (unsigned long long)a.K * WS * 2ull >= (1ull << 32)) return 2;
-    const int nbn = a.N / BN, nbm = (a.M + 255) / 256;
-    const size_t lds = (size_t)2 * 512 * 128;
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256q_kernel<T, EPI, WS, BN, VAR>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return 1;
-        attr_set = true;
-    }
-    hipLaunchKernelGGL((gemm256q_kernel<T, EPI, WS, BN, VAR>), dim3(nbm * nbn, a.batch > 1 ? a.batch : 1), dim3(512), lds, s, a);
-    return hipGetLastError() == hipSuccess ? 0 : 1;
-}
-
-// ------------------------------------------------------------------------------------------------------------------
-// gemm256w_kernel (r05): 256 x BN tile, FOUR waves -- one per SIMD, 512 registers each -- with 128 x (BN / 2) wave tiles: the structure of the vendor
-// library's kernel for these shapes (rocprofv3 names it Custom_Cijk_..._MT256x256x64_MI16x16x1, profiles/r05_vendor_kernel_names.txt; 1376 TF/s at
-// M = 15360, N = 3072, K = 4096 on the box where gemm256p reaches 1131 and gemm256k 1073, profiles/r05_vendor_yardstick.txt).
-//   Why one wave per SIMD: with two, every form measured in r03-r05 loses the matrix pipe somewhere -- both waves in the vector-memory front end at
-//   once (gemm256k), the eight-wave hand-over (gemm256 / gemm256p: ~2700 cycles per K-tile for 2048 of MFMA work), or two waves multiplying side by
-//   side (gemm256p SYNC = 1, gemm256q: slower still).  A single wave owns its SIMD's matrix pipe: its 128 MFMAs per K-tile go out back to back and
-//   the 32 ds_read_b128 + 16 LDS-DMA pieces it needs per K-tile are slotted between them, one every few MFMAs (an MFMA occupies the pipe for 16
-//   cycles and the issue port for 4).  128 x 128 wave tiles also read a third less from the LDS per MFMA (32 fragment reads per 128 MFMAs; 24 per
-//   64 with 128 x 64 tiles).
-// Software pipeline, skewed by half a K-tile so that there is always multiply work whose operands are already in registers when a barrier releases:
-//   two fragment sets, X = the first 32-deep step of a K-tile, Y = the second.  Iteration t:  vmcnt(0), lgkmcnt(0), barrier  (K-tile t visible; the
-//   buffer of K-tile t-1 free)  |  64 MFMAs on Y = (t-1, second step), with the 16 reads of X <- (t, first step) and the 16 DMA pieces of K-tile t+1 between
-//   them  |  64 MFMAs on X, with the 16 reads of Y <- (t, second step) between them.  Two 64 KB buffers, ONE four-wave barrier per K-tile.
-// Same accumulation order per output as every other tile shape (k ascending, hi before lo in each 32-deep step): identical bits.
-template <class T, int EPI, int WS, int BN, int PAT = 0>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) gemm256w_kernel(const GemmArgs p) {
-    typedef typename Vec<T>::v8 v8;
-    constexpr int BM = 256, BK = 64;
-    static_assert(WS * BN == 256, "the staged weight region is 256 rows");
-    constexpr int WN = BN / 2, MF = 8, NF = WN / 16;      // plain: 128 x 128 wave tiles (NF = 8); split: 128 x 64 against hi and lo (NF = 4)
-    constexpr int NWF = NF * WS;                          // weight fragments per 32-deep step: 8
-    constexpr unsigned BUFB = 512 * 128;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wave >> 1, wc = wave & 1;
-
-    const int nbn = p.N / BN;
-    const int nbm = (p.M + BM - 1) / BM;
-    const int nwg = nbm * nbn;
-    int bid = blockIdx.x;
-    {
-        const int xcd = bid & 7, slot = bid >> 3;
-        const int q = nwg >> 3, r = nwg & 7;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
-    }
-    constexpr int GM = 4;
-    const int tpg = GM * nbn;
-    const int gidx = bid / tpg;
-    const int gfirst = gidx * GM;
-    const int gsz = (nbm - gfirst < GM) ? nbm - gfirst : GM;
-    const int gin = bid - gidx * tpg;
-    const int m0 = (gfirst + gin % gsz) * BM;
-    const int n0 = (gin / gsz) * BN;
-
-    const int grp = blockIdx.y;
-    const char* __restrict__ A = reinterpret_cast<const char*>(reinterpret_cast<const T*>(p.A) + (size_t)grp * p.strideA);
-    const int wgrp = p.wdiv > 1 ? grp / p.wdiv : grp;
-    const char* __restrict__ W = reinterpret_cast<const char*>(reinterpret_cast<const T*>(p.W) + (size_t)wgrp * p.strideW);
-    const float* __restrict__ bias = p.bias ? p.bias + (size_t)wgrp * p.strideB : nullptr;
-    void* const outp = p.out_table ? p.out_table[grp] : p.out;
-
-    // ---- staging: a wave moves pieces 8 wave .. 8 wave + 7 (8 rows x 128 B each) of the A region and of the W region
-    const int srow = lane >> 3, pch = lane & 7;
-    unsigned a_off[8], w_off[8];
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-        const int r = (wave * 8 + q) * 8 + srow;
-        int gr = m0 + r;
-        gr = gr < p.M ? gr : p.M - 1;
-        a_off[q] = (unsigned)gr * (unsigned)(p.lda * 2) + (unsigned)(swz(r, pch) * 16);
-        const int part = r / BN, wrow = r - part * BN;
-        w_off[q] = (unsigned)(n0 + wrow) * (unsigned)(p.K * WS * 2) + (unsigned)part * (unsigned)(p.K * 2) + (unsigned)(swz(r, pch) * 16);
-    }
-    // (the buffer form of the LDS-DMA -- raw_ptr_buffer_load_lds, K-tile position in the scalar offset, no vector add per piece -- is a scheduling
-    // barrier to the compiler: the sched_group_barrier interleave below falls apart into [16 reads][16 pieces][64 MFMAs]; the flat form is scheduled)
-    auto stage = [&](int kt) {
-        char* const base = smem + (kt & 1) * BUFB + wave * 8192;
-        const char* const Ak = A + (size_t)kt * (BK * 2);
-        const char* const Wk = W + (size_t)kt * (BK * 2);
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            glds16(Ak + a_off[q], base + q * 1024);
-            glds16(Wk + w_off[q], base + 32768 + q * 1024);
-        }
-    };
-
-    f32x4 acc[MF][NF];
-#pragma unroll
-    for (int i = 0; i < MF; ++i)
-#pragma unroll
-        for (int j = 0; j < NF; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    const int fr = lane & 15, fg = lane >> 4;
-    const int nk = p.K / BK;
-    unsigned a_lane[2], w_lane[2];
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-        const int ra = wr * 128 + fr, rw = wc * WN + fr;
-        a_lane[ks] = (unsigned)(ra * 128 + swz(ra, ks * 4 + fg) * 16);
-        w_lane[ks] = 32768u + (unsigned)(rw * 128 + swz(rw, ks * 4 + fg) * 16);
-    }
-    v8 fa[2][MF], fw[2][NWF];   // [set = 32-deep step of the K-tile]
-    auto read_set = [&](auto setc, int t) {
-        constexpr int set = decltype(setc)::value;
-        const unsigned bufb = (t & 1) * BUFB;
-#pragma unroll
-        for (int part = 0; part < WS; ++part)
-#pragma unroll
-            for (int j = 0; j < NF; ++j) fw[set][part * NF + j] = *reinterpret_cast<const v8*>(smem + bufb + w_lane[set] + (part * BN + j * 16) * 128);
-#pragma unroll
-        for (int i = 0; i < MF; ++i) fa[set][i] = *reinterpret_cast<const v8*>(smem + bufb + a_lane[set] + i * 2048);
-    };
-    auto mma_set = [&](auto setc) {
-        constexpr int set = decltype(setc)::value;
-#pragma unroll
-        for (int part = 0; part < WS; ++part)
-#pragma unroll
-            for (int i = 0; i < MF; ++i)
-#pragma unroll
-                for (int j = 0; j < NF; ++j) acc[i][j] = mfma16(fw[set][part * NF + j], fa[set][i], acc[i][j]);
-    };
-    typedef std::integral_constant<int, 0> SX;
-    typedef std::integral_constant<int, 1> SY;
-
-    stage(0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    read_set(SX{}, 0);
-    if (nk > 1) stage(1);
-    read_set(SY{}, 0);
-    mma_set(SX{});
-    // one iteration; MORE: K-tile t + 1 exists (its DMA pieces ride in the Y block) -- a compile-time flag, a branch would cut the scheduling region
-    auto iter = [&](auto morec, int t) {
-        constexpr bool MORE = decltype(morec)::value;
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-        read_set(SX{}, t);
-        if constexpr (MORE) stage(t + 1);
-        mma_set(SY{});
-        read_set(SY{}, t);
-        mma_set(SX{});
-        // the interleave.  PAT 0: Y block = 16 x [2 MFMA, 1 DS read] + 16 x [2 MFMA, 1 DMA piece]; X block = 16 x [4 MFMA, 1 DS read]
-        //                  PAT 1: the 16 reads of X under the first 16 MFMAs, then one DMA piece per 4 MFMAs over the next 64 (the last 48 of the Y block and the
-        //                         first 16 of the X block: ~70 cycles per piece and wave = the ~17 cycles per piece the CU's front end takes, times its four
-        //                         waves), then the 16 reads of Y, one per 3 MFMAs
-        if constexpr (PAT == 0) {
-#pragma unroll
-            for (int g = 0; g < 16; ++g) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-            }
-#pragma unroll
-            for (int g = 0; g < 16; ++g) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-                if constexpr (MORE) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-            }
-#pragma unroll
-            for (int g = 0; g < 16; ++g) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
-                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-            }
-        } else {
-#pragma unroll
-            for (int g = 0; g < 16; ++g) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-            }
-#pragma unroll
-            for (int g = 0; g < 16; ++g) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
-                if constexpr (MORE) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-            }
-#pragma unroll
-            for (int g = 0; g < 16; ++g) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
-                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-            }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-    };
-    int t = 1;
-    for (; t + 1 < nk; ++t) iter(std::true_type{}, t);
-    if (t < nk) iter(std::false_type{}, t);
-    __builtin_amdgcn_sched_barrier(0);   // (or the scheduler pairs the last X block with the Y block below: back-to-back MFMAs on the same accumulator)
-    mma_set(SY{});
-
-    // ---- epilogue, 64 columns at a time (the full-line 16-bit stores and the RoPE pairs of epilogue_tile want 64-column wave tiles)
-#pragma unroll
-    for (int half = 0; half < NF / 4; ++half) {
-        f32x4 part[MF][4];
-#pragma unroll
-        for (int i = 0; i < MF; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) part[i][j] = acc[i][half * 4 + j];
-        epilogue_tile<T, EPI, 4, MF, 4, false>(p, outp, bias, m0 + wr * 128 + fr, n0 + wc * WN + half * 64, fg, part, NoLnFold{});
-    }
-}
-
-template <class T, int EPI, int WS, int BN, int PAT = 0>
-static int launch_256w(const GemmArgs& a, hipStream_t s) {
-    if ((unsigned long long)a.M * (unsigned long long)a.lda * 2ull >= (1ull << 32) || (unsigned long long)a.N * (unsigned long long)a.K * WS * 2ull >= (1ull << 32)) return 2;
-    const int nbn = a.N / BN, nbm = (a.M + 255) / 256;
-    const size_t lds = (size_t)2 * 512 * 128;
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256w_kernel<T, EPI, WS, BN, PAT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return 1;
-        attr_set = true;
-    }
-    hipLaunchKernelGGL((gemm256w_kernel<T, EPI, WS, BN, PAT>), dim3(nbm * nbn, a.batch > 1 ? a.batch : 1), dim3(256), lds, s, a);
-    return hipGetLastError() == hipSuccess ? 0 : 1;
-}
+#ifdef M3R_GEMM_LAB   // gemm256pp_kernel / gemm256q_kernel / gemm256w_kernel: persistent tiles, one barrier per K-tile, four-wave 128 x 128 tiles (measured, not used)
+#include "lab/gemm256_pp_q_w.inc"
+#endif
 
 // ------------------------------------------------------------------------------------------------------------------
 // M = 768 launches with N = 768 (proj, fc2, projq of the memory update): 48 x 48 tiles = exactly 256 blocks, ONE per CU,
@@ -3094,8 +2346,9 @@ static int g256k_mode() {
 //   split weights  (M3R_G256P_SPLIT, default 1): 0 never, 1 where its 256 x 128 tiles fill their rounds at least as well as the widest tile gemm256_kernel
 //                  would pick (decoder qkv N = 2304: 109 -> 103 us, K|V N = 1536: 72.6 -> 65.2 us; NOT the 256-wide encoder qkv 160 -> 162 us or the
 //                  192-wide decoder proj 44.7 -> 51.8 us, profiles/r05_g256p_split_ab.txt), 2 whenever the shape allows.
-// The other forms measured in r05 (four phases per K-tile; one barrier per phase with group 1 lagging; gemm256q: one barrier per K-tile; gemm256w: four
-// waves with 128 x 128 wave tiles) stay in this file as templates for scripts/probes/kloop_lab.hip and are not instantiated by the library.
+// The other forms measured in r05: four phases per K-tile and one barrier per phase with group 1 lagging are template arguments of gemm256p_kernel the library does
+// not instantiate; gemm256n (one phase per K-tile), gemm256pp (persistent tiles), gemm256q (one barrier per K-tile) and gemm256w (four waves, 128 x 128 wave tiles) live
+// in csrc/lab/*.inc and are compiled only with -DM3R_GEMM_LAB (scripts/probes/kloop_lab.hip).
 static int g256p_mode(bool split) {
     static int v[2] = {-1, -1};
     if (v[split] < 0) {
