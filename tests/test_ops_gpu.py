@@ -447,14 +447,15 @@ def test_attention_running_max_jump(lib, dt):
 
 
 @pytest.mark.parametrize("dt", ["bf16", "fp16"])
+@pytest.mark.parametrize("skip", [(0, 0), (300, 720)])   # an excluded key range (the MUSt3R own-token rule): partial tiles at both ends, the +17 spike (key 700) and the +11.5 one (500) inside it
 @pytest.mark.parametrize("geom", [(1, 1), (12, 16)])   # (heads, views): one group = the 16-rows-per-wave form, 192 groups = the 32-row form (attention_is_small)
-def test_attention_reference_moves_on_tile_row_sums(lib, dt, geom):
+def test_attention_reference_moves_on_tile_row_sums(lib, dt, geom, skip):
     """r05 rule of attn3_kernel: the softmax references move when the row sums of a 64-key tile leave [0, 4096] (or are not finite), not on score maxima.
     Exact scores (q = unit vectors, four key columns carry the score): a staircase that climbs 5 log2 units per tile (the reference lags and catches up
     every other tile), a spike that overflows the 16-bit P (+17), one that overflows the fp32 exp2 (+140), one that stays below the trigger (+11.5:
     P = 2896 accumulates against the old reference) followed by scores 30 below it -- the four patterns interleaved inside every wave."""
     heads, nviews = geom
-    nq, nk = 64, 1024
+    nq, nk = 64, (1024 if skip == (0, 0) else 1000)   # with the excluded range also a partial last tile
     tdt, u = DT[dt][1], DT[dt][2]
     g = torch.Generator(device="cuda").manual_seed(29)
     per = 8.0 / 1.4426950408889634            # key column value of ONE log2 unit of score (softmax scale 1 / 8)
@@ -470,7 +471,7 @@ def test_attention_reference_moves_on_tile_row_sums(lib, dt, geom):
     k = k1.repeat(1, heads).to(tdt)
     v = torch.randn((nk, heads * 64), device="cuda", generator=g).to(tdt)
     D = heads * 64
-    views = [(i * nq, nq, 0, nk, 0, 0) for i in range(nviews)]
+    views = [(i * nq, nq, 0, nk, skip[0], skip[1]) for i in range(nviews)]
     o = torch.empty((nviews * nq, D), device="cuda", dtype=tdt)
     tab = torch.tensor(views, dtype=torch.int32, device="cuda")
     lib.check(lib.load().must3r_hip_op_attention(DT[dt][0], P(q), P(k), P(v), P(o), D, D, D, D, heads, P(tab), nviews, nq, 0, None, 0, stream()))
@@ -478,7 +479,7 @@ def test_attention_reference_moves_on_tile_row_sums(lib, dt, geom):
     assert torch.isfinite(o.float()).all()
     ref = attn_ref(q.cpu(), k.cpu(), v.cpu(), views, heads)
     per_pattern = [rel_inf(o.cpu()[i::4], ref[i::4]) for i in range(4)]
-    record("attention_row_sum_rule", dt=dt, geom=list(geom), per_pattern=per_pattern)
+    record("attention_row_sum_rule", dt=dt, geom=list(geom), skip=list(skip), per_pattern=per_pattern)
     assert max(per_pattern) < 8 * u, per_pattern
 
 
