@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MUST3R_HIP_ABI_VERSION 7
+#define MUST3R_HIP_ABI_VERSION 8
 
 typedef struct must3r_hip_ctx must3r_hip_ctx;
 
@@ -63,6 +63,12 @@ typedef struct must3r_hip_config {
 
 int must3r_hip_abi_version(void);
 const char* must3r_hip_last_error(void);
+/* ABI 8.  Process-wide A/B switches of the library (measuring instruments, not model semantics: DESIGN.md section 10 lists them -- "PERSIST", "GEMM256",
+ * "G256K", "G256P", "G256P_SPLIT", "SPARSE_256", "SPARSE_LO", "BK128", "LN_ROWS", "LNFOLD", "ENC_CHUNK_ROWS", "ATTN_LZ").  Each has a default and an allowed
+ * range; an unknown name or a value outside the range is refused (status 1, must3r_hip_last_error() says why).  Without a call a switch takes its value from the
+ * environment variable M3R_<NAME> (validated alike; a bad value is reported on stderr and ignored).  No counterpart in the reference: its only back-end
+ * switch is toggle_memory_efficient_attention (must3r/model/blocks/attention.py:18-27). */
+int must3r_hip_set_option(const char* name, long long value);
 
 /* lifetime.  replaces: eval(encoder_args)/eval(decoder_args) + .to(device) in load_model, model/__init__.py:38-46 */
 int must3r_hip_create(const must3r_hip_config* cfg, int device, must3r_hip_ctx** out);
@@ -96,11 +102,13 @@ typedef struct must3r_hip_group {
     /* ABI 7: elements between the pointmaps of consecutive SCENES of this group; 0 = n_views*H*W*7 (the contiguous [B, n_views, H, W, 7] of the
      * reference).  A caller that walks a scene's views over several calls (the sequential memory update) can hand every call the slice
      * [:, i:i+n] of ONE [B, V, H, W, 7] buffer instead of concatenating the calls' outputs afterwards (must3r_amd.engine.run_scenes). */
-    int64_t pointmaps_scene_stride;
+    int64_t pointmaps_scene_stride;   /* must be a multiple of 4 (the head epilogue stores 16-byte vectors); the call is refused otherwise */
 } must3r_hip_group;
 
 typedef struct must3r_hip_decode_args {
-    int32_t dtype;        /* MUST3R_BF16 / MUST3R_F16 / MUST3R_F16_W2: operand type AND element type of the memory buffers;
+    int32_t dtype;        /* MUST3R_BF16 / MUST3R_F16 / MUST3R_F16_W2 / MUST3R_F16_WA (the default of the Python modules: fp16 operands, split weights
+                           * in the attention-side Linears, plain in the Mlp Linears): operand type AND element type of the memory buffers (fp16 for the
+                           * three F16 modes);
                            * | MUST3R_ATTN_FP8: e4m3 Q / K, MUST3R_MEM_KV memory rows are [K e4m3 | V 16-bit] = 3*dec_dim bytes */
     int32_t mem_mode;     /* MUST3R_MEM_* */
     int32_t render;       /* decoder.py:267 `render`: memory is read-only, no exclusion mask */

@@ -15,7 +15,7 @@ ATTN_FP8 = 0x100   # OR-able: fp8 (e4m3) attention operands, include/must3r_hip.
 MEM_KV, MEM_NORM_Y, MEM_RAW = 0, 1, 2
 PART_ENCODER, PART_DECODER = 1, 2
 EPI_STORE16, EPI_STORE16_GELU, EPI_QKV_ROPE, EPI_RESID_F32, EPI_F32, EPI_HEAD = range(6)
-ABI_VERSION = 7
+ABI_VERSION = 8
 ACT_NORM_EXP, ACT_LINEAR = 0, 1
 
 # every symbol include/must3r_hip.h declares
@@ -31,6 +31,7 @@ EXPORTS = (
     "must3r_hip_op_gemm_lnfold",
     "must3r_hip_postprocess_act", "must3r_hip_postprocess_cam_act",
     "must3r_hip_op_sparse24_pack", "must3r_hip_op_gemm_sp",
+    "must3r_hip_set_option",
 )
 
 
@@ -114,6 +115,7 @@ def load():
     lib.must3r_hip_postprocess_cam_scratch_bytes.argtypes = [i32, i32, i32]
     lib.must3r_hip_postprocess_cam_scratch_bytes.restype = C.c_size_t
     lib.must3r_hip_get_profile.argtypes = [vp, C.POINTER(ProfRecord), i32, i32]
+    lib.must3r_hip_set_option.argtypes = [C.c_char_p, C.c_longlong]
     for name in EXPORTS:
         fn = getattr(lib, name)
         if fn.restype is C.c_int and name not in ("must3r_hip_abi_version", "must3r_hip_attention_scratch_bytes",
@@ -128,6 +130,12 @@ def load():
 def check(rc):
     if rc != 0:
         raise HipError(load().must3r_hip_last_error().decode("utf-8", "replace"))
+
+
+def set_option(name, value):
+    """Process-wide A/B switch of the library (include/must3r_hip.h ``must3r_hip_set_option``): raises on an unknown
+    name or a value outside the switch's range."""
+    check(load().must3r_hip_set_option(name.encode(), int(value)))
 
 
 def make_config(cfg):

@@ -15,6 +15,7 @@
 #include <type_traits>
 #include "common.hpp"
 #include "kernels.hpp"
+#include "options.hpp"
 
 namespace m3r {
 
@@ -1266,7 +1267,7 @@ int launch_attention_phase(DType dt, const AttnArgs& a_in, int phase, hipStream_
 #endif
             {
                 // M3R_ATTN_LZ (A/B instrument): 1 (default) = references move on the tile's row sums, 0 = on the per-lane score maxima (r02-r04)
-                static const int lz = getenv("M3R_ATTN_LZ") ? atoi(getenv("M3R_ATTN_LZ")) : 1;
+                const int lz = opt(OPT_ATTN_LZ);
 #ifdef M3R_ATTN_EXPERIMENTS
                 // measured and not kept (profiles/r05_attn_step_ab.txt): M3R_ATTN_NB=3 K/V tiles staged two tiles ahead through three buffers (-1.9 % on the step),
                 // M3R_ATTN_PR=1 / 2 s_setprio 1 around the MFMA clusters / the exp2 cluster (+3 % on random operands, 0 / -0.9 % on the step)

@@ -17,6 +17,7 @@
 #include <type_traits>
 #include "common.hpp"
 #include "kernels.hpp"
+#include "options.hpp"
 
 namespace m3r {
 
@@ -785,8 +786,8 @@ static int launch_cfg(const GemmArgs& a, hipStream_t s) {
     const size_t lds = (size_t)NST * (BM + WS * BN) * BK * sizeof(T) + ln_fold_lds_bytes<BM, 64 * WGM * WGN>();
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<T, BM, BN, WGM, WGN, EPI, NST, WS, BK, PIPE>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<T, BM, BN, WGM, WGN, EPI, NST, WS, BK, PIPE>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return 1;
         attr_set = true;
     }
     hipLaunchKernelGGL((gemm_kernel<T, BM, BN, WGM, WGN, EPI, NST, WS, BK, PIPE>), dim3(nbm * nbn, a.batch > 1 ? a.batch : 1),
@@ -984,7 +985,7 @@ static int launch_256(const GemmArgs& a, hipStream_t s) {
     const size_t lds = (size_t)(OCC == 2 ? 2 : (WS * BN >= 384 ? 3 : 4)) * (256 + WS * BN) * 32 * sizeof(T);
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256_kernel<T, EPI, WS, BN, OCC>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256_kernel<T, EPI, WS, BN, OCC>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return 1;
         attr_set = true;
     }
     hipLaunchKernelGGL((gemm256_kernel<T, EPI, WS, BN, OCC>), dim3(nbm * nbn, a.batch > 1 ? a.batch : 1), dim3(512), lds, s, a);
@@ -1223,7 +1224,7 @@ static int launch_256k_v(const GemmArgs& a, hipStream_t s) {
     const size_t lds = (size_t)2 * (256 + WS * BN) * 64 * sizeof(T);
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256k_kernel<T, EPI, WS, BN, ABL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256k_kernel<T, EPI, WS, BN, ABL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return 1;
         attr_set = true;
     }
     hipLaunchKernelGGL((gemm256k_kernel<T, EPI, WS, BN, ABL>), dim3(nbm * nbn, a.batch > 1 ? a.batch : 1), dim3(512), lds, s, a);
@@ -1280,7 +1281,14 @@ static int launch_256k(const GemmArgs& a, hipStream_t s) {
 // form (~80 cycles per barrier with the matrix pipe drained, same trace) is paid once per phase instead of twice.
 //   RAW  the counted wait for phase q's half-tiles sits in every wave's load block of interval q-1 (before barrier #q); both groups read them in interval q.
 //   WAR  group 1 retires its reads of phase r at the end of interval r (lgkmcnt 0 before barrier #r+1); the restage goes out in interval r+1.
-template <class T, int EPI, int WS, int BN, int NPH, int SYNC = 2>
+// PERS = 1 (r06): PERSISTENT tiles.  The grid is one block per CU (launch_256p) and a block walks the work items blockIdx.x, + gridDim.x, ... (work item = tile of
+// problem `grp`); the block -> tile map per item is the non-persistent one, so a CU's sequence of tiles is what the dispatcher's round-robin gives the plain launch.
+// What it removes is the tile boundary of a multi-round launch: s_endpgm waits for the wave's outstanding stores, the workgroup's 160 KB of LDS are released only when its
+// last wave has ended, the next workgroup is dispatched, reads its kernel arguments and only then issues its first DMA (~3000 cycles to the first MFMA) -- here the
+// stores of tile i drain under the prologue of tile i + 1, issued straight behind them (the vendor's stream-K kernel has the same loop: profiles/r06_vendor_tile_boundary.txt).
+// LDS across the boundary: after the barrier that re-aligns the two wave groups at the end of the K loop every wave has retired its last fragment reads (lgkmcnt(0) in front of
+// its last load-interval barrier), the epilogue does not touch LDS, so the next prologue's DMA may start in any wave at once.  Same accumulation order: same bits.
+template <class T, int EPI, int WS, int BN, int NPH, int SYNC = 2, int PERS = 0>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) gemm256p_kernel(const GemmArgs p) {
     typedef typename Vec<T>::v8 v8;
     constexpr int BM = 256, BK = 64;
@@ -1301,7 +1309,12 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
     constexpr unsigned BUFB = 4 * HALFB;                   // A0 A1 B0 B1
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
-    const int tid = threadIdx.x;
+    for (int work = blockIdx.x;; work += gridDim.x) {   // PERS = 0: one pass (the body is not re-indented)
+    int tid_ = threadIdx.x;
+    // PERS: everything derived from the lane is recomputed per tile (a few integer instructions) -- hoisted out of the tile loop it would have to live across the
+    // epilogue, and the kernel sits at the 256-register cap of two waves per SIMD (spills)
+    if constexpr (PERS != 0) asm volatile("" : "+v"(tid_));
+    const int tid = tid_;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 2, wc = wave & 3;
@@ -1309,7 +1322,10 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
     const int nbn = p.N / BN;
     const int nbm = (p.M + BM - 1) / BM;
     const int nwg = nbm * nbn;
-    int bid = blockIdx.x;
+    const int nwork = PERS ? nwg * (p.batch > 1 ? p.batch : 1) : 0;
+    if constexpr (PERS != 0) { if (work >= nwork) break; }
+    const int grp = PERS ? work / nwg : (int)blockIdx.y;
+    int bid = PERS ? work - grp * nwg : (int)blockIdx.x;
     {
         const int xcd = bid & 7, slot = bid >> 3;
         const int q = nwg >> 3, r = nwg & 7;
@@ -1324,7 +1340,6 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
     const int m0 = (gfirst + gin % gsz) * BM;
     const int n0 = (gin / gsz) * BN;
 
-    const int grp = blockIdx.y;
     const T* __restrict__ A = reinterpret_cast<const T*>(p.A) + (size_t)grp * p.strideA;
     const int wgrp = p.wdiv > 1 ? grp / p.wdiv : grp;
     const T* __restrict__ W = reinterpret_cast<const T*>(p.W) + (size_t)wgrp * p.strideW;
@@ -1603,12 +1618,37 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
 #undef M3R_P_MUL_END
 
     epilogue_tile<T, EPI, NF, MF, 4, false>(p, outp, bias, m0 + wr * 128 + fr, n0 + wc * WN, fg, acc, NoLnFold{}, bpre);
+    if constexpr (PERS == 0) break;
+    }
 }
+
+// blocks of a persistent launch: one per CU (the kernels hold a CU's whole LDS / half its registers: one block is resident per CU)
+static int persistent_blocks() {
+    static int n = 0;
+    if (n == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        n = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+    }
+    return n;
+}
+// M3R_PERSIST (A/B instrument): 1 (default) the chip-filling kernels walk their tiles in a persistent loop when the launch has more than one round, 0 never
+static int persist_mode() { return opt(OPT_PERSIST); }
 
 template <class T, int EPI, int WS, int BN, int NPH, int SYNC = 2>
 static int launch_256p(const GemmArgs& a, hipStream_t s) {
     const int nbn = a.N / BN, nbm = (a.M + 255) / 256;
     const size_t lds = (size_t)2 * 4 * 128 * 64 * sizeof(T);
+    const long nwork = (long)nbm * nbn * (a.batch > 1 ? a.batch : 1);
+    if (persist_mode() != 0 && nwork > persistent_blocks() && nwork < (1l << 30)) {
+        static bool attr_set_p = false;
+        if (!attr_set_p) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256p_kernel<T, EPI, WS, BN, NPH, SYNC, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return 1;
+            attr_set_p = true;
+        }
+        hipLaunchKernelGGL((gemm256p_kernel<T, EPI, WS, BN, NPH, SYNC, 1>), dim3(persistent_blocks()), dim3(512), lds, s, a);
+        return hipGetLastError() == hipSuccess ? 0 : 1;
+    }
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256p_kernel<T, EPI, WS, BN, NPH, SYNC>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return 1;
@@ -1619,7 +1659,7 @@ static int launch_256p(const GemmArgs& a, hipStream_t s) {
 }
 
 #ifdef M3R_GEMM_LAB   // gemm256n_kernel: one phase per K-tile (measured equal; scripts/probes/kloop_lab.hip)
-#include "lab/gemm256n.inc"
+#include "../../scripts/probes/lab/gemm256n.inc"
 #endif
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -1634,7 +1674,8 @@ static int launch_256p(const GemmArgs& a, hipStream_t s) {
 //     phase 0: read a0, h0, h1, lo | stage H1, LO, A1 of t+1 | vmcnt(6): A1(t) and the positions of t landed | 48 matrix instructions
 //     phase 1: read a1            | stage A0, H0 of t+2, load the positions of t+1 | vmcnt(8): H1, LO, A0, H0 of t+1 landed | 48 matrix instructions
 // Numerics: those of gemm256p_kernel<.., WS = 3> (hi products in k order, then the sparse low product of the K-tile): identical bits between the two.
-template <class T, int EPI>
+// PERS = 1 (r06): persistent tiles, as gemm256p_kernel (the positions' first load of the next tile goes out behind this tile's stores; in-order vmcnt covers it).
+template <class T, int EPI, int PERS = 0>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) gemm256s_kernel(const GemmArgs p) {
     static_assert(sizeof(T) == 2 && !__is_same(T, bf16_t), "fp16 only");
     typedef typename Vec<T>::v8 v8;
@@ -1645,7 +1686,12 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
     constexpr unsigned BUFB = 5 * HALFB;                   // A0 A1 H0 H1 LO
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
-    const int tid = threadIdx.x;
+    for (int work = blockIdx.x;; work += gridDim.x) {   // PERS = 0: one pass (the body is not re-indented)
+    int tid_ = threadIdx.x;
+    // PERS: everything derived from the lane is recomputed per tile (a few integer instructions) -- hoisted out of the tile loop it would have to live across the
+    // epilogue, and the kernel sits at the 256-register cap of two waves per SIMD (spills)
+    if constexpr (PERS != 0) asm volatile("" : "+v"(tid_));
+    const int tid = tid_;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 2, wc = wave & 3;
@@ -1653,7 +1699,10 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
     const int nbn = p.N / BN;
     const int nbm = (p.M + BM - 1) / BM;
     const int nwg = nbm * nbn;
-    int bid = blockIdx.x;
+    const int nwork = PERS ? nwg * (p.batch > 1 ? p.batch : 1) : 0;
+    if constexpr (PERS != 0) { if (work >= nwork) break; }
+    const int grp = PERS ? work / nwg : (int)blockIdx.y;
+    int bid = PERS ? work - grp * nwg : (int)blockIdx.x;
     {
         const int xcd = bid & 7, slot = bid >> 3;
         const int q = nwg >> 3, r = nwg & 7;
@@ -1668,7 +1717,6 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
     const int m0 = (gfirst + gin % gsz) * BM;
     const int n0 = (gin / gsz) * BN;
 
-    const int grp = blockIdx.y;
     const T* __restrict__ A = reinterpret_cast<const T*>(p.A) + (size_t)grp * p.strideA;
     const int wgrp = p.wdiv > 1 ? grp / p.wdiv : grp;
     const T* __restrict__ W = reinterpret_cast<const T*>(p.W) + (size_t)wgrp * p.strideW;
@@ -1823,12 +1871,24 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
 #undef M3R_P_MUL_END
 
     epilogue_tile<T, EPI, NF, MF, 4, false>(p, outp, bias, m0 + wr * 128 + fr, n0 + wc * WN, fg, acc, NoLnFold{});
+    if constexpr (PERS == 0) break;
+    }
 }
 
 template <class T, int EPI>
 static int launch_256s(const GemmArgs& a, hipStream_t s) {
     const int nbn = a.N / 256, nbm = (a.M + 255) / 256;
     const size_t lds = (size_t)2 * 5 * 128 * 64 * sizeof(T);   // 163840 B: the CU's whole LDS
+    const long nwork = (long)nbm * nbn * (a.batch > 1 ? a.batch : 1);
+    if (persist_mode() != 0 && nwork > persistent_blocks() && nwork < (1l << 30)) {
+        static bool attr_set_p = false;
+        if (!attr_set_p) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256s_kernel<T, EPI, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return 1;
+            attr_set_p = true;
+        }
+        hipLaunchKernelGGL((gemm256s_kernel<T, EPI, 1>), dim3(persistent_blocks()), dim3(512), lds, s, a);
+        return hipGetLastError() == hipSuccess ? 0 : 1;
+    }
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256s_kernel<T, EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return 1;
@@ -1839,7 +1899,7 @@ static int launch_256s(const GemmArgs& a, hipStream_t s) {
 }
 
 #ifdef M3R_GEMM_LAB   // gemm256pp_kernel / gemm256q_kernel / gemm256w_kernel: persistent tiles, one barrier per K-tile, four-wave 128 x 128 tiles (measured, not used)
-#include "lab/gemm256_pp_q_w.inc"
+#include "../../scripts/probes/lab/gemm256_pp_q_w.inc"
 #endif
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -2004,14 +2064,7 @@ static int launch_48k(const GemmArgs& a, hipStream_t s) {
 // bits; fc2 (K = 3072) 17.4 -> 14.1 us plain, 19.0 -> 17.9 us split; the K = 768 launches +-0.2 us (their 12 tiles are not what they spend their
 // time on); one-scene-at-a-time 331 -> 336 views/s.  The same depth in the 64 x 64 ring kernels (2 x 128-deep stages): qkv 11.1 -> 15.1 us,
 // K|V 10.2 -> 14.4 us, fc1 13.3 -> 12.5 us, scene 326 views/s -- not kept.
-static int bk128_mode() {
-    static int v = -1;
-    if (v < 0) {
-        const char* e = getenv("M3R_BK128");
-        v = e ? atoi(e) : 1;
-    }
-    return v;
-}
+static int bk128_mode() { return opt(OPT_BK128); }
 template <class T, int EPI, int WS>
 static int launch_48(const GemmArgs& a, hipStream_t s) {
     if (a.K % 128 == 0 && a.K >= 256 && bk128_mode() != 0) return launch_48k<T, EPI, WS, 128>(a, s);
@@ -2257,7 +2310,7 @@ static int launch_96pf(const GemmArgs& a, hipStream_t s) {
     const size_t lds = (size_t)NST * (96 + 2 * 96) * 64 * sizeof(T) + ln_fold_lds_bytes<96, 576>();
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm96_kernel<T, EPI, NST, PF>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm96_kernel<T, EPI, NST, PF>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return 1;
         attr_set = true;
     }
     hipLaunchKernelGGL((gemm96_kernel<T, EPI, NST, PF>), dim3(nbm * nbn, a.batch > 1 ? a.batch : 1), dim3(576), lds, s, a);
@@ -2319,27 +2372,13 @@ static bool use_96(const GemmArgs& a, long nb) {
 }
 
 // M3R_GEMM256: 0 = never use the 8-wave kernel, 1 = by the fill rule below (default), 2 = whenever the shape allows it
-static int gemm256_mode() {
-    static int v = -1;
-    if (v < 0) {
-        const char* e = getenv("M3R_GEMM256");
-        v = e ? atoi(e) : 1;
-    }
-    return v;
-}
+static int gemm256_mode() { return opt(OPT_GEMM256); }
 // the 8-wave kernel holds one block per CU: use it when its rounds over the 256 CUs are reasonably full
 static int fill256(long tiles) {   // percentage of the CU slots of its rounds that do work
     const long rounds = (tiles + 255) / 256;
     return (int)(tiles * 100 / (rounds * 256));
 }
-static int g256k_mode() {
-    static int v = -1;
-    if (v < 0) {
-        const char* e = getenv("M3R_G256K");
-        v = e ? atoi(e) : 1;
-    }
-    return v;
-}
+static int g256k_mode() { return opt(OPT_G256K); }
 // M3R_G256P (r05): the phase-staggered 64-deep kernel (gemm256p_kernel, two phases per K-tile, two barriers per phase) for the chip-filling launches.
 //   plain weights  (M3R_G256P, default 1): 0 never (gemm256k_kernel), 1 every epilogue but the RoPE one (its instantiation spills), measured on the
 //                  nine shapes of scripts/exp_gemm256.py: 2-6 % faster on each (profiles/r05_g256p_plain_ab.txt), 987 -> 1113 TF/s at K = 16384;
@@ -2348,15 +2387,8 @@ static int g256k_mode() {
 //                  192-wide decoder proj 44.7 -> 51.8 us, profiles/r05_g256p_split_ab.txt), 2 whenever the shape allows.
 // The other forms measured in r05: four phases per K-tile and one barrier per phase with group 1 lagging are template arguments of gemm256p_kernel the library does
 // not instantiate; gemm256n (one phase per K-tile), gemm256pp (persistent tiles), gemm256q (one barrier per K-tile) and gemm256w (four waves, 128 x 128 wave tiles) live
-// in csrc/lab/*.inc and are compiled only with -DM3R_GEMM_LAB (scripts/probes/kloop_lab.hip).
-static int g256p_mode(bool split) {
-    static int v[2] = {-1, -1};
-    if (v[split] < 0) {
-        const char* e = getenv(split ? "M3R_G256P_SPLIT" : "M3R_G256P");
-        v[split] = e ? atoi(e) : 1;
-    }
-    return v[split];
-}
+// in scripts/probes/lab/*.inc and are compiled only with -DM3R_GEMM_LAB (scripts/probes/kloop_lab.hip).
+static int g256p_mode(bool split) { return opt(split ? OPT_G256P_SPLIT : OPT_G256P); }
 // (r04, measured and removed: two 256 x 128 blocks per CU -- the GELU launches' OCC = 2 form -- for the other split-weight epilogues, so that one
 // block's fp32 read-modify-write epilogue runs under the other's K loop: RESID proj 44.7 -> 52.1 us (dec) / 67.2 -> 68.2 us (enc), fc2 122 -> 152 us,
 // STORE16 K|V 71.9 -> 77.8 us, RoPE qkv +-1 %; nine split shapes 1246 -> 1308 us, step 497.6 -> 487.9 views/s.  profiles/r04_occ2_ab.txt.)
@@ -2411,7 +2443,7 @@ static int launch_epi(const GemmArgs& a, hipStream_t s, const char** err) {
             else if (a.Wlo_sp != nullptr && a.Widx_sp != nullptr && g256p_mode(true) != 0 && ok128 && a.K % 64 == 0 && t128 >= 200 && a.ln_stats == nullptr && !lnp &&
                      (fill256(t128) >= 80 || pick != 0)) {
                 // 256 x 256 sparse tiles (48 matrix instructions per phase) where they fill their rounds about as well as the 256 x 128 ones (24 per phase, load-bound)
-                static const int s256 = [] { const char* e = getenv("M3R_SPARSE_256"); return e ? atoi(e) : 1; }();
+                const int s256 = opt(OPT_SPARSE_256);
                 if (s256 && ok256 && a.K % 64 == 0 && t256 >= 200 && fill256(t256) + 12 >= fill256(t128)) { pick_name("g256s", EPI, 3, 256); rc = launch_256s<T, EPI>(a, s); }
                 else { pick_name("g256ps", EPI, 3, 128); rc = launch_256p<T, EPI, 3, 128, 2>(a, s); }
             }

@@ -3,8 +3,62 @@
 // layout allows; no LDS needed (wave shuffles only).
 #include "common.hpp"
 #include "kernels.hpp"
+#include "options.hpp"
+#include <cstring>
+#include <cstdio>
+#include <cstdlib>
 
 namespace m3r {
+// ------------------------------------------------------------------------------------------------------------------
+// option registry (options.hpp)
+// ------------------------------------------------------------------------------------------------------------------
+namespace {
+struct OptRow { const char* name; long long def, lo, hi; };
+const OptRow kOpts[OPT_COUNT] = {
+    {"PERSIST", 1, 0, 1}, {"GEMM256", 1, 0, 2}, {"G256K", 1, 0, 2}, {"G256P", 1, 0, 1}, {"G256P_SPLIT", 1, 0, 2}, {"SPARSE_256", 1, 0, 1},
+    {"SPARSE_LO", 1, 0, 1}, {"BK128", 1, 0, 1}, {"LN_ROWS", 1, 0, 1}, {"LNFOLD", 1, 0, 1}, {"ENC_CHUNK_ROWS", 32768, 256, 1 << 22}, {"ATTN_LZ", 1, 0, 2},
+};
+long long g_opt_val[OPT_COUNT];
+bool g_opt_init[OPT_COUNT];
+}  // namespace
+
+int opt(Opt o) {
+    if (!g_opt_init[o]) {
+        const OptRow& r = kOpts[o];
+        long long v = r.def;
+        char env[48];
+        snprintf(env, sizeof(env), "M3R_%s", r.name);
+        if (const char* e = getenv(env)) {
+            char* end = nullptr;
+            const long long x = strtoll(e, &end, 10);
+            if (end == e || *end != 0 || x < r.lo || x > r.hi)
+                fprintf(stderr, "libmust3r_hip: %s=%s ignored (an integer in [%lld, %lld] is expected); using %lld\n", env, e, r.lo, r.hi, r.def);
+            else v = x;
+        }
+        g_opt_val[o] = v;
+        g_opt_init[o] = true;
+    }
+    return (int)g_opt_val[o];
+}
+
+int opt_set(const char* name, long long value, const char** err) {
+    static thread_local char msg[128];
+    for (int o = 0; o < OPT_COUNT; ++o) {
+        if (name == nullptr || strcmp(name, kOpts[o].name) != 0) continue;
+        if (value < kOpts[o].lo || value > kOpts[o].hi) {
+            snprintf(msg, sizeof(msg), "set_option: %s = %lld is outside [%lld, %lld]", name, value, kOpts[o].lo, kOpts[o].hi);
+            *err = msg;
+            return 1;
+        }
+        g_opt_val[o] = value;
+        g_opt_init[o] = true;
+        return 0;
+    }
+    snprintf(msg, sizeof(msg), "set_option: unknown option '%s'", name ? name : "(null)");
+    *err = msg;
+    return 1;
+}
+
 
 // ------------------------------------------------------------------------------------------------
 // LayerNorm: one wave per row, C <= 1024, C % 4 == 0.  Two-pass statistics in registers.
@@ -166,14 +220,7 @@ __global__ void __launch_bounds__(256) ln_rows_kernel(const LnArgs p) {
 }
 
 // M3R_LN_ROWS (A/B instrument): 0 = one row per wave (ln_kernel, r01-r03), 1 = row-walking waves with the next row in flight (default)
-static int ln_rows_mode() {
-    static int v = -1;
-    if (v < 0) {
-        const char* e = getenv("M3R_LN_ROWS");
-        v = e ? atoi(e) : 1;
-    }
-    return v;
-}
+static int ln_rows_mode() { return opt(OPT_LN_ROWS); }
 template <class T>
 static void launch_ln_t(const LnArgs& a, hipStream_t s) {
     // Measured (profiles/r04_ln_rows_ab.txt, same bits): the walk wins where the rows stream from HBM -- the render batch, 307200 x 768:

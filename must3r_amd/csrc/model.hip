@@ -16,6 +16,7 @@
 
 #include "../../include/must3r_hip.h"
 #include "kernels.hpp"
+#include "options.hpp"
 
 using namespace m3r;
 
@@ -208,7 +209,7 @@ static int gemm(must3r_hip_ctx* c, DType dt, Epi epi, GemmArgs a, hipStream_t s,
                             : ((a.N % 128 == 0 && tiles128 >= 192) ? PC_GEMM128 : PC_GEMM64);
     if (ws_override >= 0) a.wsplit = ws_override;
     else if (c && epi != EPI_HEAD) a.wsplit = c->wsplit;
-    if (c && a.wsplit == 2 && c->mlp_plain && epi != EPI_HEAD && !c->sparse_lo.empty()) {   // (the sparse copies of an earlier MUST3R_F16_WA forward are not for MUST3R_F16_W2)
+    if (c && a.wsplit == 2 && c->mlp_plain && epi != EPI_HEAD && !c->sparse_lo.empty() && opt(OPT_SPARSE_LO) != 0) {   // (the sparse copies of an earlier MUST3R_F16_WA forward are not for MUST3R_F16_W2)
         auto it = c->sparse_lo.find(a.W);
         if (it != c->sparse_lo.end()) { a.Wlo_sp = it->second.vals; a.Widx_sp = it->second.idx; a.wsp_rows = it->second.rows; }
     }
@@ -378,7 +379,7 @@ static int w16p(must3r_hip_ctx* c, Param& p, DType dt, const void** hi, hipStrea
     // r05: the 2:4-sparse low part for the chip-filling kernels -- MUST3R_F16_WA only (mlp_plain): there the error budget is the plain Mlp weights' and the
     // dropped half of W_lo is invisible (scripts/emul/sparse_lo.py: 5.99e-4 vs 6.05e-4); MUST3R_F16_W2 exists for its 4e-4 and keeps the dense low part
     // (all-sparse would be 4.4e-4 against 3.4e-4).  fp16; M3R_SPARSE_LO=0: never.  rows x K / 2 values + rows x K / 8 bytes of positions, built on first use.
-    static const bool sparse_on = [] { const char* e = getenv("M3R_SPARSE_LO"); return !e || atoi(e) != 0; }();
+    const bool sparse_on = opt(OPT_SPARSE_LO) != 0;
     if (sparse_on && c->mlp_plain && dt == DT_F16 && !p.sp_vals) {
         const size_t rows = (size_t)p.shape[0], K = p.n / rows;
         if (rows % 128 == 0 && K % 64 == 0) {
@@ -443,6 +444,11 @@ extern "C" int must3r_hip_rope_table(float freq, float f0, int npos, float* out)
 // C ABI: lifetime / weights
 // ------------------------------------------------------------------------------------------------
 extern "C" int must3r_hip_abi_version(void) { return MUST3R_HIP_ABI_VERSION; }
+extern "C" int must3r_hip_set_option(const char* name, long long value) {
+    const char* err = "";
+    if (opt_set(name, value, &err)) return fail("%s", err);
+    return 0;
+}
 extern "C" const char* must3r_hip_last_error(void) { return g_err; }
 
 extern "C" int must3r_hip_create(const must3r_hip_config* cfg, int device, must3r_hip_ctx** out) {
@@ -760,8 +766,8 @@ extern "C" int must3r_hip_encode(must3r_hip_ctx* c, int dtype, const float* img,
     // rows per chunk: bounds the workspace (~32k token rows: the 16-bit activations of a chunk stay inside the 256 MB MALL between producer and
     // consumer launches).  M3R_ENC_CHUNK_ROWS: A/B instrument -- larger chunks lose less to the round quantisation of the
     // one-block-per-CU GEMMs (40 views: 94 % tile fill; 64 / 128 views: 100 %) but stream their activations through HBM.
-    static const int chunk_rows = getenv("M3R_ENC_CHUNK_ROWS") ? atoi(getenv("M3R_ENC_CHUNK_ROWS")) : 32768;
-    int per = (chunk_rows > 0 ? chunk_rows : 32768) / N;
+    const int chunk_rows = opt(OPT_ENC_CHUNK_ROWS);
+    int per = chunk_rows / N;
     if (per < 1) per = 1;
     {   // ... in chunks of equal size (80 views of 768 tokens: 2 x 40 -- 94 % tile fill -- instead of 42 + 38)
         const int nch = (n_views + per - 1) / per;
@@ -838,7 +844,7 @@ static int decode_impl(must3r_hip_ctx* c, const must3r_hip_decode_args* A, void*
     }
     // LN fold (one-view update calls, fp16 + split weights): none of the 36 LayerNorm launches of the blocks is issued; the residual GEMMs
     // leave 16-bit rows + per-fragment sums, the Linears that follow normalise after their product (kernels.hpp GemmArgs "LN fold").
-    static const bool lnf_on = !(getenv("M3R_LNFOLD") && atoi(getenv("M3R_LNFOLD")) == 0);
+    const bool lnf_on = opt(OPT_LNFOLD) != 0;
     // (S > 1: the consumers of the fold only exist on the small-M tile shapes; a batched call is past the launch floor the fold removes)
     const bool lnf = lnf_on && update && !need_pre_kv && c->wsplit == 2 && dt == DT_F16 && !a8 && !A->feats && A->n_groups == 1 &&
                      S == 1 && D == 768 && F % 96 == 0;
@@ -1218,6 +1224,8 @@ extern "C" int must3r_hip_decode(must3r_hip_ctx* c, const must3r_hip_decode_args
         if (G.n_views <= 0 || G.n_tokens <= 0) return fail("decode: empty group %d", gi);
         if (G.pointmaps_scene_stride != 0 && G.pointmaps_scene_stride < (long long)G.n_views * G.H * G.W * 7)
             return fail("decode: group %d: pointmaps_scene_stride %lld is smaller than one scene's pointmaps", gi, (long long)G.pointmaps_scene_stride);
+        if (G.pointmaps_scene_stride % 4 != 0 || (reinterpret_cast<uintptr_t>(G.pointmaps) & 15) != 0)   // the head epilogue stores (and accumulates) f32x4 vectors
+            return fail("decode: group %d: pointmaps must be 16-byte aligned and pointmaps_scene_stride (%lld) a multiple of 4 floats", gi, (long long)G.pointmaps_scene_stride);
         if (G.H % 16 || G.W % 16 || (G.H / 16) * (G.W / 16) != G.n_tokens)
             return fail("decode: group %d: %dx%d does not give %d tokens", gi, G.H, G.W, G.n_tokens);
         if (G.H / 16 > c->rope_npos || G.W / 16 > c->rope_npos) return fail("decode: group %d: image too large for the RoPE table", gi);

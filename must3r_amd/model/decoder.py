@@ -261,7 +261,8 @@ class MUSt3R(HipModule):
                 pm = pouts[i]
                 inner = n * H * W * 7
                 if (not pm.is_cuda or pm.dtype != torch.float32 or tuple(pm.shape) != (B, n, H, W, 7) or pm.device != device
-                        or tuple(pm.stride()[1:]) != (H * W * 7, W * 7, 7, 1) or (B > 1 and pm.stride(0) < inner)):
+                        or tuple(pm.stride()[1:]) != (H * W * 7, W * 7, 7, 1) or (B > 1 and (pm.stride(0) < inner or pm.stride(0) % 4))
+                        or pm.data_ptr() % 16):   # (the head epilogue stores 16-byte vectors: scene stride % 4 floats, 16-byte-aligned base)
                     raise ValueError(f"pointmaps_out[{i}]: need a fp32 cuda tensor [{B}, {n}, {H}, {W}, 7] with contiguous views, got {tuple(pm.shape)} "
                                      f"{pm.dtype} strides {tuple(pm.stride())}")
                 sstride = int(pm.stride(0)) if B > 1 and int(pm.stride(0)) != inner else 0

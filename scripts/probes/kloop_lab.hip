@@ -1,7 +1,7 @@
 // Probe: K-loop structures of the chip-filling GEMM side by side on one box, random operands: time, TF/s and a checksum of the output bits
 // (all structures accumulate in the same order: the checksums must agree).
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off scripts/probes/kloop_lab.hip -o scripts/probes/build/kloop_lab
-#define M3R_GEMM_LAB 1   // the lab kernels of must3r_amd/csrc/lab/*.inc
+#define M3R_GEMM_LAB 1   // the lab kernels of scripts/probes/lab/*.inc
 #include "../../must3r_amd/csrc/gemm.hip"
 #include <cstdio>
 #include <cstring>

@@ -373,3 +373,20 @@ def test_memory_rows_of_the_other_attention_mode_are_refused_not_cast():
     src = open(os.path.join(ROOT, "must3r_amd", "model", "decoder.py")).read()
     i, j, k = src.index("self._check_memory_rows(mem_vals, mem_D, fp8_rows)"), src.index("        if render:\n            # read-only"), src.index("self._writable_memory(mem_vals, Nm")
     assert i < j < k
+
+
+def test_set_option_is_validated(monkeypatch):
+    """ABI 8: the library's A/B switches live in ONE validated table (csrc/options.hpp): an unknown name or a value outside the switch's range is refused with an
+    error string; a refused call leaves the switch as it was.  (No GPU needed: nothing is launched.)"""
+    from must3r_amd import _lib
+    L = _lib.load()
+    assert L.must3r_hip_set_option(b"PERSIST", 1) == 0
+    for name, bad in ((b"PERSIST", 2), (b"PERSIST", -1), (b"GEMM256", 3), (b"ENC_CHUNK_ROWS", 0), (b"ENC_CHUNK_ROWS", 1 << 40), (b"NOPE", 1), (b"", 0)):
+        assert L.must3r_hip_set_option(name, bad) == 1, (name, bad)
+        msg = L.must3r_hip_last_error().decode()
+        assert "set_option" in msg and (name.decode() in msg or not name), msg
+    with pytest.raises(_lib.HipError):
+        _lib.set_option("SPARSE_LO", 7)
+    for name, ok in (("PERSIST", 0), ("PERSIST", 1), ("GEMM256", 2), ("GEMM256", 1), ("ENC_CHUNK_ROWS", 32768), ("ATTN_LZ", 1), ("LNFOLD", 1), ("SPARSE_LO", 1)):
+        _lib.set_option(name, ok)
+

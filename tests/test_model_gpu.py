@@ -225,15 +225,10 @@ def test_baseline_geometry_vs_oracle_and_properties(precision):
     x, pos = enc(imgs_c, ts_c)
     x1, pos1 = enc(imgs_c[3:4], ts_c[3:4])
     assert torch.equal(pos1[0], pos[3])
-    if precision == "fp16wa":
-        # r05: the chip-filling launches of this mode (5 views = 3840 rows) multiply a 2:4-SPARSE low part of the split weights, a lone view's
-        # launches the dense one -- two approximations of the same product, each inside the mode's tolerance of the oracle (checked below and on the fixtures);
-        # what the dropped entries are worth after 24 blocks is bounded here.  Every other mode keeps ONE arithmetic for all launch sizes: bit-equal.
-        e_inv = rel_inf(x1[0].cpu(), x[3].cpu())
-        record("encoder_batch_invariance", precision=precision, err=e_inv)
-        assert e_inv < 0.5 * TOL[precision], e_inv
-    else:
-        assert torch.equal(x1[0], x[3]), "encoder is not batch-invariant"
+    # bit-equal in EVERY mode at this size: 5 views = 3840 rows launch no kernel that multiplies the 2:4-sparse low part (launch_epi: the RoPE qkv launch fills
+    # 70 % of its rounds of 256 x 128 tiles, the N = 1024 launches have fewer than 200 tiles -- ADVICE r05), so the lone view and the batch share ONE arithmetic.
+    # Where the sparse low part does run (>= 20 views in flight) its distance from the dense one is bounded by test_sparse_low_part_batch_dependence_is_bounded.
+    assert torch.equal(x1[0], x[3]), "encoder is not batch-invariant"
     mem = None
     for a, b in ((0, 2), (2, 3), (3, 4), (4, 5)):
         mem, _ = dec(x[a:b].unsqueeze(0), pos[a:b].unsqueeze(0), ts_c[a:b].unsqueeze(0), mem)
@@ -518,3 +513,34 @@ def test_render_of_more_views_than_one_view_table_holds():
     for v in (0, 1023, 1024, 2047, 2048, V - 1):
         _, one = dec(xs[v:v + 1].unsqueeze(0), ps[v:v + 1].unsqueeze(0), tsv[v:v + 1].unsqueeze(0), mem, render=True)
         assert rel_inf(one[0, 0].cpu(), ren[0, v].cpu()) < 0.5 * TOL["fp16w2"], v
+
+
+def test_sparse_low_part_batch_dependence_is_bounded():
+    """fp16wa is NOT batch-invariant since r05: chip-filling split-weight launches multiply a 2:4-sparse low part of the weights,
+    smaller launches the dense one.  Here the sparse path really runs (20 views of 384x512 = 15360 rows: every attention-side launch of the encoder takes it) and its
+    distance from the dense low part is bounded by an assertion, two ways: the same 20-view batch with the switch off (SPARSE_LO = 0: dense two-pass kernels), and
+    view 3 alone (a 768-row launch never takes the sparse path).  Both must stay far inside the mode's tolerance; everything else about the two runs is identical."""
+    from must3r_amd import _lib
+    cfg = MUST3R_512
+    H, W, V = 384, 512, 20
+    enc, _ = build(cfg, "fp16wa")
+    imgs, ts = S.make_images(V, H, W, 0)
+    imgs_c, ts_c = imgs.cuda(), ts.cuda()
+    try:
+        _lib.set_option("SPARSE_LO", 1)
+        x_sp, _ = enc(imgs_c, ts_c)
+        x_sp = x_sp.clone()
+        x_one, _ = enc(imgs_c[3:4], ts_c[3:4])
+        _lib.set_option("SPARSE_LO", 0)
+        x_de, _ = enc(imgs_c, ts_c)
+        x_one_de, _ = enc(imgs_c[3:4], ts_c[3:4])
+    finally:
+        _lib.set_option("SPARSE_LO", 1)
+    assert torch.equal(x_one, x_one_de), "a one-view launch must not depend on the sparse switch"
+    assert torch.equal(x_de[3], x_one_de[0]), "with dense low parts everywhere the encoder is batch-invariant again"
+    e_ab = max(rel_inf(x_sp[v].cpu(), x_de[v].cpu()) for v in range(V))
+    e_one = rel_inf(x_one[0].cpu(), x_sp[3].cpu())
+    record("sparse_low_part_batch_dependence", sparse_vs_dense_20_views=e_ab, one_view_vs_view_of_20=e_one)
+    assert e_ab > 0.0, "the sparse path did not run: the test is vacuous"
+    assert e_ab < 0.25 * TOL["fp16wa"] and e_one < 0.25 * TOL["fp16wa"], (e_ab, e_one)
+

@@ -264,6 +264,78 @@ def test_gemm_sparse_low_part(lib, shape):
             assert e_exact < 1.5e-4, e_exact   # weight rounding left after the sparse low part: ~0.45 x 2^-12 per weight, averaged over K
 
 
+# (every shape launches the 256-row kernels over MORE than one round of 256 tiles: 484 / 432 / 472 / 472 tiles; ragged last row block; K-tile counts 16 / 12 / 3 / 1)
+@pytest.mark.parametrize("shape", [(30720 + 70, 1024, 1024), (9000, 3072, 768), (30000, 1024, 192), (30000, 1024, 64)])
+def test_gemm_persistent_tile_loop_same_bits(lib, shape):
+    """r06: the chip-filling kernels walk their tiles in a PERSISTENT loop (one block per CU; gemm256p_kernel / gemm256s_kernel <.., PERS = 1>) whenever a launch
+    has more tiles than CUs -- set_option("PERSIST", 0) launches one block per tile as before.  The loop changes nothing about the arithmetic: the outputs of the two
+    forms are bit-identical for plain and sparse-split weights, every epilogue, ragged last row blocks, several rounds, and the persistent form leaves the same bits
+    launch after launch (no stale LDS across a tile boundary)."""
+    M, N, K = shape
+    g = torch.Generator(device="cuda").manual_seed(M + N + K)
+    A = torch.randn((M, K), device="cuda", generator=g).half()
+    Wf = torch.randn((N, K), device="cuda", generator=g) / math.sqrt(K)
+    hi = Wf.half()
+    W2 = torch.cat((hi, (Wf - hi.float()).half()), dim=1).contiguous()
+    bias = torch.randn((N,), device="cuda", generator=g)
+    x0 = torch.randn((M, N), device="cuda", generator=g)
+    L = lib.load()
+    vals = torch.empty((K // 64, N, 32), device="cuda", dtype=torch.float16)
+    idx = torch.empty((K // 64, N // 32, 64), device="cuda", dtype=torch.int32)
+    lib.check(L.must3r_hip_op_sparse24_pack(P(Wf.contiguous()), N, K, P(vals), P(idx), stream()))
+    ref = A[:300].double() @ hi[:, :].double().t() + bias.double()
+
+    def go(epi, out, sparse):
+        if sparse:
+            lib.check(L.must3r_hip_op_gemm_sp(epi, P(A), P(W2), P(vals), P(idx), P(bias), P(out), M, N, K, K, N, None, None, 0, 0, stream()))
+        else:
+            lib.check(L.must3r_hip_op_gemm(1, epi, P(A), P(hi), P(bias), P(out), M, N, K, K, N, None, None, 0, 0, None, 0, 0, 0, 0, 0, 0, 0, stream()))
+        torch.cuda.synchronize()
+    try:
+        for sparse in (False, True):
+            for epi, odt in ((lib.EPI_STORE16, torch.float16), (lib.EPI_STORE16_GELU, torch.float16), (lib.EPI_F32, torch.float32), (lib.EPI_RESID_F32, torch.float32)):
+                outs = []
+                for mode in (0, 1, 1):
+                    lib.set_option("PERSIST", mode)
+                    out = x0.clone() if epi == lib.EPI_RESID_F32 else torch.full((M, N), 7.0, device="cuda", dtype=odt)
+                    go(epi, out, sparse)
+                    outs.append(out)
+                assert torch.equal(outs[0], outs[1]) and torch.equal(outs[1], outs[2]), (sparse, epi)
+                if epi == lib.EPI_F32 and not sparse:   # (and the bits are those of the product)
+                    assert torch.allclose(outs[1][:300].double(), ref, rtol=2e-6, atol=1e-5)
+    finally:
+        lib.set_option("PERSIST", 1)
+
+
+def test_gemm_sparse_tile_widths_same_bits(lib):
+    """gemm256s_kernel (256 x 256 sparse tiles; its position dwords come in through inline-asm loads the compiler does not track) against
+    gemm256p_kernel<.., WS = 3> (256 x 128 tiles, positions through LDS): same operands, same accumulation order -- identical bits, on a shape both fill."""
+    M, N, K = 15360, 3072, 1024
+    g = torch.Generator(device="cuda").manual_seed(77)
+    A = torch.randn((M, K), device="cuda", generator=g).half()
+    Wf = torch.randn((N, K), device="cuda", generator=g) / math.sqrt(K)
+    hi = Wf.half()
+    W2 = torch.cat((hi, (Wf - hi.float()).half()), dim=1).contiguous()
+    bias = torch.randn((N,), device="cuda", generator=g)
+    L = lib.load()
+    vals = torch.empty((K // 64, N, 32), device="cuda", dtype=torch.float16)
+    idx = torch.empty((K // 64, N // 32, 64), device="cuda", dtype=torch.int32)
+    lib.check(L.must3r_hip_op_sparse24_pack(P(Wf.contiguous()), N, K, P(vals), P(idx), stream()))
+    outs = {}
+    try:
+        for w in (1, 0):
+            lib.set_option("SPARSE_256", w)
+            for rep in range(3):
+                out = torch.zeros((M, N), device="cuda", dtype=torch.float16)
+                lib.check(L.must3r_hip_op_gemm_sp(lib.EPI_STORE16, P(A), P(W2), P(vals), P(idx), P(bias), P(out), M, N, K, K, N, None, None, 0, 0, stream()))
+                torch.cuda.synchronize()
+                assert w not in outs or torch.equal(outs[w], out), ("launch-to-launch", w, rep)
+                outs[w] = out
+    finally:
+        lib.set_option("SPARSE_256", 1)
+    assert torch.equal(outs[0], outs[1])
+
+
 @pytest.mark.parametrize("dt", ["bf16", "fp16"])
 @pytest.mark.parametrize("geom", [(2, 14, 14, 128), (1, 24, 32, 768), (3, 3, 4, 1024), (4, 24, 32, 256), (20, 24, 32, 512)])
 def test_gemm_qkv_rope(lib, dt, geom):

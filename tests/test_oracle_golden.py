@@ -187,3 +187,31 @@ def test_retrieval_oracle_matches_reference_fixture():
     assert np.array_equal(RR.forward_global(sd, x).numpy(), g["deep/glob"])
     for dim in (-1, 1):
         assert np.array_equal(RR.whiten(x, sd["prewhiten.m"], sd["prewhiten.p"], l2norm=dim).numpy(), g[f"l2norm{dim}/out"])
+
+
+def test_gpu_baseline_harness_reproduces_the_port_on_cpu():
+    """bench.py's ``torch_rocm_baseline`` leg runs the port with its leaves swapped for the torch ops the reference's modules call (oracle/gpu_baseline.py) so that
+    autocast gives the reference's dtype flow.  Run on the CPU on the tiny network: with the all-fp32 policy the swapped leaves reproduce the port (1e-5), and under
+    bf16 autocast the distance from the fp32 path is the reference's own bf16 envelope (~1e-2), not an arithmetic error of the harness."""
+    import importlib.util
+    import os
+    from conftest import ROOT
+    from oracle import must3r_ref as R0, gpu_baseline as G
+    from must3r_amd.config import TINY
+    from must3r_amd import synthetic as S
+    spec = importlib.util.spec_from_file_location("must3r_ref_torch_leaves", os.path.join(ROOT, "oracle", "must3r_ref.py"))
+    R1 = importlib.util.module_from_spec(spec)          # a private copy of the port: the swap must not leak into the other tests' oracle
+    spec.loader.exec_module(R1)
+    cfg = TINY
+    sde, sdd = S.make_encoder_state_dict(cfg, 0), S.make_decoder_state_dict(cfg, 0)
+    imgs, ts = S.make_images(4, 48, 64, 0)
+    rel = lambda a, b: float((a - b).abs().max() / b.abs().max())  # noqa: E731
+    with torch.no_grad():
+        u0, r0, _ = R0.run_scene(sde, sdd, cfg, imgs, ts)
+        G.install_torch_leaves(R1, "cpu")
+        u1, r1, st = G.run_scene_gpu(R1, sde, sdd, cfg, imgs, ts, "cpu", torch.float32)
+        u2, r2, _ = G.run_scene_gpu(R1, sde, sdd, cfg, imgs, ts, "cpu", torch.bfloat16)
+    assert rel(u1, u0) < 1e-5 and rel(r1, r0) < 1e-5
+    assert 1e-4 < rel(r2, r0) < 3e-2 and 1e-4 < rel(u2, u0) < 3e-2
+    assert set(st) == {"encode", "update", "render"}
+

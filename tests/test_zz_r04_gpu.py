@@ -18,7 +18,7 @@ from test_ops_gpu import record
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("Sn", [8, 20])
+@pytest.mark.parametrize("Sn", [8, 20, 28])   # 28 = bench.py's default --scenes (the configuration BENCH_rNN times)
 def test_benched_configuration_scenes_in_flight_vs_reference_fixture(Sn):
     """What bench.py times -- S scenes of 20 views 384x512 IN FLIGHT in the default precision -- checked here, not only inside bench.py:
     scene 0 is the fixture's scene (outputs of the REAL reference, oracle/make_golden.py): every view of its update and render passes
