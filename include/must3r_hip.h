@@ -105,6 +105,28 @@ typedef struct must3r_hip_group {
     int64_t pointmaps_scene_stride;   /* must be a multiple of 4 (the head epilogue stores 16-byte vectors); the call is refused otherwise */
 } must3r_hip_group;
 
+/* ---- ABI 8: context-parallel cross attention (SURVEY.md section 8f "later"; the keys of must3r/model/decoder.py:301-321's cross attention spread over processes) ----
+ * The memory of ONE scene is SHARDED over `world` ranks (one process per GPU): every rank holds some of the memory rows of every layer, runs the same one-view
+ * memory update on the same tokens (the projections / self attention / Mlp of a 768-row call are replicated, they do not shard), but attends only ITS rows and
+ * contributes one fp32 PARTIAL per layer: un-normalised O [rows][dec_dim] followed by (m, l) [rows][heads][2] -- the flash-attention partial.  The library then
+ * calls `exchange`, which must leave rank r's partial in slot r on every rank (an all-gather over xGMI: RCCL's ncclAllGather, or
+ * torch.distributed.all_gather_into_tensor on the caller's stream), and merges the `world` slots.  A rank may hold no rows at all (n_mem = 0).
+ * Only for memory-update calls of ONE view on ONE scene in MUST3R_MEM_KV mode against a non-empty (global) memory: the per-frame call of the streaming schedule
+ * (engine/inference.py:232-366).  The new K|V rows are appended to THIS rank's buffers as usual; the caller decides which rank keeps them
+ * (must3r_amd.parallel.run_video_sharded(context_parallel=True): the frame's owner keeps, the others rewind).
+ * `exchange` runs on the calling thread between launches on `stream`: it must enqueue the collective in stream order and must not synchronise the device with the
+ * library's launches still queued behind it unless it has to (a host-staged exchange may).  Non-zero return aborts the call (status 1). */
+typedef int (*must3r_hip_cp_exchange_fn)(void* user, int layer, void* slots, size_t slot_bytes, int n_slots, int my_slot, void* stream);
+typedef struct must3r_hip_cp {
+    int32_t world, rank;     /* ranks the memory is sharded over (>= 1; 1 = a group of one rank, the exchange still runs), this rank */
+    int32_t n_mem_total;     /* memory rows over ALL ranks before this call (> 0); must3r_hip_decode_args.n_mem = THIS rank's rows (>= 0) */
+    int32_t reserved;        /* 0 */
+    void* slots;             /* device buffer of world x slot_bytes bytes, 16-byte aligned; slot r = rank r's partial of the layer being exchanged */
+    size_t slot_bytes;       /* >= must3r_hip_cp_slot_bytes(ctx, rows of the call), a multiple of 16 */
+    must3r_hip_cp_exchange_fn exchange;
+    void* user;
+} must3r_hip_cp;
+
 typedef struct must3r_hip_decode_args {
     int32_t dtype;        /* MUST3R_BF16 / MUST3R_F16 / MUST3R_F16_W2 / MUST3R_F16_WA (the default of the Python modules: fp16 operands, split weights
                            * in the attention-side Linears, plain in the Mlp Linears): operand type AND element type of the memory buffers (fp16 for the
@@ -133,7 +155,12 @@ typedef struct must3r_hip_decode_args {
      * mode's tolerance otherwise.  0 / 1 = one scene. */
     int32_t n_scenes;
     int64_t mem_scene_stride;
+    /* ---- ABI 8 ---- */
+    const must3r_hip_cp* cp;   /* NULL: off.  Context-parallel cross attention (above): `mem` / `n_mem` describe this rank's SHARD of the memory */
 } must3r_hip_decode_args;
+
+/* bytes of one rank's partial for a context-parallel call of `rows` token rows: rows x (dec_dim + 2 x dec_heads) floats, rounded up to 256 */
+size_t must3r_hip_cp_slot_bytes(const must3r_hip_ctx* ctx, int rows);
 
 /* MUSt3R.forward / forward_list (decoder.py:158-350).  Render calls whose view tables exceed the library's staging slot
  * (1365 views) are cut into ranges of scenes / views inside the library: rendered views are independent. */
@@ -230,6 +257,15 @@ int must3r_hip_op_gemm_lnfold(int dtype, int epi, const void* A, const void* W2,
                               int lda, int ldc, void* x16_out, float* copy32_out, float* stats_out, const float* ln_stats,
                               const float* ln_s, float ln_eps, float* ln_shift, int ln_shift_init, const int64_t* pos,
                               const float* rope_tab, int rope_cols, int rope_npos, float out_scale, int scale_cols, void* stream);
+/* ABI 8 (r06).  The same fold on the chip-filling 256 x 256 tiles (batched decoder calls, encoder chunks; fp16; the library uses it by itself in MUST3R_F16_WA mode,
+ * M3R_LNFOLD256=0: never).  wsplit = 2: W = [N, 2K] split rows + the packed sparse low part (must3r_hip_op_sparse24_pack), epi STORE16 / QKV_ROPE (consumer) or
+ * RESID_F32 (producer); wsplit = 0: plain fp16 W [N, K], epi STORE16_GELU (consumer) or RESID_F32 (producer).  N % 256 == 0.
+ * Producer: M % 256 == 0; x16_out rows (stride ldc) of x - ln_shift[m], (sum, sum of squares) per row and 64-COLUMN wave tile into stats_out [M][N/64][2], optional
+ * copy32_out.  Consumer: ln_stats in that layout ([M][K/64][2]; K = 768 or 1024); ln_shift [M] (required; optional on producers) must hold valid values: += the measured mean. */
+int must3r_hip_op_gemm_fold256(int epi, int wsplit, const void* A, const void* W, const void* Wlo_sp, const void* Widx_sp, const float* bias, void* out,
+                               int M, int N, int K, int lda, int ldc, void* x16_out, float* copy32_out, float* stats_out, const float* ln_stats,
+                               const float* ln_s, float ln_eps, float* ln_shift, const int64_t* pos, const float* rope_tab, int rope_cols, int rope_npos,
+                               float out_scale, int scale_cols, void* stream);
 /* cos/sin table fp32 [npos][16][2] for RoPE2D(freq, F0) with head dim 64 (host pointer) */
 int must3r_hip_rope_table(float freq, float f0, int npos, float* out_host);
 

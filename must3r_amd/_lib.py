@@ -31,7 +31,7 @@ EXPORTS = (
     "must3r_hip_op_gemm_lnfold",
     "must3r_hip_postprocess_act", "must3r_hip_postprocess_cam_act",
     "must3r_hip_op_sparse24_pack", "must3r_hip_op_gemm_sp",
-    "must3r_hip_set_option",
+    "must3r_hip_set_option", "must3r_hip_cp_slot_bytes", "must3r_hip_op_gemm_fold256",
 )
 
 
@@ -48,11 +48,22 @@ class Group(C.Structure):
                 ("pointmaps", C.c_void_p), ("pointmaps_scene_stride", C.c_int64)]
 
 
+# must3r_hip_cp_exchange_fn: (user, layer, slots, slot_bytes, n_slots, my_slot, stream) -> status
+CpExchangeFn = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p)
+
+
+class Cp(C.Structure):
+    """must3r_hip_cp: context-parallel cross attention over a memory sharded across ranks (include/must3r_hip.h, ABI 8)."""
+    _fields_ = [("world", C.c_int32), ("rank", C.c_int32), ("n_mem_total", C.c_int32), ("reserved", C.c_int32),
+                ("slots", C.c_void_p), ("slot_bytes", C.c_size_t), ("exchange", CpExchangeFn), ("user", C.c_void_p)]
+
+
 class DecodeArgs(C.Structure):
     _fields_ = [("dtype", C.c_int32), ("mem_mode", C.c_int32), ("render", C.c_int32), ("first_call", C.c_int32),
                 ("n_groups", C.c_int32), ("groups", C.POINTER(Group)), ("n_mem", C.c_int32),
                 ("mem", C.POINTER(C.c_void_p)), ("feats", C.c_void_p),
-                ("mem_capacity", C.c_int32), ("n_scenes", C.c_int32), ("mem_scene_stride", C.c_int64)]
+                ("mem_capacity", C.c_int32), ("n_scenes", C.c_int32), ("mem_scene_stride", C.c_int64),
+                ("cp", C.POINTER(Cp))]
 
 
 class ProfRecord(C.Structure):
@@ -96,6 +107,7 @@ def load():
     lib.must3r_hip_attention_scratch_bytes.restype = C.c_size_t
     lib.must3r_hip_op_layernorm.argtypes = [i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, fp, vp]
     lib.must3r_hip_op_gemm_lnfold.argtypes = [i32, i32, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, fp, vp, i32, vp, vp, i32, i32, fp, i32, vp]
+    lib.must3r_hip_op_gemm_fold256.argtypes = [i32, i32, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, fp, vp, vp, vp, i32, i32, fp, i32, vp]
     lib.must3r_hip_op_sparse24_pack.argtypes = [vp, i32, i32, vp, vp, vp]
     lib.must3r_hip_op_gemm_sp.argtypes = [i32, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, i32, i32, vp]
     lib.must3r_hip_op_im2col.argtypes = [i32, vp, vp, i32, i32, i32, vp]
@@ -116,10 +128,12 @@ def load():
     lib.must3r_hip_postprocess_cam_scratch_bytes.restype = C.c_size_t
     lib.must3r_hip_get_profile.argtypes = [vp, C.POINTER(ProfRecord), i32, i32]
     lib.must3r_hip_set_option.argtypes = [C.c_char_p, C.c_longlong]
+    lib.must3r_hip_cp_slot_bytes.argtypes = [vp, i32]
+    lib.must3r_hip_cp_slot_bytes.restype = C.c_size_t
     for name in EXPORTS:
         fn = getattr(lib, name)
         if fn.restype is C.c_int and name not in ("must3r_hip_abi_version", "must3r_hip_attention_scratch_bytes",
-                                                    "must3r_hip_postprocess_cam_scratch_bytes"):
+                                                    "must3r_hip_postprocess_cam_scratch_bytes", "must3r_hip_cp_slot_bytes"):
             fn.restype = i32
     if lib.must3r_hip_abi_version() != ABI_VERSION:
         raise ImportError(f"{LIB_PATH}: ABI version {lib.must3r_hip_abi_version()} != {ABI_VERSION}; rebuild")

@@ -132,6 +132,147 @@ __device__ __forceinline__ void ln_fold_rows(const GemmArgs& p, const int m0, fl
 }
 template <int BM, int NT> constexpr size_t ln_fold_lds_bytes() { return (size_t)(BM * (NT / BM) * 2 + BM * 2) * sizeof(float); }
 
+// ---- r06: the LN fold on the chip-filling 256 x 256 tiles (GemmArgs::fold256; gemm256s_kernel / gemm256p_kernel<.., FOLD = 1>) ----
+// Statistics travel per row and 64-column WAVE TILE ([M][N/64][2]: a quarter of the legacy per-fragment layout's bytes): 12 (K = 768) or 16 (K = 1024) slots per row.
+// Consumer, in front of its first DMA: two threads per row request their halves of the row's slots (16-byte loads) + the row's current shift (+ the caller's s_n
+// columns).  INLINE ASM: a load the compiler knows about makes it wait vmcnt(0) in front of the first use -- i.e. for the whole prologue's DMA, K-tile 1 included
+// (measured: +2.5 us per tile).  The registers are "defined" for the compiler at the asm statement and really filled when the loads land: they must not be read,
+// copied or spilled before fold256_landed() -- placed behind the prologue's counted wait, which these older loads are covered by (in-order vmcnt) -- has
+// re-defined them in place (the pattern of gemm256s_kernel's load_ix / take_ix; checked in the listing: scripts/checks/fold256_regs.py).
+struct Fold256In { f32x4 q0, q1, q2, q3, s; float sh; };
+__device__ __forceinline__ void fold256_issue(const GemmArgs& p, const int m0, const int n0, const int tid, Fold256In& f) {
+    const int nsl = p.K >> 6, half = nsl >> 1;   // launch_gemm: 12 or 16 slots per row
+    int m = m0 + (tid >> 1);
+    m = m < p.M ? m : p.M - 1;
+    const float* src = p.ln_stats + ((size_t)m * nsl + (size_t)(tid & 1) * half) * 2;
+    const float* src3 = src + (half == 8 ? 12 : 8);   // K = 768: three loads cover the half row; the fourth repeats the third and is dropped
+    const float* shp = p.ln_shift + m;
+    const float* sp = p.ln_s + n0 + (tid & 63) * 4;
+    asm volatile("global_load_dwordx4 %0, %6, off\n\tglobal_load_dwordx4 %1, %6, off offset:16\n\tglobal_load_dwordx4 %2, %6, off offset:32\n\t"
+                 "global_load_dwordx4 %3, %7, off\n\tglobal_load_dword %4, %8, off\n\tglobal_load_dwordx4 %5, %9, off"
+                 : "=&v"(f.q0), "=&v"(f.q1), "=&v"(f.q2), "=&v"(f.q3), "=&v"(f.sh), "=&v"(f.s)
+                 : "v"(src), "v"(src3), "v"(shp), "v"(sp)
+                 : "memory");
+}
+__device__ __forceinline__ void fold256_landed(Fold256In& f) {
+    asm volatile("" : "+v"(f.q0), "+v"(f.q1), "+v"(f.q2), "+v"(f.q3), "+v"(f.sh), "+v"(f.s));
+}
+// ... and, with the rest of the prologue's DMA in flight, add them up in slot order (the partner lane's half through a DPP quad permute: both lanes hold the row's
+// (mean, 1/sigma) of the SHIFTED row -- all the fold needs, see GemmArgs::ln_shift); the column-0 blocks leave shift + mean = the row's current mean.
+__device__ __forceinline__ void fold256_finish(const GemmArgs& p, const int m0, const int n0, const int tid, const Fold256In& f, float& mu, float& rstd) {
+    float s1 = 0.f, s2 = 0.f;
+    s1 += f.q0[0]; s2 += f.q0[1]; s1 += f.q0[2]; s2 += f.q0[3];
+    s1 += f.q1[0]; s2 += f.q1[1]; s1 += f.q1[2]; s2 += f.q1[3];
+    s1 += f.q2[0]; s2 += f.q2[1]; s1 += f.q2[2]; s2 += f.q2[3];
+    if ((p.K >> 7) == 8) {   // (kernel-uniform)
+        s1 += f.q3[0]; s2 += f.q3[1]; s1 += f.q3[2]; s2 += f.q3[3];
+    }
+    const float o1 = __uint_as_float((unsigned)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(s1), 0xB1, 0xf, 0xf, false));   // quad_perm [1,0,3,2]
+    const float o2 = __uint_as_float((unsigned)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(s2), 0xB1, 0xf, 0xf, false));
+    const float a = (tid & 1) ? o1 + s1 : s1 + o1;   // first half + second half, in both lanes
+    const float b = (tid & 1) ? o2 + s2 : s2 + o2;
+    const float inv = 1.0f / (float)p.K;
+    mu = a * inv;
+    float var = b * inv - mu * mu;
+    var = var > 0.f ? var : 0.f;
+    rstd = rsqrtf(var + p.ln_eps);
+    if (n0 == 0 && !(tid & 1) && m0 + (tid >> 1) < p.M) st_global<float>(p.ln_shift + m0 + (tid >> 1), f.sh + mu);
+}
+// Producer: one row fragment of a 64-column wave tile (NF = 4), new fp32 values xn of this lane -> the shifted row's 16-bit copy (whole 128-byte lines, the
+// lane exchanges of the 16-bit-store epilogues) and the wave tile's (sum, sum of squares) of that row.  Needs all 16 rows of the fragment (M % 256 == 0).
+template <class T>
+__device__ __forceinline__ void fold256_emit(const GemmArgs& p, const int m, const int nw0, const int fg, const f32x4 (&xn)[4], const float shift) {
+    typedef typename Vec<T>::v4 v4;
+    f32x4 y[4];
+    float s1 = 0.f, s2 = 0.f, t1 = 0.f, t2 = 0.f;   // (two chains each; squares by fused multiply-add: the file is built with -ffp-contract=off)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        y[j] = xn[j] - shift;
+        s1 += y[j][0] + y[j][1];
+        t1 += y[j][2] + y[j][3];
+        s2 = __builtin_fmaf(y[j][0], y[j][0], s2); t2 = __builtin_fmaf(y[j][1], y[j][1], t2);
+        s2 = __builtin_fmaf(y[j][2], y[j][2], s2); t2 = __builtin_fmaf(y[j][3], y[j][3], t2);
+    }
+    s1 = quad_row_sum(s1 + t1);
+    s2 = quad_row_sum(s2 + t2);
+    if (fg == 0) st_global<f32x2>(p.stats_out + ((size_t)m * (p.N >> 6) + (nw0 >> 6)) * 2, f32x2{s1, s2});
+    const int lane = (int)__lane_id();
+    u32x4 o[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const v4 h0 = cvt4_sat<T>(y[2 * q]), h1 = cvt4_sat<T>(y[2 * q + 1]);
+        unsigned a[2], c[2];
+        __builtin_memcpy(a, &h0, 8);
+        __builtin_memcpy(c, &h1, 8);
+#pragma unroll
+        for (int d = 0; d < 2; ++d) {
+            auto w1 = __builtin_amdgcn_permlane32_swap(a[d], c[d], false, false);
+            auto w2 = __builtin_amdgcn_permlane16_swap(w1[0], w1[1], false, false);
+            o[q][d] = w2[0];
+            o[q][2 + d] = w2[1];
+        }
+    }
+    u32x4 x, z;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        x[d] = (unsigned)__builtin_amdgcn_update_dpp((int)o[0][d], (int)o[1][d], 0x128, 0xf, 0xc, false);
+        z[d] = (unsigned)__builtin_amdgcn_update_dpp((int)o[1][d], (int)o[0][d], 0x128, 0xf, 0x3, false);
+    }
+    const int row0 = m - (lane & 15);
+    const int nq = nw0 + ((lane >> 5) & 1) * 16 + ((lane >> 4) & 1) * 8;
+    T* const dst = reinterpret_cast<T*>(p.x16_out) + (size_t)(row0 + (lane & 7)) * p.ldc + nq + ((lane >> 3) & 1) * 32;
+    st_global<u32x4>(dst, x);
+    st_global<u32x4>(dst + (size_t)8 * p.ldc, z);
+}
+
+// Consumer, behind the K loop: acc <- acc / sigma_m - (mu_m / sigma_m) s_n, i.e. what epilogue_row's LN path computes per row ((acc - mu s) / sigma) in two
+// operations per value instead of three; the epilogue then adds c_n as the bias.  The rows' (mean, 1/sigma) and the columns' s_n reach the lanes that hold the
+// accumulators through LDS:
+//   fold256_apply_staged (gemm256p_kernel: 32 KB of the CU's LDS are free beside its two 64 KB buffers): the kernel left them at `sm` in front of its K loop -- no
+//     barrier, no global load here;
+template <int NF, int MF>
+__device__ __forceinline__ void fold256_apply_staged(const char* const sm, const int row_in_tile, const int col_in_tile, f32x4 (&acc)[MF][NF]) {
+    const f32x2* const sm2 = reinterpret_cast<const f32x2*>(sm);
+    const float* const ss = reinterpret_cast<const float*>(sm + 2048);
+    f32x4 s4[NF];
+#pragma unroll
+    for (int j = 0; j < NF; ++j) s4[j] = *reinterpret_cast<const f32x4*>(ss + col_in_tile + j * 16);
+#pragma unroll
+    for (int i = 0; i < MF; ++i) {
+        const f32x2 mr = sm2[row_in_tile + i * 16];
+        const float nm = -mr[0] * mr[1];
+#pragma unroll
+        for (int j = 0; j < NF; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[i][j][r] = __builtin_fmaf(s4[j][r], nm, acc[i][j][r] * mr[1]);
+    }
+}
+//   fold256_apply (gemm256s_kernel: its two buffers are the whole LDS): s_n and the bias columns c_n are requested together (ONE round trip: the kernel's epilogue
+//     would have paid it for the bias anyway; the caller hands `b` on as epilogue_tile's bpre), the statistics go through the first 2 KB of the idle buffers.
+template <int NF, int MF>
+__device__ __forceinline__ void fold256_apply(const GemmArgs& p, const float* __restrict__ bias, char* const smem, const int tid, const int row_in_tile, const int col,
+                                              const float mu, const float rstd, f32x4 (&acc)[MF][NF], f32x4 (&b)[NF]) {
+    f32x4 s4[NF];
+#pragma unroll
+    for (int j = 0; j < NF; ++j) {
+        s4[j] = ld_global<f32x4>(p.ln_s + col + j * 16);
+        b[j] = ld_global<f32x4>(bias + col + j * 16);
+    }
+    f32x2* const sm2 = reinterpret_cast<f32x2*>(smem);
+    if (!(tid & 1)) sm2[tid >> 1] = f32x2{mu, rstd};
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int i = 0; i < MF; ++i) {
+        const f32x2 mr = sm2[row_in_tile + i * 16];
+        const float nm = -mr[0] * mr[1];
+#pragma unroll
+        for (int j = 0; j < NF; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[i][j][r] = __builtin_fmaf(s4[j][r], nm, acc[i][j][r] * mr[1]);
+    }
+}
+
 // LN = false: the LN-fold paths (consumer: ln_stats / ln_s; producer: x16_out / copy32_out / stats_out / ln_shift) are compiled out -- the
 // chip-filling tile shapes never run them (launch_epi routes such calls to the small-tile kernels), and a load under a branch in front of
 // every row fragment's stores makes the compiler wait for vmcnt(0) at the join, i.e. for the previous fragment's stores.
@@ -291,9 +432,10 @@ __device__ __forceinline__ void epilogue_row(const GemmArgs& p, void* const outp
 // (profiles/r03_gemm256k_fixed.txt: a K = 64 launch 56 us with its epilogue, 11 us without).  Here everything that depends only on the column
 // (bias, bias2) is loaded once, and the row-dependent operands (old fp32 rows, positions -> table entries) BI fragments at a time, all in front
 // of that batch's stores.  Values and rounding are those of epilogue_row.
-template <class T, int EPI, int NF, int MF, int BI, bool LN, class LnF>
+template <class T, int EPI, int NF, int MF, int BI, bool LN, class LnF, bool FP = false>
 __device__ __forceinline__ void epilogue_tile(const GemmArgs& p, void* const outp, const float* __restrict__ bias, const int m_first,
                                               const int nw0, const int fg, f32x4 (&acc)[MF][NF], LnF lnf, const f32x4* bpre = nullptr) {
+    static_assert(!FP || (EPI == EPI_RESID_F32 && !LN && MF % 2 == 0 && NF == 4), "fold256 producer: the straight-line fp32 residual path of a 64-column wave tile");
     static_assert(MF % BI == 0, "batches of BI row fragments");
     const int nb = nw0 + fg * 4;
     const bool nobias = (EPI == EPI_F32 || EPI == EPI_HEAD) && p.accumulate;
@@ -312,8 +454,13 @@ __device__ __forceinline__ void epilogue_tile(const GemmArgs& p, void* const out
         // pair of row fragments are requested in front of this pair's stores and waited for with those stores still in flight (vmcnt(N) waits for
         // the older loads only).  One exposed round trip per tile instead of one per batch.  Same arithmetic as epilogue_row: x + (acc + bias).
         const int lane16 = (int)__lane_id() & 15;
-        if (m_first - lane16 + MF * 16 - 1 < p.M) {
+        if (FP || m_first - lane16 + MF * 16 - 1 < p.M) {   // (FP: launch_gemm checked M % 256 == 0)
             float* const o0 = reinterpret_cast<float*>(outp) + (size_t)m_first * p.ldc + nb;
+            float sh[MF];   // FP: the rows' shifts (GemmArgs::ln_shift), requested in front of everything else
+            if constexpr (FP) {
+#pragma unroll
+                for (int i = 0; i < MF; ++i) sh[i] = p.ln_shift != nullptr ? ld_global<float>(p.ln_shift + m_first + i * 16) : 0.f;
+            }
             f32x4 x[2][2][NF];
             auto ld = [&](int pair, int slot) {
 #pragma unroll
@@ -326,14 +473,24 @@ __device__ __forceinline__ void epilogue_tile(const GemmArgs& p, void* const out
             for (int pair = 0; pair < MF / 2; ++pair) {
                 if (pair + 1 < MF / 2) ld(pair + 1, (pair + 1) & 1);
 #pragma unroll
-                for (int ii = 0; ii < 2; ++ii)
+                for (int ii = 0; ii < 2; ++ii) {
+                    f32x4 xn[NF];
 #pragma unroll
                     for (int j = 0; j < NF; ++j) {
                         f32x4 v = acc[2 * pair + ii][j];
                         v += b[j];
-                        const f32x4 xn = x[pair & 1][ii][j] + v;
-                        st_global<f32x4>(o0 + (size_t)((2 * pair + ii) * 16) * p.ldc + j * 16, xn);
+                        xn[j] = x[pair & 1][ii][j] + v;
+                        st_global<f32x4>(o0 + (size_t)((2 * pair + ii) * 16) * p.ldc + j * 16, xn[j]);
                     }
+                    if constexpr (FP) {
+                        const int m = m_first + (2 * pair + ii) * 16;
+                        if (p.copy32_out != nullptr) {   // (kernel-uniform; stores only)
+#pragma unroll
+                            for (int j = 0; j < NF; ++j) st_global<f32x4>(p.copy32_out + (size_t)m * p.ldc + nb + j * 16, xn[j]);
+                        }
+                        fold256_emit<T>(p, m, nw0, fg, xn, sh[2 * pair + ii]);
+                    }
+                }
             }
             return;
         }
@@ -1288,10 +1445,14 @@ static int launch_256k(const GemmArgs& a, hipStream_t s) {
 // stores of tile i drain under the prologue of tile i + 1, issued straight behind them (the vendor's stream-K kernel has the same loop: profiles/r06_vendor_tile_boundary.txt).
 // LDS across the boundary: after the barrier that re-aligns the two wave groups at the end of the K loop every wave has retired its last fragment reads (lgkmcnt(0) in front of
 // its last load-interval barrier), the epilogue does not touch LDS, so the next prologue's DMA may start in any wave at once.  Same accumulation order: same bits.
-template <class T, int EPI, int WS, int BN, int NPH, int SYNC = 2, int PERS = 0>
+template <class T, int EPI, int WS, int BN, int NPH, int SYNC = 2, int PERS = 0, int FOLD = 0>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) gemm256p_kernel(const GemmArgs p) {
     typedef typename Vec<T>::v8 v8;
     constexpr int BM = 256, BK = 64;
+    // FOLD (r06): LayerNorm folded into the chip-filling launches (GemmArgs::fold256) -- consumer for the 16-bit-store epilogues, producer for the fp32 residual one
+    constexpr bool FOLDC = FOLD != 0 && (EPI == EPI_STORE16 || EPI == EPI_STORE16_GELU || EPI == EPI_QKV_ROPE);
+    constexpr bool FOLDP = FOLD != 0 && EPI == EPI_RESID_F32;
+    static_assert(FOLD == 0 || ((FOLDC || FOLDP) && PERS == 0 && SYNC == 2 && BN == 256 && sizeof(T) == 2), "fold256: 64-column wave tiles, one tile per block");
     static_assert((WS <= 2 && WS * BN == 256) || (WS == 3 && BN == 128), "the staged weight region is 256 rows: 256 plain columns or 128 columns hi + lo");
     static_assert(NPH == 2 || (NPH == 4 && WS == 1), "the four-phase form multiplies (a, b0) and (a, b1) in different phases: plain weights only");
     static_assert(WS != 3 || (NPH == 2 && SYNC == 2 && sizeof(T) == 2 && !__is_same(T, bf16_t)), "sparse low part: fp16, two-phase two-barrier form");
@@ -1418,6 +1579,9 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
     }
     f32x4 bpre[NF];   // bias columns, in front of the first DMA (gemm256k_kernel)
     epilogue_bias<EPI, NF>(p, bias, n0 + wc * WN, fg, bpre);
+    Fold256In fin;
+    float fmu = 0.f, frstd = 0.f;
+    if constexpr (FOLDC) fold256_issue(p, m0, n0, tid, fin);   // (fin.s: the tile's 256 s_n, on their way to LDS)
     unsigned lo_lane = 0, ix_lane = 0;   // WS = 3: this lane's 16 bytes of kept values of fragment 0 (fragment 1: + 16 rows x 64 B) and its dword of positions
     if constexpr (WS == 3) {
         const int rw = wc * 32 + fr;
@@ -1508,6 +1672,14 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
         else M3R_VMCNT(2);
     }
     __builtin_amdgcn_s_barrier();
+    if constexpr (FOLDC) {   // (its loads are older than the DMA the wait above covered)
+        fold256_landed(fin);
+        fold256_finish(p, m0, n0, tid, fin, fmu, frstd);
+        // behind the two buffers: [256] (mean, 1/sigma) | [256] s_n of the tile's columns; every barrier of the K loop lies between these writes and their reads
+        char* const fs = smem + 2 * BUFB;
+        if (!(tid & 1)) reinterpret_cast<f32x2*>(fs)[tid >> 1] = f32x2{fmu, frstd};
+        if (tid < 64) *reinterpret_cast<f32x4*>(fs + 2048 + tid * 16) = fin.s;
+    }
     if constexpr (SYNC == 2) {
     if (wr == 1) __builtin_amdgcn_s_barrier();   // group 1 runs one barrier behind
 
@@ -1617,7 +1789,8 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
 #undef M3R_P_LOAD_END
 #undef M3R_P_MUL_END
 
-    epilogue_tile<T, EPI, NF, MF, 4, false>(p, outp, bias, m0 + wr * 128 + fr, n0 + wc * WN, fg, acc, NoLnFold{}, bpre);
+    if constexpr (FOLDC) fold256_apply_staged<NF, MF>(smem + 2 * BUFB, wr * 128 + fr, wc * WN + fg * 4, acc);
+    epilogue_tile<T, EPI, NF, MF, 4, false, NoLnFold, FOLDP>(p, outp, bias, m0 + wr * 128 + fr, n0 + wc * WN, fg, acc, NoLnFold{}, bpre);
     if constexpr (PERS == 0) break;
     }
 }
@@ -1632,7 +1805,8 @@ static int persistent_blocks() {
     }
     return n;
 }
-// M3R_PERSIST (A/B instrument): 1 (default) the chip-filling kernels walk their tiles in a persistent loop when the launch has more than one round, 0 never
+// PERSIST (A/B instrument): 1 the chip-filling kernels walk their tiles in a persistent loop when the launch has more than one round, 0 (default) never.
+// Measured (profiles/r06_gemm_persist_ab.txt, one process, interleaved rounds, identical bits): x0.96 ... x1.04 per shape, x1.003 over the 16 shapes; step 526.1 (0) vs 523.6 (1) views/s.
 static int persist_mode() { return opt(OPT_PERSIST); }
 
 template <class T, int EPI, int WS, int BN, int NPH, int SYNC = 2>
@@ -1640,7 +1814,7 @@ static int launch_256p(const GemmArgs& a, hipStream_t s) {
     const int nbn = a.N / BN, nbm = (a.M + 255) / 256;
     const size_t lds = (size_t)2 * 4 * 128 * 64 * sizeof(T);
     const long nwork = (long)nbm * nbn * (a.batch > 1 ? a.batch : 1);
-    if (persist_mode() != 0 && nwork > persistent_blocks() && nwork < (1l << 30)) {
+    if (persist_mode() != 0 && !a.fold256 && nwork > persistent_blocks() && nwork < (1l << 30)) {
         static bool attr_set_p = false;
         if (!attr_set_p) {
             if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256p_kernel<T, EPI, WS, BN, NPH, SYNC, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return 1;
@@ -1649,6 +1823,18 @@ static int launch_256p(const GemmArgs& a, hipStream_t s) {
         hipLaunchKernelGGL((gemm256p_kernel<T, EPI, WS, BN, NPH, SYNC, 1>), dim3(persistent_blocks()), dim3(512), lds, s, a);
         return hipGetLastError() == hipSuccess ? 0 : 1;
     }
+    if constexpr (WS == 1 && BN == 256 && NPH == 2 && SYNC == 2 && sizeof(T) == 2 && (EPI == EPI_STORE16_GELU || EPI == EPI_RESID_F32)) {
+        if (a.fold256) {   // r06: the LN-fold forms (fc1 consumer, fc2 producer of the fp16wa mode)
+            static bool attr_set_f = false;
+            if (!attr_set_f) {
+                if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256p_kernel<T, EPI, WS, BN, NPH, SYNC, 0, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds + 4096) != hipSuccess) return 1;
+                attr_set_f = true;
+            }
+            hipLaunchKernelGGL((gemm256p_kernel<T, EPI, WS, BN, NPH, SYNC, 0, 1>), dim3(nbm * nbn, a.batch > 1 ? a.batch : 1), dim3(512), lds + 4096, s, a);   // + (mean, 1/sigma), s_n
+            return hipGetLastError() == hipSuccess ? 0 : 1;
+        }
+    }
+    if (a.fold256) return 1;
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256p_kernel<T, EPI, WS, BN, NPH, SYNC>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return 1;
@@ -1675,9 +1861,12 @@ static int launch_256p(const GemmArgs& a, hipStream_t s) {
 //     phase 1: read a1            | stage A0, H0 of t+2, load the positions of t+1 | vmcnt(8): H1, LO, A0, H0 of t+1 landed | 48 matrix instructions
 // Numerics: those of gemm256p_kernel<.., WS = 3> (hi products in k order, then the sparse low product of the K-tile): identical bits between the two.
 // PERS = 1 (r06): persistent tiles, as gemm256p_kernel (the positions' first load of the next tile goes out behind this tile's stores; in-order vmcnt covers it).
-template <class T, int EPI, int PERS = 0>
+template <class T, int EPI, int PERS = 0, int FOLD = 0>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) gemm256s_kernel(const GemmArgs p) {
     static_assert(sizeof(T) == 2 && !__is_same(T, bf16_t), "fp16 only");
+    constexpr bool FOLDC = FOLD != 0 && (EPI == EPI_STORE16 || EPI == EPI_STORE16_GELU || EPI == EPI_QKV_ROPE);   // r06: LN fold, as gemm256p_kernel
+    constexpr bool FOLDP = FOLD != 0 && EPI == EPI_RESID_F32;
+    static_assert(FOLD == 0 || ((FOLDC || FOLDP) && PERS == 0), "fold256: one tile per block");
     typedef typename Vec<T>::v8 v8;
     typedef __attribute__((ext_vector_type(16))) _Float16 f16x16;
     constexpr int BM = 256, BN = 256, BK = 64;
@@ -1785,6 +1974,9 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
         const int rl = wc * 64 + fr;
         lo_lane = 4 * HALFB + (unsigned)(rl * 64 + swz32(rl, fg) * 16);
     }
+    Fold256In fin;
+    float fmu = 0.f, frstd = 0.f;
+    if constexpr (FOLDC) fold256_issue(p, m0, n0, tid, fin);
     v8 af[2][4], bh[2][2][2], bl[4];
     int ix_nxt[2], ix_cur[2] = {0, 0};
     auto read_a = [&](int h, unsigned bufb) {
@@ -1810,7 +2002,8 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
         asm volatile("global_load_dword %0, %2, %3\n\tglobal_load_dword %1, %2, %3 offset:256" : "=&v"(ix_nxt[0]), "=&v"(ix_nxt[1]) : "v"(ix_lane), "s"(b0) : "memory");
     };
     auto take_ix = [&]() {
-        asm volatile("v_mov_b32 %0, %2\n\tv_mov_b32 %1, %3" : "=v"(ix_cur[0]), "=v"(ix_cur[1]) : "v"(ix_nxt[0]), "v"(ix_nxt[1]));
+        // (%0 is written before %3 is read: early-clobber, or the allocator may give ix_cur[0] the register of ix_nxt[1] -- it did in <EPI_F32, PERS = 1>)
+        asm volatile("v_mov_b32 %0, %2\n\tv_mov_b32 %1, %3" : "=&v"(ix_cur[0]), "=v"(ix_cur[1]) : "v"(ix_nxt[0]), "v"(ix_nxt[1]));
     };
     auto mma_h = [&](auto hc) {
         constexpr int h = decltype(hc)::value;
@@ -1844,6 +2037,10 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
     if (nk > 1) { stage(HA0{}, 1); stage(HH0{}, 1); load_ix(0); M3R_VMCNT(8); }
     else { load_ix(0); M3R_VMCNT(4); }
     __builtin_amdgcn_s_barrier();
+    if constexpr (FOLDC) {   // (its loads are older than the DMA the wait above covered)
+        fold256_landed(fin);
+        fold256_finish(p, m0, n0, tid, fin, fmu, frstd);
+    }
     if (wr == 1) __builtin_amdgcn_s_barrier();   // group 1 runs one barrier behind
 
     auto ktile = [&](auto remc, int t) {
@@ -1870,7 +2067,12 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
 #undef M3R_P_LOAD_END
 #undef M3R_P_MUL_END
 
-    epilogue_tile<T, EPI, NF, MF, 4, false>(p, outp, bias, m0 + wr * 128 + fr, n0 + wc * WN, fg, acc, NoLnFold{});
+    if constexpr (FOLDC) {
+        f32x4 fb[NF];
+        fold256_apply<NF, MF>(p, bias, smem, tid, wr * 128 + fr, n0 + wc * WN + fg * 4, fmu, frstd, acc, fb);
+        epilogue_tile<T, EPI, NF, MF, 4, false, NoLnFold, false>(p, outp, bias, m0 + wr * 128 + fr, n0 + wc * WN, fg, acc, NoLnFold{}, fb);
+    } else
+    epilogue_tile<T, EPI, NF, MF, 4, false, NoLnFold, FOLDP>(p, outp, bias, m0 + wr * 128 + fr, n0 + wc * WN, fg, acc, NoLnFold{});
     if constexpr (PERS == 0) break;
     }
 }
@@ -1880,7 +2082,7 @@ static int launch_256s(const GemmArgs& a, hipStream_t s) {
     const int nbn = a.N / 256, nbm = (a.M + 255) / 256;
     const size_t lds = (size_t)2 * 5 * 128 * 64 * sizeof(T);   // 163840 B: the CU's whole LDS
     const long nwork = (long)nbm * nbn * (a.batch > 1 ? a.batch : 1);
-    if (persist_mode() != 0 && nwork > persistent_blocks() && nwork < (1l << 30)) {
+    if (persist_mode() != 0 && !a.fold256 && nwork > persistent_blocks() && nwork < (1l << 30)) {
         static bool attr_set_p = false;
         if (!attr_set_p) {
             if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256s_kernel<T, EPI, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return 1;
@@ -1889,6 +2091,18 @@ static int launch_256s(const GemmArgs& a, hipStream_t s) {
         hipLaunchKernelGGL((gemm256s_kernel<T, EPI, 1>), dim3(persistent_blocks()), dim3(512), lds, s, a);
         return hipGetLastError() == hipSuccess ? 0 : 1;
     }
+    if constexpr (EPI == EPI_STORE16 || EPI == EPI_QKV_ROPE || EPI == EPI_RESID_F32) {
+        if (a.fold256) {   // r06: the LN-fold forms (qkv / projq consumers, proj producer)
+            static bool attr_set_f = false;
+            if (!attr_set_f) {
+                if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256s_kernel<T, EPI, 0, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return 1;
+                attr_set_f = true;
+            }
+            hipLaunchKernelGGL((gemm256s_kernel<T, EPI, 0, 1>), dim3(nbm * nbn, a.batch > 1 ? a.batch : 1), dim3(512), lds, s, a);
+            return hipGetLastError() == hipSuccess ? 0 : 1;
+        }
+    }
+    if (a.fold256) return 1;
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256s_kernel<T, EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return 1;
@@ -2395,9 +2609,31 @@ static int g256p_mode(bool split) { return opt(split ? OPT_G256P_SPLIT : OPT_G25
 // (r04, measured and removed: the same two-blocks-per-CU form for the PLAIN-weight GELU launches instead of gemm256k -- enc fc1 146.8 -> 172.8 us, dec fc1 92.6 ->
 // 105.4 us, step 495.9 -> 486.3 views/s: the 64-byte DMA rows and 256 x 128 tiles cost more than the hidden erf epilogue (~8 us of a 39 us tile) gives back.
 // profiles/r04_plain_gelu_occ2.txt.)
+// r06: does the default dispatch below send a chip-filling launch of this shape to gemm256s_kernel (split, sparse low part) / gemm256p_kernel<.., 1, 256> (plain)?
+// Only then is the LN fold offered (kernels.hpp): forcing 256 x 256 tiles on a launch the fill rule gives to another tile would cost more than the fold returns.
+bool gemm_fold256_shape_ok(int M, int N, int K, bool split) {
+    if (M <= 0 || M % 256 != 0 || N % 256 != 0 || K % 64 != 0 || gemm256_mode() != 1) return false;
+    const long rb256 = M / 256, t256 = rb256 * (N / 256), t128 = rb256 * (N / 128);
+    if (t256 < 200 || fill256(t256) < 80) return false;
+    if (!split) return g256p_mode(false) != 0;
+    return g256p_mode(true) != 0 && opt(OPT_SPARSE_256) != 0 && opt(OPT_SPARSE_LO) != 0 && fill256(t256) + 12 >= fill256(t128);
+}
+
 template <class T, int EPI>
 static int launch_epi(const GemmArgs& a, hipStream_t s, const char** err) {
     const long nb = a.batch > 1 ? a.batch : 1;
+    if (a.fold256) {   // r06: the LN fold on the chip-filling tiles -- the caller asked gemm_fold256_shape_ok first; launch_gemm validated the operands
+        int rc = 1;
+        if constexpr (sizeof(T) == 2 && std::is_same<T, f16_t>::value) {
+            if (a.wsplit == 2) {
+                if constexpr (EPI == EPI_STORE16 || EPI == EPI_QKV_ROPE || EPI == EPI_RESID_F32) { pick_name("g256sf", EPI, 3, 256); rc = launch_256s<T, EPI>(a, s); }
+            } else {
+                if constexpr (EPI == EPI_STORE16_GELU || EPI == EPI_RESID_F32) { pick_name("g256pf", EPI, 1, 256); rc = launch_256p<T, EPI, 1, 256, 2>(a, s); }
+            }
+        }
+        if (rc) *err = "gemm: fold256 is built for fp16: split STORE16 / QKV_ROPE / RESID_F32 and plain STORE16_GELU / RESID_F32";
+        return rc;
+    }
     // LN-fold producers (x16_out / copy32_out / stats_out) need a kernel whose epilogue carries the LN paths: the 64 x 64 / 96 / 48 tiles
     const bool lnp = a.x16_out != nullptr || a.copy32_out != nullptr || a.stats_out != nullptr;
     const int mode = lnp ? 0 : gemm256_mode();
@@ -2508,6 +2744,15 @@ int launch_gemm(DType dt, Epi epi, const GemmArgs& a, hipStream_t s, const char*
         *err = "gemm: rope epilogue needs pos, table and 64-aligned rope_cols"; return 1;
     }
     if (epi == EPI_HEAD && (a.N % 112 != 0 || a.ntok <= 0 || a.gw <= 0)) { *err = "gemm: head epilogue geometry"; return 1; }
+    if (a.fold256) {
+        const bool cons = epi == EPI_STORE16 || epi == EPI_STORE16_GELU || epi == EPI_QKV_ROPE;
+        if (dt != DT_F16 || a.batch > 1 || a.N % 256 != 0 || a.K % 64 != 0 || (!cons && epi != EPI_RESID_F32)) { *err = "gemm: fold256 needs fp16, one problem, N % 256 == 0"; return 1; }
+        if (cons && (a.ln_stats == nullptr || a.ln_s == nullptr || a.bias == nullptr || a.ln_shift == nullptr || (a.K != 768 && a.K != 1024) || a.x16_out || a.stats_out || a.copy32_out)) {
+            *err = "gemm: fold256 consumer needs ln_stats, ln_s, bias, ln_shift and K = 768 or 1024"; return 1;
+        }
+        if (!cons && (a.x16_out == nullptr || a.stats_out == nullptr || a.M % 256 != 0 || a.ln_stats != nullptr)) { *err = "gemm: fold256 producer needs x16_out, stats_out, M % 256 == 0"; return 1; }
+        if (a.wsplit == 2 && (a.Wlo_sp == nullptr || a.Widx_sp == nullptr)) { *err = "gemm: fold256 on split weights needs the packed sparse low part"; return 1; }
+    } else
     if (a.ln_stats != nullptr) {
         const bool epi_ok = epi == EPI_STORE16 || epi == EPI_STORE16_GELU || epi == EPI_QKV_ROPE;
         if (!epi_ok || a.ln_s == nullptr || (a.wsplit != 2 && a.wsplit != 0) || dt != DT_F16 || a.K != 16 * LNF_SLOTS || (a.batch > 1)) {
@@ -2520,7 +2765,7 @@ int launch_gemm(DType dt, Epi epi, const GemmArgs& a, hipStream_t s, const char*
         return 1;
     }
     // the consumer of the statistics reads LNF_SLOTS fragments per row (its K = 768): a producer of another width would pair with misaligned rows
-    if (a.stats_out && a.N != 16 * LNF_SLOTS) { *err = "gemm: stats_out (LN-fold producer) needs N = 768"; return 1; }
+    if (!a.fold256 && a.stats_out && a.N != 16 * LNF_SLOTS) { *err = "gemm: stats_out (LN-fold producer) needs N = 768"; return 1; }
     return dt == DT_BF16 ? launch_t<bf16_t>(epi, a, s, err) : launch_t<f16_t>(epi, a, s, err);
 }
 

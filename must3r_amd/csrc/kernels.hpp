@@ -82,6 +82,11 @@ struct GemmArgs {
     //     column-0 blocks leave shift += mean(y) (= the current row mean) for the next producer.  ln_shift_init: the buffer holds nothing yet.
     float* ln_shift;
     int ln_shift_init;
+    // r06: the same fold on the chip-filling 256 x 256 tiles (gemm256s_kernel / gemm256p_kernel<.., WS = 1, BN = 256, FOLD = 1>; batched decoder calls and the encoder).
+    //   fold256 = 1 on a producer (EPI_RESID_F32; needs M % 256 == 0, N % 256 == 0): x16_out rows + ONE (sum, sum of squares) per row and 64-column wave tile in
+    //     stats_out [M][N/64][2] (+ copy32_out);  on a consumer (STORE16 / STORE16_GELU / QKV_ROPE; K = 768 or 1024): ln_stats is that [M][K/64][2] layout.
+    //   ln_shift (required on consumers) must hold valid values (zeros at the start of a call): every consumer adds the mean it measured (ln_shift_init is ignored).
+    int fold256;
 #ifdef GEMM_TRACE
     int trace_block;         // probe builds only (scripts/probes/gemm256p_trace.hip): the block whose waves leave cycle stamps
 #endif
@@ -91,6 +96,9 @@ struct GemmArgs {
 int launch_gemm(DType dt, Epi epi, const GemmArgs& a, hipStream_t s, const char** err);
 // the kernel the calling thread's last launch_gemm picked: "<family>/e<EPI>/w<WS>/n<BN>" (one symbol of a kernel trace)
 const char* gemm_last_kernel();
+// r06: would launch_gemm route a launch of this shape to the 256 x 256 kernels that carry the LN fold (GemmArgs::fold256)?  split = [hi | lo] weights with a packed
+// 2:4-sparse low part (gemm256s_kernel), else plain fp16 weights (gemm256p_kernel).  The model folds a call's LayerNorms only when every Linear around them says yes.
+bool gemm_fold256_shape_ok(int M, int N, int K, bool split);
 
 // ---------------------------------------------------------------------------------------------
 // fused softmax attention, head dim 64, flash-style (no N x M score matrix in HBM)
@@ -128,7 +136,21 @@ struct AttnArgs {
     int fp8;               // Q and K are OCP e4m3 bytes (ldq / ldk in BYTES): Q K^T runs on v_mfma_scale_f32_32x32x64_f8f6f4; V (ldv in elements), the
                            // softmax numerators and O stay 16-bit (attn4_kernel<.., F8 = true>; DESIGN.md section 4 for why V does)
     int max_nk;            // max over views of nk when the host knows it (0: unknown): lets the launcher refuse K / V spans of 2 GiB or more
+    // r06 (context-parallel cross attention): distance between the partials of two splits / slots, in elements of part_o (fp32, or the 16-bit type with part16)
+    // and in floats of part_ml; 0 = the dense default total_q_rows * heads * 64 / total_q_rows * heads * 2.  Read by the combine kernels only.
+    long long part_stride_o, part_stride_ml;
 };
+// r06, context-parallel cross attention over a memory sharded across ranks (SURVEY.md section 8f "later"; decoder.py:301-321 with the keys of one view spread over
+// `world` processes).  A rank's contribution to one layer is ONE fp32 partial per query row: un-normalised O = sum_k 2^(s_k - m) v_k over ITS keys [rows][heads*64],
+// and (m, l) = (reference in the log2 domain, row sum) [rows][heads][2] -- the split-KV partial format one level up.
+//   launch_attention_partial_merge: the nsplit local split-KV partials of `a` (layout of launch_attention_phase(.., 1, ..)) -> one such partial in (out_o, out_ml)
+//   launch_attention_partial_empty: the partial of a rank that holds no key: O = 0, (m, l) = (-inf, 0)
+//   launch_attention_partial_final: `nslots` partials at slots_o + s * stride_o / slots_ml + s * stride_ml (floats) -> normalised 16-bit output a.O (ldo)
+// One slot in, `final` reproduces bit for bit what launch_attention_phase(.., 2, ..) writes for the same splits (same sums in the same order, 2^0 = 1).
+int launch_attention_partial_merge(DType dt, const AttnArgs& a, float* out_o, float* out_ml, hipStream_t s, const char** err);
+int launch_attention_partial_empty(float* out_o, float* out_ml, int rows, int heads, hipStream_t s, const char** err);
+int launch_attention_partial_final(DType dt, const AttnArgs& a, const float* slots_o, const float* slots_ml, long long stride_o, long long stride_ml, int nslots,
+                                   hipStream_t s, const char** err);
 // bytes of scratch launch_attention needs for a given split factor
 size_t attention_split_scratch_bytes(int nsplit, int total_q_rows, int heads);
 // heuristic split factor for a launch

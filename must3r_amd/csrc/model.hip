@@ -560,6 +560,34 @@ static int fetch(must3r_hip_ctx* c, const std::string& name, std::vector<float>&
     return 0;
 }
 
+// "LN fold" operands of a Linear that follows a LayerNorm: W' = gamma (.) W, s_n = sum_k W'[n][k], c_n = (W beta + b)_n, so that
+// LN(x) W^T + b = rstd (x W'^T - mu s) + c.  Derived parameters <block>.<linear>_ln.{weight, s, c}.
+static int derive_ln_fold(must3r_hip_ctx* c, const std::string& pb, const char* norm, const char* lin) {
+    std::vector<float> w, bb, gam, bet;
+    M3R_OK(fetch(c, pb + lin + ".weight", w));
+    M3R_OK(fetch(c, pb + lin + ".bias", bb));
+    M3R_OK(fetch(c, pb + norm + ".weight", gam));
+    M3R_OK(fetch(c, pb + norm + ".bias", bet));
+    const size_t K = gam.size(), N = bb.size();
+    if (w.size() != N * K || bet.size() != K) return fail("finalize: LN-fold shapes of %s%s", pb.c_str(), lin);
+    std::vector<float> sn(N), cn(N);
+    for (size_t n = 0; n < N; ++n) {
+        double ss = 0.0, cc = bb[n];
+        float* row = &w[n * K];
+        for (size_t k = 0; k < K; ++k) {
+            cc += (double)bet[k] * row[k];
+            row[k] *= gam[k];
+            ss += row[k];
+        }
+        sn[n] = (float)ss;
+        cn[n] = (float)cc;
+    }
+    M3R_OK(derive(c, pb + lin + "_ln.weight", {(int64_t)N, (int64_t)K}, w));
+    M3R_OK(derive(c, pb + lin + "_ln.s", {(int64_t)N}, sn));
+    M3R_OK(derive(c, pb + lin + "_ln.c", {(int64_t)N}, cn));
+    return 0;
+}
+
 extern "C" int must3r_hip_finalize_weights(must3r_hip_ctx* c, int parts) {
     if (!c) return fail("finalize: null context");
     if (!(parts & 3)) return fail("finalize: parts must include MUST3R_PART_ENCODER and/or MUST3R_PART_DECODER");
@@ -587,7 +615,16 @@ extern "C" int must3r_hip_finalize_weights(must3r_hip_ctx* c, int parts) {
         if (!c->rope_tab) HIP_OK(hipMalloc(reinterpret_cast<void**>(&c->rope_tab), t.size() * sizeof(float)));
         HIP_OK(hipMemcpy(c->rope_tab, t.data(), t.size() * sizeof(float), hipMemcpyHostToDevice));
     }
-    if (parts & 1) c->fin_enc = true;
+    if (parts & 1) {
+        // r06: LN-fold operands of the encoder blocks (norm1 -> attn.qkv, norm2 -> mlp.fc1) for the chip-filling launches (GemmArgs::fold256)
+        for (int l = 0; l < c->cfg.enc_depth; ++l) {
+            const std::string pb = "encoder.blocks_enc." + std::to_string(l) + ".";
+            M3R_OK(derive_ln_fold(c, pb, "norm1", "attn.qkv"));
+            M3R_OK(derive_ln_fold(c, pb, "norm2", "mlp.fc1"));
+        }
+        c->enc_tab.clear();
+        c->fin_enc = true;
+    }
     if (!(parts & 2)) return 0;
     const must3r_hip_config& g = c->cfg;
     const int D = g.dec_dim;
@@ -634,37 +671,12 @@ extern "C" int must3r_hip_finalize_weights(must3r_hip_ctx* c, int parts) {
         M3R_OK(derive(c, "decoder.head_dec.proj_ps.weight", {7 * P, D}, w2));
         M3R_OK(derive(c, "decoder.head_dec.proj_ps.bias", {7 * P}, b2));
     }
-    // "LN fold" operands of the one-view memory update: for the three Linears that follow a LayerNorm,
-    // W' = gamma (.) W, s_n = sum_k W'[n][k], c_n = (W beta + b)_n, so that LN(x) W^T + b = rstd (x W'^T - mu s) + c.
-    {
-        const char* pairs[3][2] = {{"norm1", "attn.qkv"}, {"norm2", "cross_attn.projq"}, {"norm3", "mlp.fc1"}};
-        std::vector<float> w, bb, gam, bet;
-        for (int l = 0; l < g.dec_depth; ++l) {
-            const std::string pb = "decoder.blocks_dec." + std::to_string(l) + ".";
-            for (auto& pr : pairs) {
-                M3R_OK(fetch(c, pb + pr[1] + ".weight", w));
-                M3R_OK(fetch(c, pb + pr[1] + ".bias", bb));
-                M3R_OK(fetch(c, pb + pr[0] + ".weight", gam));
-                M3R_OK(fetch(c, pb + pr[0] + ".bias", bet));
-                const size_t K = gam.size(), N = bb.size();
-                if (w.size() != N * K || bet.size() != K) return fail("finalize: LN-fold shapes of %s%s", pb.c_str(), pr[1]);
-                std::vector<float> sn(N), cn(N);
-                for (size_t n = 0; n < N; ++n) {
-                    double ss = 0.0, cc = bb[n];
-                    float* row = &w[n * K];
-                    for (size_t k = 0; k < K; ++k) {
-                        cc += (double)bet[k] * row[k];
-                        row[k] *= gam[k];
-                        ss += row[k];
-                    }
-                    sn[n] = (float)ss;
-                    cn[n] = (float)cc;
-                }
-                M3R_OK(derive(c, pb + pr[1] + "_ln.weight", {(int64_t)N, (int64_t)K}, w));
-                M3R_OK(derive(c, pb + pr[1] + "_ln.s", {(int64_t)N}, sn));
-                M3R_OK(derive(c, pb + pr[1] + "_ln.c", {(int64_t)N}, cn));
-            }
-        }
+    // "LN fold" operands of the decoder blocks (one-view memory updates since r02, chip-filling batched calls since r06): the three Linears that follow a LayerNorm
+    for (int l = 0; l < g.dec_depth; ++l) {
+        const std::string pb = "decoder.blocks_dec." + std::to_string(l) + ".";
+        M3R_OK(derive_ln_fold(c, pb, "norm1", "attn.qkv"));
+        M3R_OK(derive_ln_fold(c, pb, "norm2", "cross_attn.projq"));
+        M3R_OK(derive_ln_fold(c, pb, "norm3", "mlp.fc1"));
     }
     c->dec_tab.clear();   // rebuilt on the next decode (the derived entries above may be new)
     c->fin_dec = true;
@@ -687,6 +699,17 @@ static int encode_chunk(must3r_hip_ctx* c, DType dt, const float* img, int V, in
     need = ws_need(need, (size_t)R * C, 2);
     need = ws_need(need, (size_t)R * F, 2);
     need = ws_need(need, c->attn8 ? (size_t)R * 2 * C : 0, 1);
+    // r06, LN fold on the chip-filling launches (GemmArgs::fold256; MUST3R_F16_WA): norm1 of blocks 1.. and norm2 of every block are not launched -- the residual
+    // GEMM in front of them (fc2 of the previous block / proj) leaves the shifted rows in fp16 + per-wave-tile sums, qkv / fc1 normalise after their product.
+    // Block 0's norm1 keeps its kernel (its rows come from the patch embedding, an EPI_F32 launch).  Only when every Linear of the block lands on the fold kernels.
+    if (c->enc_tab.empty()) build_layer_tables(c, false);
+    const bool f256 = opt(OPT_LNFOLD256) != 0 && dt == DT_F16 && c->wsplit == 2 && c->mlp_plain && !c->attn8 && (C == 768 || C == 1024) &&
+                      c->enc_tab[0][LF_QKVLN_W] && c->enc_tab[0][LF_FC1LN_W] &&
+                      gemm_fold256_shape_ok(R, 3 * C, C, true) && gemm_fold256_shape_ok(R, C, C, true) &&
+                      gemm_fold256_shape_ok(R, F, C, false) && gemm_fold256_shape_ok(R, C, F, false);
+    need = ws_need(need, f256 ? (size_t)R * C : 0, 2);                 // x16: the shifted residual rows in fp16
+    need = ws_need(need, f256 ? (size_t)R * (C / 64) * 2 : 0, 4);      // per row and 64-column wave tile (sum, sum of squares)
+    need = ws_need(need, f256 ? (size_t)R : 0, 4);                     // per row: the current mean (GemmArgs::ln_shift)
     M3R_OK(ws_reserve(c, need, s));
     uint16_t* P16 = ws_take<uint16_t>(c, (size_t)R * 768);
     float* x = ws_take<float>(c, (size_t)R * C);
@@ -695,7 +718,15 @@ static int encode_chunk(must3r_hip_ctx* c, DType dt, const float* img, int V, in
     uint16_t* a16 = ws_take<uint16_t>(c, (size_t)R * C);
     uint16_t* g16 = ws_take<uint16_t>(c, (size_t)R * F);
     uint8_t* q8 = c->attn8 ? ws_take<uint8_t>(c, (size_t)R * 2 * C) : nullptr;
-    if (!g16 || (c->attn8 && !q8)) return fail("encode: workspace sizing bug");
+    uint16_t* x16 = f256 ? ws_take<uint16_t>(c, (size_t)R * C) : nullptr;
+    float* lnstats = f256 ? ws_take<float>(c, (size_t)R * (C / 64) * 2) : nullptr;
+    float* lnshift = f256 ? ws_take<float>(c, (size_t)R) : nullptr;
+    if (!g16 || (c->attn8 && !q8) || (f256 && !lnshift)) return fail("encode: workspace sizing bug");
+    if (f256) HIP_OK(hipMemsetAsync(lnshift, 0, (size_t)R * sizeof(float), s));
+    auto fold_in = [&](GemmArgs& g_, const Param* sn, const Param* cn) {
+        g_.A = x16; g_.ln_stats = lnstats; g_.ln_s = sn->d; g_.bias = cn->d; g_.ln_eps = 1e-6f; g_.ln_shift = lnshift; g_.fold256 = 1;
+    };
+    auto fold_out = [&](GemmArgs& g_) { g_.x16_out = x16; g_.stats_out = lnstats; g_.ln_shift = lnshift; g_.fold256 = 1; };
 
     {
         ProfScope ps(c, s, PC_MISC, 0.0);
@@ -707,16 +738,18 @@ static int encode_chunk(must3r_hip_ctx* c, DType dt, const float* img, int V, in
     void* views_dev = nullptr;
     M3R_OK(upload_table(c, views.data(), sizeof(AttnView) * V, &views_dev, s));
 
-    if (c->enc_tab.empty()) build_layer_tables(c, false);
     const void* w;
     M3R_OK(w16(c, "encoder.patch_embed.proj.weight", dt, &w, s));
     M3R_OK(gemm(c, dt, EPI_F32, gargs(P16, w, p32(c, "encoder.patch_embed.proj.bias"), x, R, C, 768, 768, C), s));
     for (int l = 0; l < g.enc_depth; ++l) {
         const std::vector<Param*>& LP = c->enc_tab[l];
-        M3R_OK(layernorm(c, dt, x, nullptr, LP[LF_N1W]->d, LP[LF_N1B]->d, h16, nullptr, nullptr,
-                         nullptr, R, C, 1e-6f, s));
-        M3R_OK(w16p(c, *LP[LF_QKVW], dt, &w, s));
+        const bool fq = f256 && l > 0;
+        if (!fq)
+            M3R_OK(layernorm(c, dt, x, nullptr, LP[LF_N1W]->d, LP[LF_N1B]->d, h16, nullptr, nullptr,
+                             nullptr, R, C, 1e-6f, s));
+        M3R_OK(w16p(c, *LP[fq ? LF_QKVLN_W : LF_QKVW], dt, &w, s));
         GemmArgs ga = gargs(h16, w, LP[LF_QKVB]->d, qkv, R, 3 * C, C, C, 3 * C);
+        if (fq) fold_in(ga, LP[LF_QKVLN_S], LP[LF_QKVLN_C]);
         ga.pos = out_pos; ga.rope_tab = c->rope_tab; ga.rope_cols = 2 * C; ga.rope_npos = c->rope_npos;
         ga.out_scale = kQScale; ga.scale_cols = C;   // q *= 1/sqrt(64) * log2(e)
         M3R_OK(gemm(c, dt, EPI_QKV_ROPE, ga, s));
@@ -733,14 +766,27 @@ static int encode_chunk(must3r_hip_ctx* c, DType dt, const float* img, int V, in
         aa.max_nk = N;
         M3R_OK(attention(c, dt, aa, 4.0 * V * (double)N * N * C, PC_ATTN_SA, s));
         M3R_OK(w16p(c, *LP[LF_PROJW], dt, &w, s));
-        M3R_OK(gemm(c, dt, EPI_RESID_F32, gargs(a16, w, LP[LF_PROJB]->d, x, R, C, C, C, C), s));
-        M3R_OK(layernorm(c, dt, x, nullptr, LP[LF_N2W]->d, LP[LF_N2B]->d, h16, nullptr, nullptr,
-                         nullptr, R, C, 1e-6f, s));
+        {
+            GemmArgs gp = gargs(a16, w, LP[LF_PROJB]->d, x, R, C, C, C, C);
+            if (f256) fold_out(gp);
+            M3R_OK(gemm(c, dt, EPI_RESID_F32, gp, s));
+        }
+        if (!f256)
+            M3R_OK(layernorm(c, dt, x, nullptr, LP[LF_N2W]->d, LP[LF_N2B]->d, h16, nullptr, nullptr,
+                             nullptr, R, C, 1e-6f, s));
         int ws;
-        M3R_OK(wmlp(c, *LP[LF_FC1W], dt, &w, &ws, s));
-        M3R_OK(gemm(c, dt, EPI_STORE16_GELU, gargs(h16, w, LP[LF_FC1B]->d, g16, R, F, C, C, F), s, ws));
+        M3R_OK(wmlp(c, *LP[f256 ? LF_FC1LN_W : LF_FC1W], dt, &w, &ws, s));
+        {
+            GemmArgs g1 = gargs(h16, w, LP[LF_FC1B]->d, g16, R, F, C, C, F);
+            if (f256) fold_in(g1, LP[LF_FC1LN_S], LP[LF_FC1LN_C]);
+            M3R_OK(gemm(c, dt, EPI_STORE16_GELU, g1, s, ws));
+        }
         M3R_OK(wmlp(c, *LP[LF_FC2W], dt, &w, &ws, s));
-        M3R_OK(gemm(c, dt, EPI_RESID_F32, gargs(g16, w, LP[LF_FC2B]->d, x, R, C, F, F, C), s, ws));
+        {
+            GemmArgs g2 = gargs(g16, w, LP[LF_FC2B]->d, x, R, C, F, F, C);
+            if (f256 && l + 1 < g.enc_depth) fold_out(g2);   // the next block's norm1
+            M3R_OK(gemm(c, dt, EPI_RESID_F32, g2, s, ws));
+        }
     }
     M3R_OK(layernorm(c, dt, x, nullptr, p32(c, "encoder.norm_enc.weight"), p32(c, "encoder.norm_enc.bias"), nullptr, nullptr,
                      out_tokens, nullptr, R, C, 1e-6f, s));
@@ -823,8 +869,12 @@ static int decode_impl(must3r_hip_ctx* c, const must3r_hip_decode_args* A, void*
     const int R = S * Rs, total_views = S * views_s;
     const bool one_block = A->n_groups == 1;                           // a group's [S, n_views, n_tokens] rows ARE the call's row order
     const bool update = !A->render;
-    const bool use_mask = update && (Nm > 0 || views_s > 1);           // decoder.py:199 / :293
-    const bool lone_view = update && views_s == 1 && Nm > 0;           // own tokens excluded -> keys = old memory only
+    // r06, context-parallel cross attention (include/must3r_hip.h must3r_hip_cp): Nm = THIS rank's shard of the memory (possibly empty), the call's semantics
+    // follow the GLOBAL row count (validated by must3r_hip_decode: one-view update of one scene, 'kv' memory, 16-bit attention)
+    const must3r_hip_cp* cp = A->cp;
+    const int Nm_global = cp ? cp->n_mem_total : Nm;
+    const bool use_mask = update && (Nm_global > 0 || views_s > 1);    // decoder.py:199 / :293
+    const bool lone_view = update && views_s == 1 && Nm_global > 0;    // own tokens excluded -> keys = old memory only
     const bool need_pre_kv = update && !lone_view;                     // pre-feedback K|V of the new tokens are attended
 
     // ---- workspace
@@ -848,12 +898,20 @@ static int decode_impl(must3r_hip_ctx* c, const must3r_hip_decode_args* A, void*
     // (S > 1: the consumers of the fold only exist on the small-M tile shapes; a batched call is past the launch floor the fold removes)
     const bool lnf = lnf_on && update && !need_pre_kv && c->wsplit == 2 && dt == DT_F16 && !a8 && !A->feats && A->n_groups == 1 &&
                      S == 1 && D == 768 && F % 96 == 0;
-    need = ws_need(need, lnf ? (size_t)R * D : 0, 2);                 // x16: the residual stream rounded to fp16
-    need = ws_need(need, lnf ? (size_t)R * (D / 16) * 2 : 0, 4);      // per row and 16-column fragment (sum, sum of squares)
-    need = ws_need(need, lnf ? (size_t)R : 0, 4);                     // per row: the mean the last consumer measured (shift of the next rows)
+    // r06: the same fold on the chip-filling launches of a batched call -- update or render -- (GemmArgs::fold256; MUST3R_F16_WA): block 0's norm1 keeps its kernel
+    // (its rows come from an EPI_F32 launch), every other norm1 / norm2 / norm3 is folded.  Only when every Linear of the block lands on the fold kernels.
+    const bool f256 = !lnf && opt(OPT_LNFOLD256) != 0 && c->wsplit == 2 && c->mlp_plain && dt == DT_F16 && !a8 && !A->feats && !A->cp && (D == 768 || D == 1024) &&
+                      gemm_fold256_shape_ok(R, 3 * D, D, true) && gemm_fold256_shape_ok(R, D, D, true) &&
+                      gemm_fold256_shape_ok(R, F, D, false) && gemm_fold256_shape_ok(R, D, F, false);
+    const bool lnF = lnf || f256;
+    need = ws_need(need, lnF ? (size_t)R * D : 0, 2);                 // x16: the residual stream rounded to fp16
+    need = ws_need(need, lnF ? (size_t)R * (D / 16) * 2 : 0, 4);      // per row and 16-column fragment (f256: 64-column wave tile) (sum, sum of squares)
+    need = ws_need(need, lnF ? (size_t)R : 0, 4);                     // per row: the mean the last consumer measured (shift of the next rows)
     // split-KV cross attention when the launch cannot fill the chip (sequential memory update: one view per call)
     const int max_nk_ca = A->render ? Nm : Nm + (lone_view ? 0 : Rs);
-    const int ca_split = attention_pick_split(total_views, Hh, max_n, max_nk_ca);
+    // (context parallel: the local attention always leaves split-KV partials -- at least two splits, an empty one costs nothing -- for the partial merge)
+    int ca_split = attention_pick_split(total_views, Hh, max_n, max_nk_ca);
+    if (cp) ca_split = Nm > 0 ? (ca_split > 2 ? ca_split : 2) : 0;
     const size_t split_bytes = attention_split_scratch_bytes(ca_split, R, Hh);
     need = ws_need(need, split_bytes, 1);
     // memory_mode 'norm_y' / 'raw': the memory holds (normalised / raw) tokens, K|V of ALL attended rows are projected
@@ -884,10 +942,11 @@ static int decode_impl(must3r_hip_ctx* c, const must3r_hip_decode_args* A, void*
     float* newmem = update ? ws_take<float>(c, (size_t)L * R * D) : nullptr;
     float* off32 = update ? ws_take<float>(c, (size_t)R * D) : nullptr;
     uint16_t* yall = update ? ws_take<uint16_t>(c, (size_t)L * R * D) : nullptr;
-    uint16_t* x16 = lnf ? ws_take<uint16_t>(c, (size_t)R * D) : nullptr;
-    float* lnstats = lnf ? ws_take<float>(c, (size_t)R * (D / 16) * 2) : nullptr;
-    float* lnshift = lnf ? ws_take<float>(c, (size_t)R) : nullptr;
+    uint16_t* x16 = lnF ? ws_take<uint16_t>(c, (size_t)R * D) : nullptr;
+    float* lnstats = lnF ? ws_take<float>(c, (size_t)R * (D / 16) * 2) : nullptr;
+    float* lnshift = lnF ? ws_take<float>(c, (size_t)R) : nullptr;
     bool lnshift_fresh = true;   // nothing measured yet in this call: the first consumer starts the estimate
+    if (f256) HIP_OK(hipMemsetAsync(lnshift, 0, (size_t)R * sizeof(float), s));   // (the fold256 consumers add to it; its first producer reads zeros)
     char* split_ws = split_bytes ? ws_take<char>(c, split_bytes) : nullptr;
     uint16_t* kvs = kvs_rows ? ws_take<uint16_t>(c, kvs_rows * 2 * D) : nullptr;
     uint16_t* ytmp = (mode == MUST3R_MEM_RAW && kvs_rows) ? ws_take<uint16_t>(c, kvs_rows * D) : nullptr;
@@ -1035,17 +1094,21 @@ static int decode_impl(must3r_hip_ctx* c, const must3r_hip_decode_args* A, void*
         // LN fold: a consumer reads the raw 16-bit rows + fragment sums its producer left, with the gamma-scaled weight
         auto fold_in = [&](GemmArgs& g_, int fs) {
             g_.A = x16; g_.ln_stats = lnstats; g_.ln_s = LP[fs]->d; g_.bias = LP[fs + 1]->d; g_.ln_eps = 1e-6f;
-            g_.ln_shift = lnshift; g_.ln_shift_init = lnshift_fresh ? 1 : 0;
+            g_.ln_shift = lnshift; g_.ln_shift_init = (lnshift_fresh && !f256) ? 1 : 0;   // (f256: the buffer was zeroed)
+            g_.fold256 = f256 ? 1 : 0;
             lnshift_fresh = false;
         };
         // ... and a residual GEMM leaves them for the next consumer (copy: the memorised input of the next block, decoder.py:304-305)
-        auto fold_out = [&](GemmArgs& g_, float* copy) { g_.x16_out = x16; g_.stats_out = lnstats; g_.copy32_out = copy; g_.ln_shift = lnshift; };
-        if (!lnf)
+        auto fold_out = [&](GemmArgs& g_, float* copy) {
+            g_.x16_out = x16; g_.stats_out = lnstats; g_.copy32_out = copy; g_.ln_shift = lnshift; g_.fold256 = f256 ? 1 : 0;
+        };
+        const bool fq = lnf || (f256 && l > 0);   // is this block's norm1 folded?
+        if (!fq)
             M3R_OK(layernorm_a(c, dt, lnargs(x, nullptr, LP[LF_N1W]->d, LP[LF_N1B]->d, h16, nullptr, nullptr,
                                             update ? newmem + (size_t)l * R * D : nullptr, R, D, 1e-6f), s));
-        M3R_OK(w16p(c, *LP[lnf ? LF_QKVLN_W : LF_QKVW], dt, &w, s));
+        M3R_OK(w16p(c, *LP[fq ? LF_QKVLN_W : LF_QKVW], dt, &w, s));
         GemmArgs ga = gargs(h16, w, LP[LF_QKVB]->d, qkv, R, 3 * D, D, D, 3 * D);
-        if (lnf) fold_in(ga, LF_QKVLN_S);
+        if (fq) fold_in(ga, LF_QKVLN_S);
         ga.pos = pos_all; ga.rope_tab = c->rope_tab; ga.rope_cols = 2 * D; ga.rope_npos = c->rope_npos;
         ga.out_scale = kQScale; ga.scale_cols = D;
         M3R_OK(gemm(c, dt, EPI_QKV_ROPE, ga, s));
@@ -1064,17 +1127,17 @@ static int decode_impl(must3r_hip_ctx* c, const must3r_hip_decode_args* A, void*
         M3R_OK(w16p(c, *LP[LF_PROJW], dt, &w, s));
         {
             GemmArgs gp = gargs(a16, w, LP[LF_PROJB]->d, x, R, D, D, D, D);
-            if (lnf) fold_out(gp, nullptr);
+            if (lnF) fold_out(gp, nullptr);
             M3R_OK(gemm(c, dt, EPI_RESID_F32, gp, s));
         }
         // --- cross attention over the memory (layers.py:92-97; attention.py:139-149)
-        if (!lnf)
+        if (!lnF)
             M3R_OK(layernorm(c, dt, x, nullptr, LP[LF_N2W]->d, LP[LF_N2B]->d, h16, nullptr, nullptr, nullptr,
                              R, D, 1e-6f, s));
-        M3R_OK(w16p(c, *LP[lnf ? LF_PQLN_W : LF_PQW], dt, &w, s));
+        M3R_OK(w16p(c, *LP[lnF ? LF_PQLN_W : LF_PQW], dt, &w, s));
         {
             GemmArgs gq = gargs(h16, w, LP[LF_PQB]->d, q16, R, D, D, D, D);
-            if (lnf) fold_in(gq, LF_PQLN_S);
+            if (lnF) fold_in(gq, LF_PQLN_S);
             gq.out_scale = kQScale; gq.scale_cols = D;
             M3R_OK(gemm(c, dt, EPI_STORE16, gq, s));
         }
@@ -1097,28 +1160,53 @@ static int decode_impl(must3r_hip_ctx* c, const must3r_hip_decode_args* A, void*
             aa.part_o = reinterpret_cast<float*>(split_ws);
             aa.part_ml = aa.part_o + (size_t)ca_split * R * D;
         }
+        if (cp) {
+            // this rank's keys -> ONE fp32 partial in its slot; all-gather of the slots (the caller's collective); merge of the world's partials into a16
+            float* const slot0 = reinterpret_cast<float*>(cp->slots);
+            const long long sstride = (long long)(cp->slot_bytes / sizeof(float));
+            float* const my_o = slot0 + (size_t)cp->rank * sstride;
+            float* const my_ml = my_o + (size_t)R * D;
+            if (Nm > 0) {
+                {
+                    ProfScope ps(c, s, PC_ATTN_CA, ca_flops);
+                    if (launch_attention_phase(dt, aa, 1, s, &err)) return fail("%s", err);
+                    ps.kernel(attention_last_kernel(), "/cross");
+                }
+                ProfScope ps(c, s, PC_ATTN_COMBINE, 0.0);
+                aa.total_q_rows = R;
+                if (launch_attention_partial_merge(dt, aa, my_o, my_ml, s, &err)) return fail("%s", err);
+            } else {
+                ProfScope ps(c, s, PC_ATTN_COMBINE, 0.0);
+                if (launch_attention_partial_empty(my_o, my_ml, R, Hh, s, &err)) return fail("%s", err);
+            }
+            if (cp->exchange(cp->user, l, cp->slots, cp->slot_bytes, cp->world, cp->rank, stream))
+                return fail("decode: the context-parallel exchange of layer %d failed", l);
+            ProfScope ps(c, s, PC_ATTN_COMBINE, 0.0);
+            aa.total_q_rows = R;
+            if (launch_attention_partial_final(dt, aa, slot0, slot0 + (size_t)R * D, sstride, sstride, cp->world, s, &err)) return fail("%s", err);
+        } else
         M3R_OK(attention(c, dt, aa, ca_flops, PC_ATTN_CA, s));
         M3R_OK(w16p(c, *LP[LF_CPW], dt, &w, s));
         {
             GemmArgs gp = gargs(a16, w, LP[LF_CPB]->d, x, R, D, D, D, D);
-            if (lnf) fold_out(gp, nullptr);
+            if (lnF) fold_out(gp, nullptr);
             M3R_OK(gemm(c, dt, EPI_RESID_F32, gp, s));
         }
         // --- MLP (layers.py:98)
-        if (!lnf)
+        if (!lnF)
             M3R_OK(layernorm(c, dt, x, nullptr, LP[LF_N3W]->d, LP[LF_N3B]->d, h16, nullptr, nullptr, nullptr,
                              R, D, 1e-6f, s));
         int ws_mlp;
-        M3R_OK(wmlp(c, *LP[lnf ? LF_FC1LN_W : LF_FC1W], dt, &w, &ws_mlp, s));
+        M3R_OK(wmlp(c, *LP[lnF ? LF_FC1LN_W : LF_FC1W], dt, &w, &ws_mlp, s));
         {
             GemmArgs g1 = gargs(h16, w, LP[LF_FC1B]->d, g16, R, F, D, D, F);
-            if (lnf) fold_in(g1, LF_FC1LN_S);
+            if (lnF) fold_in(g1, LF_FC1LN_S);
             M3R_OK(gemm(c, dt, EPI_STORE16_GELU, g1, s, ws_mlp));
         }
         M3R_OK(wmlp(c, *LP[LF_FC2W], dt, &w, &ws_mlp, s));
         {
             GemmArgs g2 = gargs(g16, w, LP[LF_FC2B]->d, x, R, D, F, F, D);
-            if (lnf && l + 1 < L) fold_out(g2, newmem + (size_t)(l + 1) * R * D);   // the next block's norm1 input
+            if (lnF && l + 1 < L) fold_out(g2, update ? newmem + (size_t)(l + 1) * R * D : nullptr);   // the next block's norm1 input (+ its memorised copy)
             M3R_OK(gemm(c, dt, EPI_RESID_F32, g2, s, ws_mlp));
         }
         if (A->feats && l < L - 1)   // return_feats: the residual stream after block l (decoder.py:321)
@@ -1204,6 +1292,11 @@ static int decode_impl(must3r_hip_ctx* c, const must3r_hip_decode_args* A, void*
 // MUSt3R.forward / forward_list (decoder.py:158-350).  Validates everything the launches rely on (so that a non-Python caller
 // cannot overrun a memory buffer or a table) and cuts render calls whose view tables would not fit the staging slot: rendered
 // views (and scenes) are independent of each other, the pieces give the same pointmaps.
+extern "C" size_t must3r_hip_cp_slot_bytes(const must3r_hip_ctx* c, int rows) {
+    if (!c || rows <= 0) return 0;
+    return align_up((size_t)rows * ((size_t)c->cfg.dec_dim + 2 * (size_t)c->cfg.dec_heads) * sizeof(float), 256);
+}
+
 extern "C" int must3r_hip_decode(must3r_hip_ctx* c, const must3r_hip_decode_args* A, void* stream) {
     if (!c || !A || !A->groups || !A->mem) return fail("decode: null argument");
     if (!c->fin_dec) return fail("decode: decoder weights not finalized");
@@ -1217,6 +1310,18 @@ extern "C" int must3r_hip_decode(must3r_hip_ctx* c, const must3r_hip_decode_args
     if (A->first_call && A->n_mem != 0) return fail("decode: first_call with a non-empty memory");
     if (A->n_scenes < 0) return fail("decode: negative n_scenes");
     const int S = A->n_scenes > 1 ? A->n_scenes : 1;
+    if (A->cp) {   // context-parallel cross attention: the one-view update of the streaming schedule, nothing else
+        const must3r_hip_cp& P = *A->cp;
+        if (P.world < 1 || P.rank < 0 || P.rank >= P.world) return fail("decode: context parallel: bad rank %d of %d", P.rank, P.world);
+        if (A->render || A->first_call || S != 1 || A->n_groups != 1 || A->groups[0].n_views != 1)
+            return fail("decode: context parallel is for memory-update calls of ONE view on ONE scene against an existing memory");
+        if (A->mem_mode != MUST3R_MEM_KV || (A->dtype & MUST3R_ATTN_FP8)) return fail("decode: context parallel needs memory_mode 'kv' and 16-bit attention operands");
+        if (P.n_mem_total <= 0 || A->n_mem > P.n_mem_total) return fail("decode: context parallel: n_mem_total %d with %d local rows", P.n_mem_total, A->n_mem);
+        if (!P.exchange || !P.slots || (reinterpret_cast<uintptr_t>(P.slots) & 15) || (P.slot_bytes & 15) ||
+            P.slot_bytes < must3r_hip_cp_slot_bytes(c, A->groups[0].n_tokens))
+            return fail("decode: context parallel: slots must be 16-byte aligned, world x slot_bytes with slot_bytes >= %zu, and an exchange function given",
+                        must3r_hip_cp_slot_bytes(c, A->groups[0].n_tokens));
+    }
     long long Rs = 0, views_s = 0;
     for (int gi = 0; gi < A->n_groups; ++gi) {
         const must3r_hip_group& G = A->groups[gi];
@@ -1430,6 +1535,22 @@ extern "C" int must3r_hip_op_gemm(int dtype, int epi, const void* A, const void*
 extern "C" int must3r_hip_op_sparse24_pack(const float* w, int rows, int K, void* vals, void* idx, void* stream) {
     const char* err = "";
     if (launch_sparse24_pack(w, rows, K, vals, idx, reinterpret_cast<hipStream_t>(stream), &err)) return fail("%s", err);
+    return 0;
+}
+// r06: the LN fold on the chip-filling 256 x 256 tiles alone (tests): GemmArgs::fold256 with split weights + packed sparse low part (wsplit = 2) or plain fp16 weights
+extern "C" int must3r_hip_op_gemm_fold256(int epi, int wsplit, const void* A, const void* W, const void* Wlo_sp, const void* Widx_sp, const float* bias, void* out,
+                                          int M, int N, int K, int lda, int ldc, void* x16_out, float* copy32_out, float* stats_out, const float* ln_stats,
+                                          const float* ln_s, float ln_eps, float* ln_shift, const int64_t* pos, const float* rope_tab, int rope_cols, int rope_npos,
+                                          float out_scale, int scale_cols, void* stream) {
+    if (epi < 0 || epi >= EPI_COUNT) return fail("op_gemm_fold256: bad epilogue");
+    GemmArgs a = gargs(A, W, bias, out, M, N, K, lda, ldc);
+    a.wsplit = wsplit == 2 ? 2 : 0; a.Wlo_sp = Wlo_sp; a.Widx_sp = Widx_sp; a.wsp_rows = N;
+    a.x16_out = x16_out; a.copy32_out = copy32_out; a.stats_out = stats_out;
+    a.ln_stats = ln_stats; a.ln_s = ln_s; a.ln_eps = ln_eps; a.ln_shift = ln_shift; a.fold256 = 1;
+    a.pos = pos; a.rope_tab = rope_tab; a.rope_cols = rope_cols; a.rope_npos = rope_npos;
+    a.out_scale = out_scale; a.scale_cols = scale_cols;
+    const char* err = "";
+    if (launch_gemm(DT_F16, (Epi)epi, a, reinterpret_cast<hipStream_t>(stream), &err)) return fail("%s", err);
     return 0;
 }
 extern "C" int must3r_hip_op_gemm_sp(int epi, const void* A, const void* W2, const void* Wlo_sp, const void* Widx_sp, const float* bias, void* out, int M,

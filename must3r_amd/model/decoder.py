@@ -185,16 +185,20 @@ class MUSt3R(HipModule):
 
     # -- forward -------------------------------------------------------------------------------
     @torch.no_grad()
-    def forward(self, x, pos, true_shape, current_mem=None, render=False, return_feats=False, pointmaps_out=None):
+    def forward(self, x, pos, true_shape, current_mem=None, render=False, return_feats=False, pointmaps_out=None, cp=None):
         """``pointmaps_out`` (extension, r05): where to write the raw pointmaps -- a fp32 cuda tensor [B, n, H, W, 7] (a list of them for list inputs) whose last four
         dimensions are contiguous; its batch stride is free, so a caller walking a scene's views over several calls can pass the slice ``buf[:, i:i+n]`` of one
-        [B, V, H, W, 7] buffer (engine.run_scenes) instead of concatenating the calls' outputs.  Returned in place of a fresh tensor."""
+        [B, V, H, W, 7] buffer (engine.run_scenes) instead of concatenating the calls' outputs.  Returned in place of a fresh tensor.
+
+        ``cp`` (extension, r06): a ``must3r_amd.parallel.ContextParallel`` -- ``current_mem`` is THIS rank's shard of a memory spread over the ranks of ``cp.group``
+        (``cp.n_mem_total`` rows in all); the cross attention of the call attends the local rows, exchanges one fp32 partial per layer with the other ranks
+        (all-gather) and merges them (include/must3r_hip.h ``must3r_hip_cp``).  One-view memory updates of one scene in memory_mode 'kv' only."""
         is_list = isinstance(x, (list, tuple))
         if is_list:
             return_feats = False   # the reference's list dispatch drops the flag (decoder.py:270); forward_list honours it
-        return self._forward(x, pos, true_shape, current_mem, render, return_feats, pointmaps_out)
+        return self._forward(x, pos, true_shape, current_mem, render, return_feats, pointmaps_out, cp)
 
-    def _forward(self, x, pos, true_shape, current_mem, render, return_feats, pointmaps_out=None):
+    def _forward(self, x, pos, true_shape, current_mem, render, return_feats, pointmaps_out=None, cp=None):
         is_list = isinstance(x, (list, tuple))
         xs = list(x) if is_list else [x]
         poss = list(pos) if is_list else [pos]
@@ -205,12 +209,12 @@ class MUSt3R(HipModule):
         # attention are all per batch element -- and are decoded by ONE native call (must3r_hip_decode_args.n_scenes): every GEMM
         # sees M = B x rows, the attention tables B x views, each scene its own rows of the [B, capacity, mem_D] memory buffers.
         pouts = None if pointmaps_out is None else (list(pointmaps_out) if isinstance(pointmaps_out, (list, tuple)) else [pointmaps_out])
-        out, outs, feats = self._forward_scene(xs, poss, shapes, current_mem, render, return_feats, pouts)
+        out, outs, feats = self._forward_scene(xs, poss, shapes, current_mem, render, return_feats, pouts, cp)
         if return_feats:
             return out, (outs if is_list else outs[0]), (feats if is_list else feats[0])
         return out, (outs if is_list else outs[0])
 
-    def _forward_scene(self, xs, poss, shapes, current_mem, render, return_feats, pouts=None):
+    def _forward_scene(self, xs, poss, shapes, current_mem, render, return_feats, pouts=None, cp=None):
         """B scenes of identical shapes: ONE native decode call.  Returns (memory, [pointmaps per group], [feats per group] | None)."""
         # (The per-call view tables travel through a 64 KiB staging slot, 1365 views; the reference renders every view of an aspect
         # ratio in ONE call when the caller sets no max_bs (engine/inference.py:489-522), so the LIBRARY cuts larger render calls
@@ -311,11 +315,20 @@ class MUSt3R(HipModule):
         # return_feats (decoder.py:344-347): [encoder tokens, residual stream after blocks 0..depth-2, norm_dec(last)] -- fp32
         # here (the residual stream is fp32 on this path, bf16 in the reference under autocast)
         feats_buf = torch.empty((self.depth, B, R, D), dtype=torch.float32, device=device) if return_feats else None
+        cp_struct = None
+        if cp is not None:
+            if render or current_mem is None or B != 1 or len(xs) != 1 or nimgs[0] != 1 or self.memory_mode != "kv" or self.attention_fp8:
+                raise ValueError("context-parallel cross attention is for one-view memory updates of one scene against an existing memory, memory_mode 'kv', "
+                                 "16-bit attention operands")
+            cp_struct = cp.native_args(ctx, R, device)   # allocates / reuses the slot buffer; keeps the callback alive
         args = _lib.DecodeArgs(odt | (_lib.ATTN_FP8 if self.attention_fp8 else 0), _MEM_MODE[self.memory_mode],
                                1 if render else 0, 1 if current_mem is None else 0,
                                len(xs), groups, Nm, ptrs, feats_buf.data_ptr() if return_feats else None,
-                               cap, B, stride)
-        _lib.check(ctx.lib.must3r_hip_decode(ctx.handle, C.byref(args), self._stream(dev)))
+                               cap, B, stride, C.pointer(cp_struct) if cp_struct is not None else None)
+        rc = ctx.lib.must3r_hip_decode(ctx.handle, C.byref(args), self._stream(dev))
+        if cp is not None and rc != 0:
+            cp.reraise()          # an exception raised inside the exchange callback (ctypes cannot propagate it) comes out here
+        _lib.check(rc)
 
         if render:
             out = current_mem  # decoder.py:252 / :339: the memory comes back untouched

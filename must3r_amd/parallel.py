@@ -197,9 +197,140 @@ def run_scene_sharded(encoder, decoder, imgs_local, true_shape_local, keyframe_l
     return out
 
 
+class ContextParallel:
+    """Exchange side of the context-parallel cross attention (SURVEY.md section 8f "later"; include/must3r_hip.h ``must3r_hip_cp``): the memory of ONE scene is
+    sharded over the ranks of ``group``; in a one-view memory update every rank attends its own rows, leaves one fp32 partial per layer -- un-normalised O plus
+    (m, l) per query row and head -- in its slot of ``slots`` and the library calls back here for the all-gather (``all_gather_into_tensor`` on the caller's
+    stream: RCCL over xGMI on the GPU node, gloo with host staging when the ranks of a dry run share a GPU), then merges the world's partials.
+
+    ``n_mem_total`` (set by the driver before every call): memory rows over all ranks."""
+
+    def __init__(self, group=None):
+        self.group = group
+        self.rank, self.world = _world(group)
+        self.live = dist.is_available() and dist.is_initialized()
+        self.n_mem_total = 0
+        self.slots = None
+        self.exchanges = 0
+        self.bytes_gathered = 0
+        self._error = None
+        self._struct = None
+        from . import _lib
+        self._cb = _lib.CpExchangeFn(self._exchange)     # (kept alive with the object: the library calls it during must3r_hip_decode)
+
+    def native_args(self, ctx, rows, device):
+        from . import _lib
+        need = int(ctx.lib.must3r_hip_cp_slot_bytes(ctx.handle, int(rows)))
+        if self.slots is None or self.slots.device != device or self.slots.shape[1] < need:
+            self.slots = torch.empty((self.world, need), dtype=torch.uint8, device=device)
+        import ctypes as C
+        self._struct = _lib.Cp(self.world, self.rank, int(self.n_mem_total), 0, self.slots.data_ptr(), int(self.slots.shape[1]), self._cb, None)
+        return self._struct
+
+    def _exchange(self, user, layer, slots_ptr, slot_bytes, n_slots, my_slot, stream):
+        try:
+            buf = self.slots
+            assert int(slots_ptr) == buf.data_ptr() and int(slot_bytes) == buf.shape[1] and int(n_slots) == self.world and int(my_slot) == self.rank
+            self.exchanges += 1
+            self.bytes_gathered += int(slot_bytes) * int(n_slots)
+            if not self.live:
+                return 0                                   # no process group: a world of one, the slot is already where it belongs
+            if buf.is_cuda and dist.get_backend(self.group) == "gloo":
+                out = torch.empty((self.world, buf.shape[1]), dtype=torch.uint8)      # ranks sharing a GPU (dry run / tests): through the host
+                dist.all_gather_into_tensor(out.view(-1), buf[self.rank].cpu(), group=self.group)
+                buf.copy_(out.to(buf.device))
+            else:
+                dist.all_gather_into_tensor(buf.view(-1), buf[self.rank].clone(), group=self.group)
+            return 0
+        except BaseException as e:   # noqa: BLE001 -- ctypes cannot propagate it: kept for reraise(), the native call fails with status 1
+            self._error = e
+            return 1
+
+    def reraise(self):
+        e, self._error = self._error, None
+        if e is not None:
+            raise e
+
+
+def _video_context_parallel(decoder, ax, apos, ats, group, local_context_size, is_keyframe, init_num_images):
+    """The streaming schedule of ``engine.run_video`` with the memory SHARDED over the ranks: image label L lives on rank L % world.  The init call (several views
+    attending each other's pre-feedback tokens) is replicated and every rank keeps its own labels' rows; every later one-view call runs context-parallel
+    (``decoder(.., cp=..)``): all ranks compute the frame, the owner of its label keeps the appended rows, the others rewind their buffers.  Eviction touches
+    the owner only.  Returns (local memory tuple, pointmaps_0 (identical on all ranks), keyframe ids, rows held per rank)."""
+    from collections import deque
+    from .engine import demo_mem_batches, remove_from_mem
+    rank, world = _world(group)
+    cpx = ContextParallel(group)
+    V, N = int(ax.shape[0]), int(ax.shape[1])
+    ts_host = ats.cpu() if ats.is_cuda else ats
+    mem = None
+    img_labels, keyframes, working, live = {}, set(), deque(), {}
+    pointmaps_0 = []
+    i = 0
+    for nb in demo_mem_batches(V, init_num_images, 1):
+        ids = list(range(i, i + nb))
+        n_before = len(img_labels)
+        if mem is None:
+            mem, pm = decoder(ax[i:i + nb].unsqueeze(0), apos[i:i + nb].unsqueeze(0), ts_host[i:i + nb].unsqueeze(0), None)
+            mem = list(mem)
+            for j in range(nb):
+                live[n_before + j] = N
+                if (n_before + j) % world != rank:
+                    mem[0], mem[1] = remove_from_mem(mem[0], mem[1], n_before + j)
+        else:
+            assert nb == 1, "the context-parallel call takes one view"
+            cpx.n_mem_total = sum(live.values())
+            old_vals, old_labels = mem[0], mem[1]
+            new_mem, pm = decoder(ax[i:i + 1].unsqueeze(0), apos[i:i + 1].unsqueeze(0), ts_host[i:i + 1].unsqueeze(0), tuple(mem), cp=cpx)
+            live[n_before] = N
+            if n_before % world == rank:
+                mem = list(new_mem)
+            else:   # not this rank's frame: the rows the call appended are scratch -- keep the (possibly re-allocated) buffers, declare the old length valid again
+                n_old = int(old_labels.shape[1])
+                own = getattr(new_mem[0][0], "_m3r_owner", None)
+                if own is not None:
+                    own.valid = n_old
+                    vals = own.views(n_old)
+                else:
+                    vals = [v[:, :n_old] for v in new_mem[0]]
+                mem = [vals, old_labels, mem[2], mem[3], mem[4]]
+        pointmaps_0.append(pm[0])
+        first = len(img_labels) == 0
+        for j, vid in enumerate(ids):
+            img_labels[vid] = n_before + j
+            working.append(vid)
+            if first or is_keyframe(vid):
+                keyframes.add(vid)
+        while len(working) > local_context_size:
+            old = working.popleft()
+            if old not in keyframes:
+                live.pop(img_labels[old], None)
+                mem[0], mem[1] = remove_from_mem(mem[0], mem[1], img_labels[old])     # a no-op on the ranks that do not hold the label
+        mem[2] = mem[3] = len(img_labels)                                             # global image count: the next call's labels are arange(n) + mem[2]
+        mem[4] = int(mem[1].shape[1])
+        i += nb
+    while working:
+        old = working.popleft()
+        if old not in keyframes:
+            live.pop(img_labels[old], None)
+            mem[0], mem[1] = remove_from_mem(mem[0], mem[1], img_labels[old])
+    mem[4] = int(mem[1].shape[1])
+    rows = [sum(n for lab, n in live.items() if lab % world == r) for r in range(world)]
+    assert rows[rank] == int(mem[1].shape[1]), (rows, rank, tuple(mem[1].shape))
+    return tuple(mem), torch.cat(pointmaps_0, dim=0), sorted(keyframes), rows, cpx
+
+
+def gather_memory(mem, rows, group=None):
+    """All ranks' shards of a sharded memory -> the whole memory on every rank (rank order), for the view-sharded render pass."""
+    vals = [all_gather_varlen(v[0], group, rows).unsqueeze(0) for v in mem[0]]
+    labels = all_gather_varlen(mem[1][0], group, rows).unsqueeze(0)
+    return (vals, labels, mem[2], mem[3], int(labels.shape[1]))
+
+
 @torch.no_grad()
 def run_video_sharded(encoder, decoder, imgs_local, true_shape_local, group=None, comm_dtype=None, local_context_size=25,
-                      is_keyframe=lambda i: i % 3 == 0, init_num_images=2, render=True, gather_outputs=False, frame_counts=None):
+                      is_keyframe=lambda i: i % 3 == 0, init_num_images=2, render=True, gather_outputs=False, frame_counts=None,
+                      context_parallel=False):
     """Online / streaming memory over a sharded frame sequence (BASELINE.json configs[3]; schedule of
     ``inference_video_multi_ar``, engine/inference.py:232-366, via ``engine.run_video``).
 
@@ -209,15 +340,28 @@ def run_video_sharded(encoder, decoder, imgs_local, true_shape_local, group=None
     frame's tokens); the sequential memory update with the sliding window / keyframe eviction is replicated
     (deterministic -> identical memories, nothing else to exchange); the final render of every frame against the final
     keyframe memory (engine/inference.py:489-522) is sharded again.  Returns dict(mem, keyframes, pointmaps_0 (update-pass
-    pointmaps of ALL frames, identical on every rank), render (local frames)[, render_all])."""
+    pointmaps of ALL frames, identical on every rank), render (local frames)[, render_all]).
+
+    ``context_parallel=True`` (r06): the memory itself is sharded over the ranks and the per-frame cross attention runs context-parallel
+    (``_video_context_parallel``): per-rank cross-attention work and K|V memory footprint drop by the world size, for one all-gather of
+    [tokens, dec_dim + 2 heads] fp32 partials per layer and frame."""
     from .engine import run_video
     x, pos = _encode_local(encoder, imgs_local, true_shape_local)
     all_kf = torch.ones(x.shape[0], dtype=torch.bool)
     grid, many_ar = _grid_of(encoder, imgs_local)
     ax, apos, ats = _gather_keyframes(x, pos, true_shape_local, all_kf, group, comm_dtype, frame_counts, grid, many_ar)
-    mem, pm0, keyframes = run_video(None, decoder, None, ats, local_context_size=local_context_size, is_keyframe=is_keyframe,
-                                    init_num_images=init_num_images, encoder_tokens=(ax, apos))
-    out = {"mem": mem, "keyframes": keyframes, "pointmaps_0": pm0}
+    if context_parallel:
+        # r06 (SURVEY.md section 8f "later"): the memory is SHARDED over the ranks (label L on rank L % world) and the per-frame update attends it context-parallel:
+        # one all-gather of fp32 partials per layer and frame instead of a replicated cross attention over the whole memory; the whole memory is gathered once, at
+        # the end, for the view-sharded render
+        mem_local, pm0, keyframes, rows, cpx = _video_context_parallel(decoder, ax, apos, ats, group, local_context_size, is_keyframe, init_num_images)
+        mem = gather_memory(mem_local, rows, group) if (render or gather_outputs) else mem_local
+        out = {"mem": mem, "mem_local": mem_local, "rows_per_rank": rows, "keyframes": keyframes, "pointmaps_0": pm0,
+               "cp_exchanges": cpx.exchanges, "cp_bytes_gathered": cpx.bytes_gathered}
+    else:
+        mem, pm0, keyframes = run_video(None, decoder, None, ats, local_context_size=local_context_size, is_keyframe=is_keyframe,
+                                        init_num_images=init_num_images, encoder_tokens=(ax, apos))
+        out = {"mem": mem, "keyframes": keyframes, "pointmaps_0": pm0}
     if render:
         out["render"] = _render_local(decoder, x, pos, true_shape_local, mem, imgs_local)
         if gather_outputs:

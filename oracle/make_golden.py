@@ -97,6 +97,25 @@ def main(cases=None, mixed=True):
     print("tiny_mixed_ar ok, Nm", mem2[0][0].shape[1])
 
 
+# r06: ALL pixels of the views of the headline scene that are worst against the oracle in the benched configuration -- the sub-sampled
+# fixture above sees every 8th pixel in each dimension (1/64 of them) and reads 5.9e-4 where the all-pixel figure is 7.1-7.3e-4.  Which views: the worst update /
+# render views of scene 0 of the 28-scene step (update 15, render 2) and of the one-scene-at-a-time run (update 1, render 19), gpurun_out/r06_c01_bench.json.
+FULL_VIEWS = {"must3r512_v20": {"update": (1, 15), "render": (2, 19)}}
+
+
+def main_full_views():
+    torch.set_num_threads(os.cpu_count() or 8)
+    for name, sel in FULL_VIEWS.items():
+        cfg, H, W, V, mb, ps, tks = BIG_CASES[name]
+        x, pos, upd, ren, mem = run_reference(cfg, H, W, V, mb)
+        z = np.load(os.path.join(OUT, name + ".npz"))   # the run must be the one the sub-sampled fixture was made from
+        assert np.array_equal(z["update"], upd[:, ::ps, ::ps].numpy()) and np.array_equal(z["render"], ren[:, ::ps, ::ps].numpy()), "reference run differs from the committed fixture"
+        np.savez_compressed(os.path.join(OUT, name + "_fullviews.npz"),
+                            update_views=np.array(sel["update"], dtype=np.int64), render_views=np.array(sel["render"], dtype=np.int64),
+                            update=upd[list(sel["update"])].numpy(), render=ren[list(sel["render"])].numpy())
+        print(name + "_fullviews", "update", sel["update"], "render", sel["render"], tuple(upd[list(sel["update"])].shape))
+
+
 def make_cam():
     """postprocess(compute_cam=True) of the REAL reference (engine/inference.py:16-48, verbatim) on a synthetic pinhole
     scene; its two third-party leaves are the restatements of oracle/cam_ref.py (un-vendored upstream)."""
@@ -185,6 +204,8 @@ if __name__ == "__main__":
         main()
     if which == "model_big":
         main(BIG_CASES, mixed=False)
+    if which == "full_views":
+        main_full_views()
     if which in BIG_CASES or which in CASES:
         main({which: {**CASES, **BIG_CASES}[which]}, mixed=False)
     if which in ("all", "cam"):

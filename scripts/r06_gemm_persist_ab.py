@@ -69,6 +69,10 @@ for name, M, N, K, epi, split in SHAPES:
 
         def run():
             lib.check(L.must3r_hip_op_gemm(1, epi, P(A), P(W), P(b), P(out), M, N, K, K, N, None, None, 0, 0, None, 0, 0, 0, 0, 0, 0, 0, st))
+    # third arm: the vendor's plain product (hipBLASLt behind torch.matmul; no bias / epilogue: an upper bound for the fused launches), same box, same rounds
+    vout = torch.empty((M, N), device="cuda", dtype=torch.float16)
+    W16 = Wf.half()
+    vendor = []
     digests, times = {}, {0: [], 1: []}
     for mode in (0, 1):
         lib.set_option("PERSIST", mode)
@@ -87,12 +91,21 @@ for name, M, N, K, epi, split in SHAPES:
             e1.record()
             torch.cuda.synchronize()
             times[mode].append(e0.elapsed_time(e1) / REPS * 1e3)
+        torch.matmul(A, W16.t(), out=vout)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(REPS):
+            torch.matmul(A, W16.t(), out=vout)
+        e1.record()
+        torch.cuda.synchronize()
+        vendor.append(e0.elapsed_time(e1) / REPS * 1e3)
     fl = 2.0 * M * N * K
     m0, m1 = statistics.median(times[0]), statistics.median(times[1])
     tot[0] += m0
     tot[1] += m1
     print(f"{name:36s} M={M:6d} N={N:5d} K={K:5d}  plain launch {min(times[0]):8.1f} / {m0:8.1f} us ({fl / m0 / 1e6:7.1f} TF/s)   persistent {min(times[1]):8.1f} / {m1:8.1f} us "
-          f"({fl / m1 / 1e6:7.1f} TF/s)   x{m0 / m1:5.3f}   bits {'equal' if digests[0] == digests[1] else 'DIFFER ' + digests[0] + ' ' + digests[1]}", flush=True)
-    del A, W, Wf, out
+          f"({fl / m1 / 1e6:7.1f} TF/s)   x{m0 / m1:5.3f}   bits {'equal' if digests[0] == digests[1] else 'DIFFER ' + digests[0] + ' ' + digests[1]}"
+          f"   | vendor plain product {min(vendor):8.1f} / {statistics.median(vendor):8.1f} us ({fl / statistics.median(vendor) / 1e6:7.1f} TF/s)", flush=True)
+    del A, W, Wf, out, vout, W16
 print(f"sum of medians: plain launch {tot[0]:.0f} us, persistent {tot[1]:.0f} us, x{tot[0] / tot[1]:.3f}")
-lib.set_option("PERSIST", 1)
+lib.set_option("PERSIST", 0)

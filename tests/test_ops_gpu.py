@@ -304,7 +304,7 @@ def test_gemm_persistent_tile_loop_same_bits(lib, shape):
                 if epi == lib.EPI_F32 and not sparse:   # (and the bits are those of the product)
                     assert torch.allclose(outs[1][:300].double(), ref, rtol=2e-6, atol=1e-5)
     finally:
-        lib.set_option("PERSIST", 1)
+        lib.set_option("PERSIST", 0)
 
 
 def test_gemm_sparse_tile_widths_same_bits(lib):

@@ -31,6 +31,20 @@ def _oracle_pair():
     return enc, dec
 
 
+def _oracle_pair_cp():
+    """the oracle pair whose decoder also takes ``cp=`` (oracle/cp_ref.py: the context-parallel protocol on CPU tensors)"""
+    from oracle import must3r_ref as R, cp_ref as CP
+    cfg = TINY
+    sde, sdd = S.make_encoder_state_dict(cfg, 0), S.make_decoder_state_dict(cfg, 0)
+    enc = lambda img, ts: R.encoder_forward(sde, cfg, img, ts)  # noqa: E731
+
+    def dec(x, pos, ts, mem=None, render=False, cp=None):
+        if cp is not None:
+            return CP.decoder_forward_cp(sdd, cfg, x, pos, ts, mem, cp)
+        return R.decoder_forward(sdd, cfg, x, pos, ts, mem, render, "kv")
+    return enc, dec
+
+
 def _keyframes():
     return torch.tensor([True, False, True, True, False, True])  # 4 keyframes, unevenly spread over the 2 shards
 
@@ -84,6 +98,15 @@ def _worker(rank, world, port, out_dir):
                                    gather_outputs=True)
         torch.save({"render_all": ov["render_all"], "pm0": ov["pointmaps_0"], "labels": ov["mem"][1], "kf": ov["keyframes"],
                     "mem_last": ov["mem"][0][-1]}, os.path.join(out_dir, f"v{rank}.pt"))
+        # r06 (SURVEY.md section 8f "later"): the same stream with the MEMORY sharded over the ranks and the per-frame cross attention context-parallel
+        enc_c, dec_c = _oracle_pair_cp()
+        with torch.no_grad():
+            oc = run_video_sharded(enc_c, dec_c, imgs[lo:hi], ts[lo:hi], local_context_size=3, is_keyframe=lambda i: i % 2 == 0,
+                                   gather_outputs=True, context_parallel=True)
+        assert oc["rows_per_rank"][rank] == int(oc["mem_local"][1].shape[1]) and sum(oc["rows_per_rank"]) == int(oc["mem"][1].shape[1])
+        assert set(oc["mem_local"][1].flatten().tolist()) <= {lab for lab in range(V) if lab % world == rank}, "a rank holds only its own labels"
+        torch.save({"render_all": oc["render_all"], "pm0": oc["pointmaps_0"], "labels": oc["mem"][1], "kf": oc["keyframes"], "mem_last": oc["mem"][0][-1],
+                    "rows": oc["rows_per_rank"], "local_labels": oc["mem_local"][1]}, os.path.join(out_dir, f"c{rank}.pt"))
     finally:
         dist.destroy_process_group()
 
@@ -121,6 +144,17 @@ def test_sharded_scene_equals_single_process(tmp_path):
     assert kf == v0["kf"] and torch.equal(memv[1], v0["labels"])
     assert torch.allclose(pm0, v0["pm0"], atol=1e-6) and torch.allclose(renv[0], v0["render_all"], atol=1e-6)
     assert torch.allclose(memv[0][-1], v0["mem_last"], atol=1e-6)
+    # context-parallel stream (memory sharded, label L on rank L % 2): identical on both ranks, equal to the single-process stream up to the order the
+    # partial sums are merged in -- the gathered memory holds the same rows per label, in rank order
+    c0, c1 = torch.load(tmp_path / "c0.pt"), torch.load(tmp_path / "c1.pt")
+    assert torch.equal(c0["render_all"], c1["render_all"]) and torch.equal(c0["pm0"], c1["pm0"]) and c0["kf"] == c1["kf"] == kf and c0["rows"] == c1["rows"]
+    assert torch.allclose(pm0, c0["pm0"], atol=2e-5) and torch.allclose(renv[0], c0["render_all"], atol=2e-5)
+    assert sorted(c0["labels"].flatten().tolist()) == sorted(memv[1].flatten().tolist())
+    assert sum(c0["rows"]) == memv[1].shape[1] and min(c0["rows"]) > 0, c0["rows"]          # both ranks really hold part of the memory
+    for lab in set(memv[1].flatten().tolist()):   # the rows of every surviving label are those of the single-process memory
+        a = memv[0][-1][0][memv[1][0] == lab]
+        b = c0["mem_last"][0][c0["labels"][0] == lab]
+        assert torch.allclose(a, b, atol=2e-5), lab
 
 
 def test_positions_rebuilt_from_the_grid_equal_the_encoders():
