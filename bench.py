@@ -406,7 +406,12 @@ def main():
             mixed = {"config": "configs[4] MUSt3R_512 mixed-resolution scene 512x{384,336,288,256,160} x4 views (forward_list), one scene at a time",
                      "views_per_step": 20, "unit": "views/s", "scene_tflop": round(fl / 1e12, 2), "modes": []}
             ref_mixed = None
-            for prec, fp8 in ((args.precision, False), (args.precision, True)):
+            from must3r_amd import _lib as _m3r_lib
+            fp8_built = _m3r_lib.has_fp8_attention()   # r06: the e4m3 attention path is parked (include/must3r_hip.h MUST3R_ATTN_FP8): timed only on an experiment build
+            if not fp8_built:
+                mixed["fp8_attention"] = ("parked in r06: 680.4 vs 677.9 views/s (+0.4 %) at 1.19e-3 / 1.40e-3 from the 16-bit path with 8 scenes in flight (BENCH_r05) -- "
+                                          "outside the 1e-3 target; built only with make EXTRA=-DM3R_ATTN_FP8")
+            for prec, fp8 in ((args.precision, False), (args.precision, True)) if fp8_built else ((args.precision, False),):
                 enc.precision = dec.precision = prec
                 enc.attention_fp8 = dec.attention_fp8 = fp8
                 fnm = lambda: run_scene_mixed(enc, dec, groups)  # noqa: E731
@@ -430,7 +435,7 @@ def main():
                       for gi, (g, h) in enumerate(zip(groups, MIXED_H))]
                 inflight = {"scenes": Sm, "views_per_step": 20 * Sm, "modes": []}
                 ref_r = None
-                for fp8 in (False, True):
+                for fp8 in ((False, True) if fp8_built else (False,)):
                     enc.attention_fp8 = dec.attention_fp8 = fp8
                     fnm = lambda: run_scenes_mixed(enc, dec, gS)  # noqa: E731
                     om = fnm()
@@ -447,8 +452,9 @@ def main():
                                                                              for a, r in zip(om["update"], ref_u) for b in range(Sm))
                     inflight["modes"].append(mode)
                 enc.attention_fp8 = dec.attention_fp8 = False
-                v16, v8 = inflight["modes"][0]["value"], inflight["modes"][1]["value"]
-                inflight["verdict"] = (f"fp8 attention {'WINS' if v8 > v16 else 'LOSES'} with {Sm} mixed scenes in flight: {v8} vs {v16} views/s; its error vs the 16-bit "
+                if fp8_built:
+                  v16, v8 = inflight["modes"][0]["value"], inflight["modes"][1]["value"]
+                  inflight["verdict"] = (f"fp8 attention {'WINS' if v8 > v16 else 'LOSES'} with {Sm} mixed scenes in flight: {v8} vs {v16} views/s; its error vs the 16-bit "
                                        f"path {inflight['modes'][1]['render_rel_inf_vs_16bit_path_worst_view']:.2e} (render) is outside the 1e-3 target -> off by default")
                 mixed["scenes_in_flight"] = inflight
                 del gS, ref_r, ref_u, om
@@ -597,7 +603,8 @@ def main():
                             "render_per_view_max": max(rv), "update_per_view_max": max(uv),
                             "render_worst_view": int(max(range(nv), key=lambda v: rv[v])), "update_worst_view": int(max(range(nv), key=lambda v: uv[v])),
                             "update_last_view": rel(upd[nv - 1], upd_o[nv - 1])}
-                for prec in ("fp16wa", "fp16w2", "fp16", "bf16", "fp16wa+fp8attn"):
+                from must3r_amd import _lib as _m3r_lib2
+                for prec in ("fp16wa", "fp16w2", "fp16", "bf16") + (("fp16wa+fp8attn",) if _m3r_lib2.has_fp8_attention() else ()):
                     enc.precision = dec.precision = prec.split("+")[0]
                     enc.attention_fp8 = dec.attention_fp8 = prec.endswith("fp8attn")
                     out = run_scene(enc, dec, imgs[:nv], ts[:nv])

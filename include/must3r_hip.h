@@ -45,8 +45,12 @@ enum { MUST3R_BF16 = 0, MUST3R_F16 = 1, MUST3R_F16_W2 = 2, MUST3R_F16_WA = 3 };
  * stay fp32 / 16-bit (3 mantissa bits on V alone cost 9e-3 of pointmap error, on Q and K 2e-3: DESIGN.md section 4).
  *   must3r_hip_op_attention: Q and K ARE e4m3 arrays (ldq, ldk in bytes); V and O 16-bit (ldv, ldo in elements).
  *   must3r_hip_encode / must3r_hip_decode: q and k are quantised on the fly; with MUST3R_MEM_KV the memory buffers hold rows of
- *   [K e4m3: dec_dim bytes | V 16-bit: 2*dec_dim bytes] = 3*dec_dim bytes (3/4 of the 16-bit footprint). */
+ *   [K e4m3: dec_dim bytes | V 16-bit: 2*dec_dim bytes] = 3*dec_dim bytes (3/4 of the 16-bit footprint).
+ * r06: PARKED.  Measured on BASELINE.json configs[4]: +0.4 % (680.4 vs 677.9 views/s) at 1.2e-3 ... 1.4e-3 from the 16-bit path -- outside the 1e-3 target for
+ * nothing.  The flag is honoured only by libraries built with `make EXTRA=-DM3R_ATTN_FP8` (must3r_hip_has_fp8_attention() == 1); the default
+ * library refuses it with status 1 and an error string that says so, and contains neither attn4_kernel<.., F8> nor the quantisation kernel. */
 #define MUST3R_ATTN_FP8 0x100
+int must3r_hip_has_fp8_attention(void);
 
 /* layout of the caller-visible memory tensors; CachedDecoderBlock MEMORY_MODES, must3r/model/blocks/layers.py:9 */
 enum { MUST3R_MEM_KV = 0, MUST3R_MEM_NORM_Y = 1, MUST3R_MEM_RAW = 2 };

@@ -31,7 +31,7 @@ EXPORTS = (
     "must3r_hip_op_gemm_lnfold",
     "must3r_hip_postprocess_act", "must3r_hip_postprocess_cam_act",
     "must3r_hip_op_sparse24_pack", "must3r_hip_op_gemm_sp",
-    "must3r_hip_set_option", "must3r_hip_cp_slot_bytes", "must3r_hip_op_gemm_fold256",
+    "must3r_hip_set_option", "must3r_hip_cp_slot_bytes", "must3r_hip_op_gemm_fold256", "must3r_hip_has_fp8_attention",
 )
 
 
@@ -144,6 +144,11 @@ def load():
 def check(rc):
     if rc != 0:
         raise HipError(load().must3r_hip_last_error().decode("utf-8", "replace"))
+
+
+def has_fp8_attention():
+    """Was the library built with the parked e4m3 attention path (make EXTRA=-DM3R_ATTN_FP8; include/must3r_hip.h MUST3R_ATTN_FP8)?"""
+    return bool(load().must3r_hip_has_fp8_attention())
 
 
 def set_option(name, value):

@@ -1256,8 +1256,13 @@ int launch_attention_phase(DType dt, const AttnArgs& a_in, int phase, hipStream_
         // fp8 (MX-scaled Q K^T) path: 983-1003 TF/s on the render shape.  M3R_ATTN=4 (experiment builds) runs its 16-bit instantiation.
 #define M3R_LAUNCH_ATTN(KERNEL) hipLaunchKernelGGL(KERNEL, dim3(grid), dim3(256), 0, s, a, nqb, ngrp, nsplit)
         g_attn_pick = a.fp8 ? "attn4f8" : (small ? "attn3/q16" : "attn3/q32");
-        if (a.fp8) {   // e4m3 Q / K through the MX-scaled 32x32x64 MFMA, 16-bit P / V
+        if (a.fp8) {   // e4m3 Q / K through the MX-scaled 32x32x64 MFMA, 16-bit P / V -- parked (kernels.hpp kAttnFp8Built): make EXTRA=-DM3R_ATTN_FP8
+#ifdef M3R_ATTN_FP8
             if (dt == DT_BF16) M3R_LAUNCH_ATTN((attn4_kernel<bf16_t, 1, true>)); else M3R_LAUNCH_ATTN((attn4_kernel<f16_t, 1, true>));
+#else
+            *err = "attention: e4m3 operands are an experiment build (make EXTRA=-DM3R_ATTN_FP8)";
+            return 1;
+#endif
         } else {
 #ifdef M3R_ATTN_EXPERIMENTS
             static const int variant = getenv("M3R_ATTN") ? atoi(getenv("M3R_ATTN")) : 2;

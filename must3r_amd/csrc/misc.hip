@@ -365,6 +365,7 @@ int launch_sparse24_pack(const float* w, int rows, int K, void* vals, void* idx,
     return 0;
 }
 
+#ifdef M3R_ATTN_FP8   // parked with the e4m3 attention path (kernels.hpp)
 // ------------------------------------------------------------------------------------------------
 // 16-bit -> OCP e4m3 (fp8 attention operands, include/must3r_hip.h MUST3R_ATTN_FP8): out8[r][c] = e4m3(clamp(in[r][c], +-448)).
 // v_cvt_pk_fp8_f32 does NOT saturate (1000 -> NaN, profiles/r02_fp8_probe.txt), hence the clamp.  One thread = 8 columns
@@ -416,6 +417,7 @@ int launch_quant8(DType dt, const void* in16, int ld_in, void* out8, int ld_out,
     if (hipGetLastError() != hipSuccess) { *err = "quant8: launch failed"; return 1; }
     return 0;
 }
+#endif
 
 // ------------------------------------------------------------------------------------------------
 // positions: pos[v][gy*gw+gx] = (gy, gx)   (croco PositionGetter)

@@ -47,6 +47,22 @@ cases = [make("render CA 20v nk15360", 12, 20, 768, 15360, False), make("enc SA 
 if os.environ.get("FIXED_COST"):   # fixed cost of a split launch: 1, 2, 6, 12 tiles per block at s = 10
     cases = [make(f"update CA nk{nk} s10", 12, 1, 768, nk, False, 10) for nk in (640, 1280, 3840, 7680, 15360)] + \
             [make(f"update CA nk{nk} s1", 12, 1, 768, nk, False, 0) for nk in (64, 640)]
+if os.environ.get("SELF_SWEEP"):
+    # r06: where does an encoder self-attention launch (768 keys = 12 tiles per block, 800 TF/s in the step) spend its time?  Same query blocks, the
+    # number of key tiles swept: the slope is the loop's cost per tile, the intercept what a block pays before / after its loop (Q fragments, first tile's DMA latency,
+    # normalise + store) plus the launch; 8 views = 768 blocks = ONE round of the 3 blocks a CU holds, 40 views = five rounds (the encoder chunk of the step).
+    def make_sweep(nviews, nk):
+        D, nq, heads = 1024, 768, 16
+        torch.manual_seed(0)
+        q = torch.randn((nviews * nq, D), device="cuda").half()
+        kv = torch.randn((nviews * nk, 2 * D), device="cuda").half()
+        k, v = kv[:, :D], kv[:, D:]
+        o = torch.empty((nviews * nq, D), device="cuda", dtype=torch.float16)
+        tab = torch.tensor([(i * nq, nq, i * nk, nk, 0, 0) for i in range(nviews)], dtype=torch.int32, device="cuda")
+        def go():
+            lib.check(L.must3r_hip_op_attention(lib.F16, P(q), P(k), P(v), P(o), q.stride(0), k.stride(0), v.stride(0), o.stride(0), heads, P(tab), nviews, nq, 0, None, 0, st))
+        return f"SA {nviews:2d}v x 16 heads, 768 q, {nk:4d} keys ({nk // 64:2d} tiles)", go, 4.0 * nviews * nq * nk * D, (q, kv, o, tab)
+    cases = [make_sweep(nv, nk) for nv in (8, 40) for nk in (64, 128, 256, 384, 768, 1536, 3072)]
 for name, go, fl, _ in cases:
     go()
 torch.cuda.synchronize()
@@ -63,3 +79,14 @@ print(f"M3R_ATTN={os.environ.get('M3R_ATTN','2')} QF={os.environ.get('M3R_ATTN_Q
 for name, go, fl, _ in cases:
     r = sorted(res[name]); med, mn = r[len(r)//2], r[0]
     print(f"  {name:28s} median {med*1e3:9.1f} us {fl/med/1e9:8.1f} TF/s   min {mn*1e3:9.1f} us {fl/mn/1e9:8.1f} TF/s", flush=True)
+
+if os.environ.get("SELF_SWEEP"):
+    import numpy as np
+    for nv in (8, 40):
+        rows = [(int(c[0].split("(")[1].split()[0]), sorted(res[c[0]])[len(res[c[0]]) // 2] * 1e3) for c in cases if c[0].startswith(f"SA {nv:2d}v")]
+        t, us = np.array([r[0] for r in rows], float), np.array([r[1] for r in rows], float)
+        slope, icpt = np.polyfit(t[2:], us[2:], 1)      # (4 tiles and up: the one- and two-tile launches sit on the launch floor)
+        blocks = nv * 16 * 6
+        rounds = blocks / 768.0
+        print(f"  {nv} views: {blocks} blocks = {rounds:.1f} rounds of 768; per launch {slope:.2f} us per key tile + {icpt:.1f} us; per ROUND {slope / rounds:.3f} us per tile + {icpt / rounds:.2f} us fixed"
+              f"  ->  at 12 tiles the fixed part is {icpt / (icpt + 12 * slope) * 100:.0f} % of the launch; loop alone = {4.0 * nv * 768 * 64 * 1024 / slope / 1e6:.0f} TF/s")

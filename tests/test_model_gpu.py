@@ -75,6 +75,9 @@ def test_fp8_attention_scene_vs_reference_fixture(name):
     attention of the encoder and the decoder (memory rows [K e4m3 | V fp16]), P / V and everything else as in fp16w2.  Its error is
     reported next to fp16w2's: it does NOT meet the 1e-3 target (3 mantissa bits on Q and K), the assertion is the mode's own stated
     tolerance (1e-2)."""
+    from must3r_amd import _lib as _l
+    if not _l.has_fp8_attention():
+        pytest.skip("the e4m3 attention path is parked: built only with make EXTRA=-DM3R_ATTN_FP8 (include/must3r_hip.h)")
     g = load_golden(name)
     cfg = dict(CASES, **BIG_CASES)[name]
     H, W, V, ps, tks = (int(v) for v in g["meta"][:5])

@@ -143,6 +143,9 @@ def test_batched_forward_list_mixed_aspect_ratios():
 
 def test_batched_decode_fp8_attention():
     """MUST3R_ATTN_FP8 with B = 2: [K e4m3 | V fp16] memory rows per scene (grouped quantisation into each scene's rows)."""
+    from must3r_amd import _lib as _l
+    if not _l.has_fp8_attention():
+        pytest.skip("the e4m3 attention path is parked: built only with make EXTRA=-DM3R_ATTN_FP8 (include/must3r_hip.h)")
     cfg = TINY
     enc, dec = build(cfg, "fp16w2")
     enc.attention_fp8 = dec.attention_fp8 = True
