@@ -467,10 +467,25 @@ def main():
             fnv = lambda: run_video(enc, dec, vimgs, vts)  # noqa: E731
             memv, _, kfs = fnv()
             d = timed(fnv, 1)
-            configs.append({"config": f"configs[3] MUSt3R_512 {F}-frame online streaming memory 384x512 on ONE GPU (window 25, keyframe every 3rd, "
-                                      "in-place eviction): encode + per-frame memory update",
-                            "value": round(F / d, 2), "unit": "frames/s", "ms_per_step": round(d * 1e3, 2), "frames": F,
-                            "keyframes": len(kfs), "final_memory_tokens": int(memv[0][0].shape[1]), "dtype": dtype_label})
+            stream_cfg = {"config": f"configs[3] MUSt3R_512 {F}-frame online streaming memory 384x512 on ONE GPU (window 25, keyframe every 3rd, "
+                                    "in-place eviction): encode + per-frame memory update",
+                          "value": round(F / d, 2), "unit": "frames/s", "ms_per_step": round(d * 1e3, 2), "frames": F,
+                          "keyframes": len(kfs), "final_memory_tokens": int(memv[0][0].shape[1]), "dtype": dtype_label}
+            # r06 (SURVEY.md section 8f "later"): the same stream through the context-parallel decoder call with a world of ONE rank -- the memory "sharded" over one
+            # rank, every layer's cross attention leaving its fp32 partial and merging the one slot (include/must3r_hip.h must3r_hip_cp).  What the machinery costs
+            # before any link is crossed; the N > 1 line times the real exchange (view_sharded.stream_context_parallel).
+            try:
+                from must3r_amd.parallel import run_video_sharded as _rvs
+                fncp = lambda: _rvs(enc, dec, vimgs, vts, render=False, frame_counts=[F], context_parallel=True)  # noqa: E731
+                ocp = fncp()
+                dcp = timed(fncp, 1)
+                stream_cfg["context_parallel_world1"] = {"value": round(F / dcp, 2), "unit": "frames/s", "ms_per_step": round(dcp * 1e3, 2),
+                                                         "exchanges": int(ocp["cp_exchanges"]), "partial_bytes_per_exchange": int(ocp["cp_bytes_gathered"] // max(1, ocp["cp_exchanges"])),
+                                                         "what": "run_video_sharded(context_parallel=True) without a process group: 12 partial merges + 12 slot merges per frame, no link"}
+                del ocp
+            except Exception as e:   # noqa: BLE001 -- a side figure must not take the line down
+                stream_cfg["context_parallel_world1"] = {"error": repr(e)[:300]}
+            configs.append(stream_cfg)
             del vimgs, memv
             # configs[1]: MUSt3R_224, 10 views of 224x224, one scene at a time and S scenes in flight
             e2, d2, _, _ = build_models(MUST3R_224, args.precision, device)
@@ -542,6 +557,18 @@ def main():
                                       "(encode sharded, all-gather of all frame tokens, per-frame memory update replicated)",
                             "value": round(F / d, 2), "unit": "frames/s", "ms_per_step": round(d * 1e3, 2), "frames": F,
                             "scaling": "strong", "dtype": dtype_label})
+            # r06: ... and with the memory itself sharded over the ranks, the per-frame cross attention context-parallel (12 all-gathers of fp32 partials per frame)
+            try:
+                fncp = lambda: run_video_sharded(enc, dec, vimgs, vts, comm_dtype=tdt, render=False, frame_counts=fc_all, context_parallel=True)  # noqa: E731
+                ocp = fncp()
+                dcp = timed(fncp, 1)
+                sharded["stream_context_parallel"] = {"value": round(F / dcp, 2), "unit": "frames/s", "ms_per_step": round(dcp * 1e3, 2), "frames": F,
+                                                      "exchanges": int(ocp["cp_exchanges"]), "bytes_gathered": int(ocp["cp_bytes_gathered"]),
+                                                      "memory_rows_per_rank": [int(r) for r in ocp["rows_per_rank"]]}
+                rccl["all_gather_bytes_per_step"]["stream_context_parallel"] = int(ocp["cp_bytes_gathered"])
+                del ocp
+            except Exception as e:   # noqa: BLE001
+                sharded["stream_context_parallel"] = {"error": repr(e)[:300]}
             del vimgs
 
     cpu_baseline, parity, torch_rocm_baseline = None, None, None

@@ -112,7 +112,8 @@ typedef struct must3r_hip_group {
 /* ---- ABI 8: context-parallel cross attention (SURVEY.md section 8f "later"; the keys of must3r/model/decoder.py:301-321's cross attention spread over processes) ----
  * The memory of ONE scene is SHARDED over `world` ranks (one process per GPU): every rank holds some of the memory rows of every layer, runs the same one-view
  * memory update on the same tokens (the projections / self attention / Mlp of a 768-row call are replicated, they do not shard), but attends only ITS rows and
- * contributes one fp32 PARTIAL per layer: un-normalised O [rows][dec_dim] followed by (m, l) [rows][heads][2] -- the flash-attention partial.  The library then
+ * contributes one PARTIAL per layer: un-normalised O fp32 [rows][dec_dim] (or, with partial16, O / l in the 16-bit operand type) followed by fp32 (m, l)
+ * [rows][heads][2] -- the flash-attention partial.  The library then
  * calls `exchange`, which must leave rank r's partial in slot r on every rank (an all-gather over xGMI: RCCL's ncclAllGather, or
  * torch.distributed.all_gather_into_tensor on the caller's stream), and merges the `world` slots.  A rank may hold no rows at all (n_mem = 0).
  * Only for memory-update calls of ONE view on ONE scene in MUST3R_MEM_KV mode against a non-empty (global) memory: the per-frame call of the streaming schedule
@@ -124,9 +125,10 @@ typedef int (*must3r_hip_cp_exchange_fn)(void* user, int layer, void* slots, siz
 typedef struct must3r_hip_cp {
     int32_t world, rank;     /* ranks the memory is sharded over (>= 1; 1 = a group of one rank, the exchange still runs), this rank */
     int32_t n_mem_total;     /* memory rows over ALL ranks before this call (> 0); must3r_hip_decode_args.n_mem = THIS rank's rows (>= 0) */
-    int32_t reserved;        /* 0 */
+    int32_t partial16;       /* 0: fp32 partials (un-normalised O); 1: the 16-bit partial format of the library's own split-KV path (O / l in the operand type + fp32
+                              * (m, l)): half the bytes on the links, one more 16-bit rounding of an intermediate (inside the precision mode's tolerance; tests) */
     void* slots;             /* device buffer of world x slot_bytes bytes, 16-byte aligned; slot r = rank r's partial of the layer being exchanged */
-    size_t slot_bytes;       /* >= must3r_hip_cp_slot_bytes(ctx, rows of the call), a multiple of 16 */
+    size_t slot_bytes;       /* >= must3r_hip_cp_slot_bytes(ctx, rows of the call) (partial16: must3r_hip_cp_slot_bytes16), a multiple of 16 */
     must3r_hip_cp_exchange_fn exchange;
     void* user;
 } must3r_hip_cp;
@@ -163,8 +165,10 @@ typedef struct must3r_hip_decode_args {
     const must3r_hip_cp* cp;   /* NULL: off.  Context-parallel cross attention (above): `mem` / `n_mem` describe this rank's SHARD of the memory */
 } must3r_hip_decode_args;
 
-/* bytes of one rank's partial for a context-parallel call of `rows` token rows: rows x (dec_dim + 2 x dec_heads) floats, rounded up to 256 */
+/* bytes of one rank's partial for a context-parallel call of `rows` token rows: rows x (dec_dim + 2 x dec_heads) floats, rounded up to 256;
+ * ...16: with partial16 = 1: rows x (2 dec_dim bytes + 2 x dec_heads floats) */
 size_t must3r_hip_cp_slot_bytes(const must3r_hip_ctx* ctx, int rows);
+size_t must3r_hip_cp_slot_bytes16(const must3r_hip_ctx* ctx, int rows);
 
 /* MUSt3R.forward / forward_list (decoder.py:158-350).  Render calls whose view tables exceed the library's staging slot
  * (1365 views) are cut into ranges of scenes / views inside the library: rendered views are independent. */

@@ -31,7 +31,7 @@ EXPORTS = (
     "must3r_hip_op_gemm_lnfold",
     "must3r_hip_postprocess_act", "must3r_hip_postprocess_cam_act",
     "must3r_hip_op_sparse24_pack", "must3r_hip_op_gemm_sp",
-    "must3r_hip_set_option", "must3r_hip_cp_slot_bytes", "must3r_hip_op_gemm_fold256", "must3r_hip_has_fp8_attention",
+    "must3r_hip_set_option", "must3r_hip_cp_slot_bytes", "must3r_hip_cp_slot_bytes16", "must3r_hip_op_gemm_fold256", "must3r_hip_has_fp8_attention",
 )
 
 
@@ -54,7 +54,7 @@ CpExchangeFn = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t,
 
 class Cp(C.Structure):
     """must3r_hip_cp: context-parallel cross attention over a memory sharded across ranks (include/must3r_hip.h, ABI 8)."""
-    _fields_ = [("world", C.c_int32), ("rank", C.c_int32), ("n_mem_total", C.c_int32), ("reserved", C.c_int32),
+    _fields_ = [("world", C.c_int32), ("rank", C.c_int32), ("n_mem_total", C.c_int32), ("partial16", C.c_int32),
                 ("slots", C.c_void_p), ("slot_bytes", C.c_size_t), ("exchange", CpExchangeFn), ("user", C.c_void_p)]
 
 
@@ -130,6 +130,8 @@ def load():
     lib.must3r_hip_set_option.argtypes = [C.c_char_p, C.c_longlong]
     lib.must3r_hip_cp_slot_bytes.argtypes = [vp, i32]
     lib.must3r_hip_cp_slot_bytes.restype = C.c_size_t
+    lib.must3r_hip_cp_slot_bytes16.argtypes = [vp, i32]
+    lib.must3r_hip_cp_slot_bytes16.restype = C.c_size_t
     for name in EXPORTS:
         fn = getattr(lib, name)
         if fn.restype is C.c_int and name not in ("must3r_hip_abi_version", "must3r_hip_attention_scratch_bytes",

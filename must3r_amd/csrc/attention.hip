@@ -1068,10 +1068,11 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(QF == 
 }
 
 // merge of the split-KV partials: O = sum_s 2^(m_s - m*) O_s / sum_s 2^(m_s - m*) l_s ; one thread = 4 columns
-// TO_PARTIAL (r06, context-parallel cross attention): instead of the normalised 16-bit rows the merged sums themselves leave as ONE fp32 partial -- acc (un-normalised)
-// to cp_o [rows][D], (m*, L) to cp_ml [rows][heads][2] -- which attn_combine_kernel<T, false> reads back (part16 = 0) among the partials of the other ranks.
+// TO_PARTIAL (r06, context-parallel cross attention): instead of the normalised 16-bit rows the merged sums themselves leave as ONE partial -- cp16 = 0: acc
+// (un-normalised, fp32) to cp_o [rows][D]; cp16 = 1: acc / L in the 16-bit type (the split-KV partial format, half the bytes on the links) --, (m*, L) to cp_ml
+// [rows][heads][2] -- which attn_combine_kernel<T, false> reads back (part16 = cp16) among the partials of the other ranks.
 template <class T, bool TO_PARTIAL = false>
-__global__ void attn_combine_kernel(const AttnArgs p, const int nsplit, float* __restrict__ cp_o = nullptr, float* __restrict__ cp_ml = nullptr) {
+__global__ void attn_combine_kernel(const AttnArgs p, const int nsplit, float* __restrict__ cp_o = nullptr, float* __restrict__ cp_ml = nullptr, const int cp16 = 0) {
     typedef typename Vec<T>::v4 v4;
     const size_t D = (size_t)p.heads * 64;
     const size_t total = (size_t)p.total_q_rows * (D / 4);
@@ -1098,7 +1099,8 @@ __global__ void attn_combine_kernel(const AttnArgs p, const int nsplit, float* _
         }
         if (mstar == -INFINITY) {   // row not produced by any view of this launch (a partial: the row of a rank without keys)
             if constexpr (TO_PARTIAL) {
-                *reinterpret_cast<f32x4*>(cp_o + row * D + col) = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (cp16) *reinterpret_cast<v4*>(reinterpret_cast<T*>(cp_o) + row * D + col) = cvt4<T>(f32x4{0.f, 0.f, 0.f, 0.f});
+                else *reinterpret_cast<f32x4*>(cp_o + row * D + col) = f32x4{0.f, 0.f, 0.f, 0.f};
                 if ((col & 63) == 0) { cp_ml[(row * p.heads + head) * 2] = -INFINITY; cp_ml[(row * p.heads + head) * 2 + 1] = 0.f; }
             }
             continue;
@@ -1127,7 +1129,8 @@ __global__ void attn_combine_kernel(const AttnArgs p, const int nsplit, float* _
             }
         }
         if constexpr (TO_PARTIAL) {
-            *reinterpret_cast<f32x4*>(cp_o + row * D + col) = acc;
+            if (cp16) *reinterpret_cast<v4*>(reinterpret_cast<T*>(cp_o) + row * D + col) = cvt4<T>(acc * (L > 0.f ? 1.0f / L : 0.f));
+            else *reinterpret_cast<f32x4*>(cp_o + row * D + col) = acc;
             if ((col & 63) == 0) { cp_ml[(row * p.heads + head) * 2] = mstar; cp_ml[(row * p.heads + head) * 2 + 1] = L; }
         } else {
             const float inv = L > 0.f ? 1.0f / L : 0.f;
@@ -1314,8 +1317,8 @@ int launch_attention_phase(DType dt, const AttnArgs& a_in, int phase, hipStream_
     } else if (nsplit > 1) {
         const size_t total = (size_t)a.total_q_rows * a.heads * 16;
         const unsigned g2 = (unsigned)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
-        if (dt == DT_BF16) hipLaunchKernelGGL((attn_combine_kernel<bf16_t, false>), dim3(g2), dim3(256), 0, s, a, nsplit, (float*)nullptr, (float*)nullptr);
-        else hipLaunchKernelGGL((attn_combine_kernel<f16_t, false>), dim3(g2), dim3(256), 0, s, a, nsplit, (float*)nullptr, (float*)nullptr);
+        if (dt == DT_BF16) hipLaunchKernelGGL((attn_combine_kernel<bf16_t, false>), dim3(g2), dim3(256), 0, s, a, nsplit, (float*)nullptr, (float*)nullptr, 0);
+        else hipLaunchKernelGGL((attn_combine_kernel<f16_t, false>), dim3(g2), dim3(256), 0, s, a, nsplit, (float*)nullptr, (float*)nullptr, 0);
     }
     if (hipGetLastError() != hipSuccess) { *err = "attention: kernel launch failed"; return 1; }
     return 0;
@@ -1326,40 +1329,41 @@ static unsigned combine_grid(const AttnArgs& a) {
     const size_t total = (size_t)a.total_q_rows * a.heads * 16;
     return (unsigned)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
 }
-int launch_attention_partial_merge(DType dt, const AttnArgs& a_in, float* out_o, float* out_ml, hipStream_t s, const char** err) {
+int launch_attention_partial_merge(DType dt, const AttnArgs& a_in, float* out_o, float* out_ml, int p16, hipStream_t s, const char** err) {
     AttnArgs a = a_in;
     if (a.nsplit < 2 || !a.part_o || !a.part_ml || a.total_q_rows <= 0 || !out_o || !out_ml) { *err = "attention: partial merge needs split-KV partials and an output slot"; return 1; }
     a.part16 = dt == DT_F16 ? 1 : 0;   // the layout launch_attention_phase(.., 1, ..) wrote
     a.part_stride_o = a.part_stride_ml = 0;
-    if (dt == DT_BF16) hipLaunchKernelGGL((attn_combine_kernel<bf16_t, true>), dim3(combine_grid(a)), dim3(256), 0, s, a, a.nsplit, out_o, out_ml);
-    else hipLaunchKernelGGL((attn_combine_kernel<f16_t, true>), dim3(combine_grid(a)), dim3(256), 0, s, a, a.nsplit, out_o, out_ml);
+    if (dt == DT_BF16) hipLaunchKernelGGL((attn_combine_kernel<bf16_t, true>), dim3(combine_grid(a)), dim3(256), 0, s, a, a.nsplit, out_o, out_ml, p16);
+    else hipLaunchKernelGGL((attn_combine_kernel<f16_t, true>), dim3(combine_grid(a)), dim3(256), 0, s, a, a.nsplit, out_o, out_ml, p16);
     if (hipGetLastError() != hipSuccess) { *err = "attention: kernel launch failed"; return 1; }
     return 0;
 }
 __global__ void attn_partial_empty_kernel(float* __restrict__ o, float* __restrict__ ml, size_t n_o4, size_t n_ml) {
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_o4; i += (size_t)gridDim.x * blockDim.x) {
-        reinterpret_cast<f32x4*>(o)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < (n_o4 > n_ml ? n_o4 : n_ml); i += (size_t)gridDim.x * blockDim.x) {
+        if (i < n_o4) reinterpret_cast<f32x4*>(o)[i] = f32x4{0.f, 0.f, 0.f, 0.f};   // (zero bits are zero in fp32 and in both 16-bit types)
         if (i < n_ml) { ml[i * 2] = -INFINITY; ml[i * 2 + 1] = 0.f; }
     }
 }
-int launch_attention_partial_empty(float* out_o, float* out_ml, int rows, int heads, hipStream_t s, const char** err) {
+int launch_attention_partial_empty(float* out_o, float* out_ml, int rows, int heads, int p16, hipStream_t s, const char** err) {
     if (rows <= 0) return 0;
-    const size_t n_o4 = (size_t)rows * heads * 16, n_ml = (size_t)rows * heads;   // n_ml <= n_o4
-    hipLaunchKernelGGL(attn_partial_empty_kernel, dim3((unsigned)((n_o4 + 255) / 256 < 2048 ? (n_o4 + 255) / 256 : 2048)), dim3(256), 0, s, out_o, out_ml, n_o4, n_ml);
+    const size_t n_o4 = (size_t)rows * heads * (p16 ? 8 : 16), n_ml = (size_t)rows * heads;
+    const size_t n = n_o4 > n_ml ? n_o4 : n_ml;
+    hipLaunchKernelGGL(attn_partial_empty_kernel, dim3((unsigned)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048)), dim3(256), 0, s, out_o, out_ml, n_o4, n_ml);
     if (hipGetLastError() != hipSuccess) { *err = "attention: kernel launch failed"; return 1; }
     return 0;
 }
 int launch_attention_partial_final(DType dt, const AttnArgs& a_in, const float* slots_o, const float* slots_ml, long long stride_o, long long stride_ml, int nslots,
-                                   hipStream_t s, const char** err) {
+                                   int p16, hipStream_t s, const char** err) {
     AttnArgs a = a_in;
     if (nslots < 1 || !slots_o || !slots_ml || a.total_q_rows <= 0 || !a.O || (a.ldo % 4)) { *err = "attention: final merge needs slots and an output"; return 1; }
     a.part_o = const_cast<float*>(slots_o);
     a.part_ml = const_cast<float*>(slots_ml);
-    a.part16 = 0;
+    a.part16 = p16 ? 1 : 0;
     a.part_stride_o = stride_o;
     a.part_stride_ml = stride_ml;
-    if (dt == DT_BF16) hipLaunchKernelGGL((attn_combine_kernel<bf16_t, false>), dim3(combine_grid(a)), dim3(256), 0, s, a, nslots, (float*)nullptr, (float*)nullptr);
-    else hipLaunchKernelGGL((attn_combine_kernel<f16_t, false>), dim3(combine_grid(a)), dim3(256), 0, s, a, nslots, (float*)nullptr, (float*)nullptr);
+    if (dt == DT_BF16) hipLaunchKernelGGL((attn_combine_kernel<bf16_t, false>), dim3(combine_grid(a)), dim3(256), 0, s, a, nslots, (float*)nullptr, (float*)nullptr, 0);
+    else hipLaunchKernelGGL((attn_combine_kernel<f16_t, false>), dim3(combine_grid(a)), dim3(256), 0, s, a, nslots, (float*)nullptr, (float*)nullptr, 0);
     if (hipGetLastError() != hipSuccess) { *err = "attention: kernel launch failed"; return 1; }
     return 0;
 }

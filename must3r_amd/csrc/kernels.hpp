@@ -150,16 +150,17 @@ struct AttnArgs {
     long long part_stride_o, part_stride_ml;
 };
 // r06, context-parallel cross attention over a memory sharded across ranks (SURVEY.md section 8f "later"; decoder.py:301-321 with the keys of one view spread over
-// `world` processes).  A rank's contribution to one layer is ONE fp32 partial per query row: un-normalised O = sum_k 2^(s_k - m) v_k over ITS keys [rows][heads*64],
-// and (m, l) = (reference in the log2 domain, row sum) [rows][heads][2] -- the split-KV partial format one level up.
+// `world` processes).  A rank's contribution to one layer is ONE partial per query row -- the split-KV partial format one level up:
+//   p16 = 0: un-normalised O = sum_k 2^(s_k - m) v_k over ITS keys, fp32 [rows][heads*64];   p16 = 1: O / l in the 16-bit type [rows][heads*64] (half the link bytes);
+//   then (m, l) = (reference in the log2 domain, row sum) fp32 [rows][heads][2].
 //   launch_attention_partial_merge: the nsplit local split-KV partials of `a` (layout of launch_attention_phase(.., 1, ..)) -> one such partial in (out_o, out_ml)
 //   launch_attention_partial_empty: the partial of a rank that holds no key: O = 0, (m, l) = (-inf, 0)
-//   launch_attention_partial_final: `nslots` partials at slots_o + s * stride_o / slots_ml + s * stride_ml (floats) -> normalised 16-bit output a.O (ldo)
-// One slot in, `final` reproduces bit for bit what launch_attention_phase(.., 2, ..) writes for the same splits (same sums in the same order, 2^0 = 1).
-int launch_attention_partial_merge(DType dt, const AttnArgs& a, float* out_o, float* out_ml, hipStream_t s, const char** err);
-int launch_attention_partial_empty(float* out_o, float* out_ml, int rows, int heads, hipStream_t s, const char** err);
+//   launch_attention_partial_final: `nslots` partials at slots_o + s * stride_o (elements of the partial's O type) / slots_ml + s * stride_ml (floats) -> a.O (ldo)
+// One fp32 slot in, `final` reproduces bit for bit what launch_attention_phase(.., 2, ..) writes for the same splits (same sums in the same order, 2^0 = 1).
+int launch_attention_partial_merge(DType dt, const AttnArgs& a, float* out_o, float* out_ml, int p16, hipStream_t s, const char** err);
+int launch_attention_partial_empty(float* out_o, float* out_ml, int rows, int heads, int p16, hipStream_t s, const char** err);
 int launch_attention_partial_final(DType dt, const AttnArgs& a, const float* slots_o, const float* slots_ml, long long stride_o, long long stride_ml, int nslots,
-                                   hipStream_t s, const char** err);
+                                   int p16, hipStream_t s, const char** err);
 // bytes of scratch launch_attention needs for a given split factor
 size_t attention_split_scratch_bytes(int nsplit, int total_q_rows, int heads);
 // heuristic split factor for a launch

@@ -154,6 +154,8 @@ static int upload_table(must3r_hip_ctx* c, const void* host, size_t bytes, void*
     char* h = c->pin + (size_t)i * must3r_hip_ctx::kSlotBytes;
     char* d = c->pin_dev + (size_t)i * must3r_hip_ctx::kSlotBytes;
     memcpy(h, host, bytes);
+    // (r06, measured and dropped: a one-block copy KERNEL reading the pinned slot instead of this copy-engine transfer -- the 28 gaps of ~35 us per one-scene pass that
+    // surround these uploads became ~40 gaps of 6-40 us, 59.3 vs 58.7 ms per pass: scripts/r06_runs/c08_tables.sh, profiles/r06_single_scene_seams.txt)
     HIP_OK(hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, s));
     HIP_OK(hipEventRecord(c->slot_ev[i], s));
     c->slot_used[i] = true;
@@ -1167,11 +1169,13 @@ static int decode_impl(must3r_hip_ctx* c, const must3r_hip_decode_args* A, void*
             aa.part_ml = aa.part_o + (size_t)ca_split * R * D;
         }
         if (cp) {
-            // this rank's keys -> ONE fp32 partial in its slot; all-gather of the slots (the caller's collective); merge of the world's partials into a16
-            float* const slot0 = reinterpret_cast<float*>(cp->slots);
-            const long long sstride = (long long)(cp->slot_bytes / sizeof(float));
-            float* const my_o = slot0 + (size_t)cp->rank * sstride;
-            float* const my_ml = my_o + (size_t)R * D;
+            // this rank's keys -> ONE partial in its slot (fp32 un-normalised, or 16-bit normalised with must3r_hip_cp::partial16); all-gather of the slots (the
+            // caller's collective); merge of the world's partials into a16
+            const int p16 = cp->partial16 ? 1 : 0;
+            char* const slot0 = reinterpret_cast<char*>(cp->slots);
+            const size_t o_bytes = (size_t)R * D * (p16 ? 2 : 4);
+            float* const my_o = reinterpret_cast<float*>(slot0 + (size_t)cp->rank * cp->slot_bytes);
+            float* const my_ml = reinterpret_cast<float*>(slot0 + (size_t)cp->rank * cp->slot_bytes + o_bytes);
             if (Nm > 0) {
                 {
                     ProfScope ps(c, s, PC_ATTN_CA, ca_flops);
@@ -1180,16 +1184,17 @@ static int decode_impl(must3r_hip_ctx* c, const must3r_hip_decode_args* A, void*
                 }
                 ProfScope ps(c, s, PC_ATTN_COMBINE, 0.0);
                 aa.total_q_rows = R;
-                if (launch_attention_partial_merge(dt, aa, my_o, my_ml, s, &err)) return fail("%s", err);
+                if (launch_attention_partial_merge(dt, aa, my_o, my_ml, p16, s, &err)) return fail("%s", err);
             } else {
                 ProfScope ps(c, s, PC_ATTN_COMBINE, 0.0);
-                if (launch_attention_partial_empty(my_o, my_ml, R, Hh, s, &err)) return fail("%s", err);
+                if (launch_attention_partial_empty(my_o, my_ml, R, Hh, p16, s, &err)) return fail("%s", err);
             }
             if (cp->exchange(cp->user, l, cp->slots, cp->slot_bytes, cp->world, cp->rank, stream))
                 return fail("decode: the context-parallel exchange of layer %d failed", l);
             ProfScope ps(c, s, PC_ATTN_COMBINE, 0.0);
             aa.total_q_rows = R;
-            if (launch_attention_partial_final(dt, aa, slot0, slot0 + (size_t)R * D, sstride, sstride, cp->world, s, &err)) return fail("%s", err);
+            if (launch_attention_partial_final(dt, aa, reinterpret_cast<const float*>(slot0), reinterpret_cast<const float*>(slot0 + o_bytes),
+                                               (long long)(cp->slot_bytes / (p16 ? 2 : 4)), (long long)(cp->slot_bytes / 4), cp->world, p16, s, &err)) return fail("%s", err);
         } else
         M3R_OK(attention(c, dt, aa, ca_flops, PC_ATTN_CA, s));
         M3R_OK(w16p(c, *LP[LF_CPW], dt, &w, s));
@@ -1300,9 +1305,16 @@ static int decode_impl(must3r_hip_ctx* c, const must3r_hip_decode_args* A, void*
 // views (and scenes) are independent of each other, the pieces give the same pointmaps.
 extern "C" int must3r_hip_has_fp8_attention(void) { return kAttnFp8Built ? 1 : 0; }
 
+static size_t cp_slot_bytes(const must3r_hip_ctx* c, int rows, int partial16) {
+    return align_up((size_t)rows * ((size_t)c->cfg.dec_dim * (partial16 ? 2 : 4) + 2 * (size_t)c->cfg.dec_heads * sizeof(float)), 256);
+}
 extern "C" size_t must3r_hip_cp_slot_bytes(const must3r_hip_ctx* c, int rows) {
     if (!c || rows <= 0) return 0;
-    return align_up((size_t)rows * ((size_t)c->cfg.dec_dim + 2 * (size_t)c->cfg.dec_heads) * sizeof(float), 256);
+    return cp_slot_bytes(c, rows, 0);
+}
+extern "C" size_t must3r_hip_cp_slot_bytes16(const must3r_hip_ctx* c, int rows) {
+    if (!c || rows <= 0) return 0;
+    return cp_slot_bytes(c, rows, 1);
 }
 
 extern "C" int must3r_hip_decode(must3r_hip_ctx* c, const must3r_hip_decode_args* A, void* stream) {
@@ -1326,10 +1338,11 @@ extern "C" int must3r_hip_decode(must3r_hip_ctx* c, const must3r_hip_decode_args
             return fail("decode: context parallel is for memory-update calls of ONE view on ONE scene against an existing memory");
         if (A->mem_mode != MUST3R_MEM_KV || (A->dtype & MUST3R_ATTN_FP8)) return fail("decode: context parallel needs memory_mode 'kv' and 16-bit attention operands");
         if (P.n_mem_total <= 0 || A->n_mem > P.n_mem_total) return fail("decode: context parallel: n_mem_total %d with %d local rows", P.n_mem_total, A->n_mem);
+        if (P.partial16 != 0 && P.partial16 != 1) return fail("decode: context parallel: partial16 must be 0 or 1");
         if (!P.exchange || !P.slots || (reinterpret_cast<uintptr_t>(P.slots) & 15) || (P.slot_bytes & 15) ||
-            P.slot_bytes < must3r_hip_cp_slot_bytes(c, A->groups[0].n_tokens))
+            P.slot_bytes < cp_slot_bytes(c, A->groups[0].n_tokens, P.partial16))
             return fail("decode: context parallel: slots must be 16-byte aligned, world x slot_bytes with slot_bytes >= %zu, and an exchange function given",
-                        must3r_hip_cp_slot_bytes(c, A->groups[0].n_tokens));
+                        cp_slot_bytes(c, A->groups[0].n_tokens, P.partial16));
     }
     long long Rs = 0, views_s = 0;
     for (int gi = 0; gi < A->n_groups; ++gi) {

@@ -205,8 +205,9 @@ class ContextParallel:
 
     ``n_mem_total`` (set by the driver before every call): memory rows over all ranks."""
 
-    def __init__(self, group=None):
+    def __init__(self, group=None, partial16=True):
         self.group = group
+        self.partial16 = bool(partial16)   # the 16-bit partial format (O / l in the operand type): half the bytes of the fp32 one on the links
         self.rank, self.world = _world(group)
         self.live = dist.is_available() and dist.is_initialized()
         self.n_mem_total = 0
@@ -220,11 +221,11 @@ class ContextParallel:
 
     def native_args(self, ctx, rows, device):
         from . import _lib
-        need = int(ctx.lib.must3r_hip_cp_slot_bytes(ctx.handle, int(rows)))
+        need = int((ctx.lib.must3r_hip_cp_slot_bytes16 if self.partial16 else ctx.lib.must3r_hip_cp_slot_bytes)(ctx.handle, int(rows)))
         if self.slots is None or self.slots.device != device or self.slots.shape[1] < need:
             self.slots = torch.empty((self.world, need), dtype=torch.uint8, device=device)
         import ctypes as C
-        self._struct = _lib.Cp(self.world, self.rank, int(self.n_mem_total), 0, self.slots.data_ptr(), int(self.slots.shape[1]), self._cb, None)
+        self._struct = _lib.Cp(self.world, self.rank, int(self.n_mem_total), 1 if self.partial16 else 0, self.slots.data_ptr(), int(self.slots.shape[1]), self._cb, None)
         return self._struct
 
     def _exchange(self, user, layer, slots_ptr, slot_bytes, n_slots, my_slot, stream):
@@ -252,7 +253,7 @@ class ContextParallel:
             raise e
 
 
-def _video_context_parallel(decoder, ax, apos, ats, group, local_context_size, is_keyframe, init_num_images):
+def _video_context_parallel(decoder, ax, apos, ats, group, local_context_size, is_keyframe, init_num_images, partial16=True):
     """The streaming schedule of ``engine.run_video`` with the memory SHARDED over the ranks: image label L lives on rank L % world.  The init call (several views
     attending each other's pre-feedback tokens) is replicated and every rank keeps its own labels' rows; every later one-view call runs context-parallel
     (``decoder(.., cp=..)``): all ranks compute the frame, the owner of its label keeps the appended rows, the others rewind their buffers.  Eviction touches
@@ -260,7 +261,7 @@ def _video_context_parallel(decoder, ax, apos, ats, group, local_context_size, i
     from collections import deque
     from .engine import demo_mem_batches, remove_from_mem
     rank, world = _world(group)
-    cpx = ContextParallel(group)
+    cpx = ContextParallel(group, partial16=partial16)
     V, N = int(ax.shape[0]), int(ax.shape[1])
     ts_host = ats.cpu() if ats.is_cuda else ats
     mem = None
@@ -344,7 +345,7 @@ def run_video_sharded(encoder, decoder, imgs_local, true_shape_local, group=None
 
     ``context_parallel=True`` (r06): the memory itself is sharded over the ranks and the per-frame cross attention runs context-parallel
     (``_video_context_parallel``): per-rank cross-attention work and K|V memory footprint drop by the world size, for one all-gather of
-    [tokens, dec_dim + 2 heads] fp32 partials per layer and frame."""
+    [tokens, dec_dim] 16-bit + [tokens, 2 heads] fp32 partials per layer and frame (``context_parallel="fp32"``: fp32 partials, twice the bytes)."""
     from .engine import run_video
     x, pos = _encode_local(encoder, imgs_local, true_shape_local)
     all_kf = torch.ones(x.shape[0], dtype=torch.bool)
@@ -354,7 +355,8 @@ def run_video_sharded(encoder, decoder, imgs_local, true_shape_local, group=None
         # r06 (SURVEY.md section 8f "later"): the memory is SHARDED over the ranks (label L on rank L % world) and the per-frame update attends it context-parallel:
         # one all-gather of fp32 partials per layer and frame instead of a replicated cross attention over the whole memory; the whole memory is gathered once, at
         # the end, for the view-sharded render
-        mem_local, pm0, keyframes, rows, cpx = _video_context_parallel(decoder, ax, apos, ats, group, local_context_size, is_keyframe, init_num_images)
+        mem_local, pm0, keyframes, rows, cpx = _video_context_parallel(decoder, ax, apos, ats, group, local_context_size, is_keyframe, init_num_images,
+                                                                       partial16=(context_parallel != "fp32"))
         mem = gather_memory(mem_local, rows, group) if (render or gather_outputs) else mem_local
         out = {"mem": mem, "mem_local": mem_local, "rows_per_rank": rows, "keyframes": keyframes, "pointmaps_0": pm0,
                "cp_exchanges": cpx.exchanges, "cp_bytes_gathered": cpx.bytes_gathered}

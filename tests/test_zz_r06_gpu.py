@@ -40,7 +40,8 @@ def _oracle_stream(cfg, imgs, ts):
     return pm0, ren[0], kf
 
 
-def test_context_parallel_stream_through_rccl_group_of_one_rank():
+@pytest.mark.parametrize("partials", [True, "fp32"])
+def test_context_parallel_stream_through_rccl_group_of_one_rank(partials):
     """One rank, RCCL: every layer's partial really goes through all_gather_into_tensor (12 exchanges per one-view call), the merge of ONE slot reproduces the
     single-process stream (same sums; the local attention is always split in two or more, so the first frames -- whose memory the plain path attends unsplit --
     differ in the last bits), and both sit inside the mode's tolerance of the oracle."""
@@ -53,7 +54,7 @@ def test_context_parallel_stream_through_rccl_group_of_one_rank():
         cfg, prec = SMALL, "fp16w2"
         enc, dec = build(cfg, prec)
         imgs, ts = S.make_images(V, H, W, 11)
-        ov = run_video_sharded(enc, dec, imgs.cuda(), ts, local_context_size=WINDOW, is_keyframe=KF, frame_counts=[V], context_parallel=True, gather_outputs=True)
+        ov = run_video_sharded(enc, dec, imgs.cuda(), ts, local_context_size=WINDOW, is_keyframe=KF, frame_counts=[V], context_parallel=partials, gather_outputs=True)
         memv, pm0, kfs = run_video(enc, dec, imgs.cuda(), ts, local_context_size=WINDOW, is_keyframe=KF)
         torch.cuda.synchronize()
         assert ov["keyframes"] == kfs and torch.equal(ov["mem"][1], memv[1]) and ov["rows_per_rank"] == [int(memv[1].shape[1])]
@@ -61,7 +62,7 @@ def test_context_parallel_stream_through_rccl_group_of_one_rank():
         e_cp = rel_inf(ov["pointmaps_0"].cpu(), pm0.cpu())
         pm_o, ren_o, kf_o = _oracle_stream(cfg, imgs, ts)
         e_or = max(rel_inf(ov["pointmaps_0"].cpu(), pm_o), rel_inf(ov["render_all"].cpu(), ren_o))
-        record("context_parallel_world1", vs_plain_stream=e_cp, vs_oracle=e_or, exchanges=ov["cp_exchanges"], bytes_gathered=ov["cp_bytes_gathered"])
+        record("context_parallel_world1", partials=str(partials), vs_plain_stream=e_cp, vs_oracle=e_or, exchanges=ov["cp_exchanges"], bytes_gathered=ov["cp_bytes_gathered"])
         # (measured 2.7e-4 from the plain stream: the context-parallel call always leaves 16-bit split-KV partials, the plain one-view call attends these short
         # memories unsplit -- the rounding of one more 16-bit intermediate; 4.5e-4 from the oracle)
         assert kf_o == kfs and e_cp < 0.5 * TOL[prec] and e_or < TOL[prec], (e_cp, e_or)
