@@ -1492,7 +1492,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
         const int q = nwg >> 3, r = nwg & 7;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
     }
-    constexpr int GM = 4;
+    const int GM = p.gm > 0 ? p.gm : 4;   // row-blocks per group of the tile walk (option G256_GM; launch_256p)
     const int tpg = GM * nbn;
     const int gidx = bid / tpg;
     const int gfirst = gidx * GM;
@@ -1810,7 +1810,9 @@ static int persistent_blocks() {
 static int persist_mode() { return opt(OPT_PERSIST); }
 
 template <class T, int EPI, int WS, int BN, int NPH, int SYNC = 2>
-static int launch_256p(const GemmArgs& a, hipStream_t s) {
+static int launch_256p(const GemmArgs& a_in, hipStream_t s) {
+    GemmArgs a = a_in;
+    a.gm = opt(OPT_G256_GM);
     const int nbn = a.N / BN, nbm = (a.M + 255) / 256;
     const size_t lds = (size_t)2 * 4 * 128 * 64 * sizeof(T);
     const long nwork = (long)nbm * nbn * (a.batch > 1 ? a.batch : 1);
@@ -1897,7 +1899,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
         const int q = nwg >> 3, r = nwg & 7;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
     }
-    constexpr int GM = 4;
+    const int GM = p.gm > 0 ? p.gm : 4;   // (option G256_GM; launch_256s)
     const int tpg = GM * nbn;
     const int gidx = bid / tpg;
     const int gfirst = gidx * GM;
@@ -2078,7 +2080,9 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
 }
 
 template <class T, int EPI>
-static int launch_256s(const GemmArgs& a, hipStream_t s) {
+static int launch_256s(const GemmArgs& a_in, hipStream_t s) {
+    GemmArgs a = a_in;
+    a.gm = opt(OPT_G256_GM);
     const int nbn = a.N / 256, nbm = (a.M + 255) / 256;
     const size_t lds = (size_t)2 * 5 * 128 * 64 * sizeof(T);   // 163840 B: the CU's whole LDS
     const long nwork = (long)nbm * nbn * (a.batch > 1 ? a.batch : 1);

@@ -96,6 +96,7 @@ struct GemmArgs {
     //     stats_out [M][N/64][2] (+ copy32_out);  on a consumer (STORE16 / STORE16_GELU / QKV_ROPE; K = 768 or 1024): ln_stats is that [M][K/64][2] layout.
     //   ln_shift (required on consumers) must hold valid values (zeros at the start of a call): every consumer adds the mean it measured (ln_shift_init is ignored).
     int fold256;
+    int gm;                  // set by the 256-row launchers from the option G256_GM: row-blocks per group of the tile walk (0 = 4)
 #ifdef GEMM_TRACE
     int trace_block;         // probe builds only (scripts/probes/gemm256p_trace.hip): the block whose waves leave cycle stamps
 #endif

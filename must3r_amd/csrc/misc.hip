@@ -17,7 +17,7 @@ struct OptRow { const char* name; long long def, lo, hi; };
 const OptRow kOpts[OPT_COUNT] = {
     {"PERSIST", 0, 0, 1}, {"GEMM256", 1, 0, 2}, {"G256K", 1, 0, 2}, {"G256P", 1, 0, 1}, {"G256P_SPLIT", 1, 0, 2}, {"SPARSE_256", 1, 0, 1},
     {"SPARSE_LO", 1, 0, 1}, {"BK128", 1, 0, 1}, {"LN_ROWS", 1, 0, 1}, {"LNFOLD", 1, 0, 1}, {"ENC_CHUNK_ROWS", 32768, 256, 1 << 22}, {"ATTN_LZ", 1, 0, 2},
-    {"LNFOLD256", 0, 0, 1},
+    {"LNFOLD256", 0, 0, 1}, {"G256_GM", 4, 1, 64},
 };
 long long g_opt_val[OPT_COUNT];
 bool g_opt_init[OPT_COUNT];

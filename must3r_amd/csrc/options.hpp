@@ -23,6 +23,7 @@ enum Opt {
     OPT_LNFOLD256,         // r06: LN fold in the chip-filling launches (batched decoder calls, encoder chunks; MUST3R_F16_WA): 0 (default) LayerNorm kernels.
                            //      Measured (profiles/r06_lnfold256_ab.txt, S = 28, interleaved runs on one box): LayerNorm 68.5 -> 13.2 ms per step, GEMMs 534 -> 582 ms
                            //      (producers + 2 B per element of HBM-bound epilogue, consumers + 32 KB of statistics per tile in front of the first DMA): 559 vs 557 views/s
+    OPT_G256_GM,           // r06: row-blocks per group of the tile walk of gemm256p / gemm256s (which tiles an XCD's 32 CUs hold together: GM rows x 32 / GM columns)
     OPT_COUNT
 };
 

@@ -19,6 +19,8 @@ from must3r_amd import _lib as lib  # noqa: E402
 L = lib.load()
 P = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None  # noqa: E731
 st = torch.cuda.current_stream().cuda_stream
+OPT = os.environ.get("OPT", "PERSIST")                         # the switch under test and its two values: OPT=G256_GM VALS=4,8
+V0, V1 = (int(v) for v in os.environ.get("VALS", "0,1").split(","))
 ROUNDS = int(os.environ.get("ROUNDS", "7"))
 REPS = int(os.environ.get("REPS", "10"))
 
@@ -75,14 +77,14 @@ for name, M, N, K, epi, split in SHAPES:
     vendor = []
     digests, times = {}, {0: [], 1: []}
     for mode in (0, 1):
-        lib.set_option("PERSIST", mode)
+        lib.set_option(OPT, (V0, V1)[mode])
         out.zero_()
         run()
         torch.cuda.synchronize()
         digests[mode] = sha(out)
     for r in range(ROUNDS):
         for mode in (0, 1):
-            lib.set_option("PERSIST", mode)
+            lib.set_option(OPT, (V0, V1)[mode])
             run()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -103,9 +105,10 @@ for name, M, N, K, epi, split in SHAPES:
     m0, m1 = statistics.median(times[0]), statistics.median(times[1])
     tot[0] += m0
     tot[1] += m1
-    print(f"{name:36s} M={M:6d} N={N:5d} K={K:5d}  plain launch {min(times[0]):8.1f} / {m0:8.1f} us ({fl / m0 / 1e6:7.1f} TF/s)   persistent {min(times[1]):8.1f} / {m1:8.1f} us "
+    print(f"{name:36s} M={M:6d} N={N:5d} K={K:5d}  {OPT}={V0} {min(times[0]):8.1f} / {m0:8.1f} us ({fl / m0 / 1e6:7.1f} TF/s)   {OPT}={V1} {min(times[1]):8.1f} / {m1:8.1f} us "
           f"({fl / m1 / 1e6:7.1f} TF/s)   x{m0 / m1:5.3f}   bits {'equal' if digests[0] == digests[1] else 'DIFFER ' + digests[0] + ' ' + digests[1]}"
           f"   | vendor plain product {min(vendor):8.1f} / {statistics.median(vendor):8.1f} us ({fl / statistics.median(vendor) / 1e6:7.1f} TF/s)", flush=True)
     del A, W, Wf, out, vout, W16
-print(f"sum of medians: plain launch {tot[0]:.0f} us, persistent {tot[1]:.0f} us, x{tot[0] / tot[1]:.3f}")
+print(f"sum of medians: {OPT}={V0} {tot[0]:.0f} us, {OPT}={V1} {tot[1]:.0f} us, x{tot[0] / tot[1]:.3f}")
+lib.set_option(OPT, V0)
 lib.set_option("PERSIST", 0)
