@@ -241,7 +241,8 @@ class ContextParallel:
                 dist.all_gather_into_tensor(out.view(-1), buf[self.rank].cpu(), group=self.group)
                 buf.copy_(out.to(buf.device))
             else:
-                dist.all_gather_into_tensor(buf.view(-1), buf[self.rank].clone(), group=self.group)
+                # in place: rank r's contribution already sits at slot r of the receive buffer (ncclAllGather's in-place form: sendbuff = recvbuff + rank * count)
+                dist.all_gather_into_tensor(buf.view(-1), buf[self.rank], group=self.group)
             return 0
         except BaseException as e:   # noqa: BLE001 -- ctypes cannot propagate it: kept for reraise(), the native call fails with status 1
             self._error = e
