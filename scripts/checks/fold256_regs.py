@@ -27,7 +27,7 @@ def all_vregs(line):
 
 def main(path):
     lines = open(path).read().split("\n")
-    kern, bad, seen = None, 0, 0
+    kern, bad, seen, n_ix = None, 0, 0, 0
     i = 0
     while i < len(lines):
         l = lines[i]
@@ -56,7 +56,30 @@ def main(path):
             bad += 0 if ok else 1
             i += 6
             continue
+        # gemm256s_kernel's load_ix: two dword loads of the 2:4 positions, the second at offset:256 of the same address -- same rule: nothing names the two
+        # destination registers before a counted vmcnt wait (take_ix's v_mov sits behind it; in text order the next iteration's wait or the last K-tile's)
+        b2 = [x.strip() for x in lines[i:i + 2]]
+        if (len(b2) == 2 and b2[0].startswith("global_load_dword ") and b2[1].startswith("global_load_dword ") and b2[1].endswith("offset:256")
+                and "gemm256s" in (kern or "") and b2[0].split()[2] == b2[1].split()[2]):
+            dest = regs_of(b2[0].split()[1].rstrip(",")) | regs_of(b2[1].split()[1].rstrip(","))
+            waited, j = False, i + 2
+            while j < len(lines):
+                t = lines[j].strip()
+                if t.startswith("s_waitcnt") and "vmcnt" in t:
+                    waited = True
+                if t.startswith("s_endpgm"):
+                    break
+                if not t.startswith(";") and not t.startswith(".") and all_vregs(t) & dest:
+                    break
+                j += 1
+            n_ix += 1
+            if not waited:
+                bad += 1
+                print(f"BAD {kern}: load_ix registers {sorted(dest)} touched by `{lines[j].strip()}` before any counted wait")
+            i += 2
+            continue
         i += 1
+    print(f"{n_ix} load_ix sites checked in the gemm256s instantiations")
     print(f"{seen} fold256 prologue(s) checked, {bad} bad")
     return 1 if bad or not seen else 0
 
