@@ -163,6 +163,11 @@ typedef struct must3r_hip_decode_args {
     int64_t mem_scene_stride;
     /* ---- ABI 8 ---- */
     const must3r_hip_cp* cp;   /* NULL: off.  Context-parallel cross attention (above): `mem` / `n_mem` describe this rank's SHARD of the memory */
+    /* CausalMUSt3R.forward (decoder.py:435-553; the class the checkpoints are trained as), memory dropout off: in a memory update of several views, view i
+     * cross-attends the old memory and the new (pre-feedback) tokens of the views BEFORE it in the call -- make_attn_mask decoder.py:389-433 -- instead of the new
+     * tokens of every other view; when the memory is empty view 0 attends view 1's tokens (decoder.py:399-402).  One group (the class has no list dispatch); render
+     * and one-view calls are MUSt3R's.  The tuple's tail (protected images / tokens, decoder.py:461-464) is the caller's bookkeeping. */
+    int32_t causal;
 } must3r_hip_decode_args;
 
 /* bytes of one rank's partial for a context-parallel call of `rows` token rows: rows x (dec_dim + 2 x dec_heads) floats, rounded up to 256;

@@ -63,7 +63,7 @@ class DecodeArgs(C.Structure):
                 ("n_groups", C.c_int32), ("groups", C.POINTER(Group)), ("n_mem", C.c_int32),
                 ("mem", C.POINTER(C.c_void_p)), ("feats", C.c_void_p),
                 ("mem_capacity", C.c_int32), ("n_scenes", C.c_int32), ("mem_scene_stride", C.c_int64),
-                ("cp", C.POINTER(Cp))]
+                ("cp", C.POINTER(Cp)), ("causal", C.c_int32)]
 
 
 class ProfRecord(C.Structure):

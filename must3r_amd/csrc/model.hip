@@ -982,6 +982,12 @@ static int decode_impl(must3r_hip_ctx* c, const must3r_hip_decode_args* A, void*
                     AttnView cv{r0, n, (int)(b * kv_stride), Nm, 0, 0};
                     if (update) {
                         if (lone_view) { cv.nk = Nm; }
+                        else if (use_mask && A->causal) {
+                            // CausalMUSt3R.make_attn_mask (decoder.py:389-433): old memory + the new tokens of the views before this one = a PREFIX of the key rows;
+                            // empty memory: view 0 attends view 1's tokens (labels < 2, != 0: decoder.py:399-402) = rows [n, 2n) behind an excluded [0, n)
+                            if (Nm == 0 && j == 0) { cv.nk = 2 * n; cv.skip_lo = 0; cv.skip_hi = n; }
+                            else { cv.nk = Nm + rl; }
+                        }
                         else if (use_mask) { cv.nk = Nm + Rs; cv.skip_lo = Nm + rl; cv.skip_hi = Nm + rl + n; }
                         else { cv.nk = Nm + Rs; }  // first view alone: attends its own (pre-feedback) tokens
                     }
@@ -1331,6 +1337,8 @@ extern "C" int must3r_hip_decode(must3r_hip_ctx* c, const must3r_hip_decode_args
     if (A->first_call && A->n_mem != 0) return fail("decode: first_call with a non-empty memory");
     if (A->n_scenes < 0) return fail("decode: negative n_scenes");
     const int S = A->n_scenes > 1 ? A->n_scenes : 1;
+    if (A->causal != 0 && A->causal != 1) return fail("decode: causal must be 0 or 1");
+    if (A->causal && (A->n_groups != 1 || A->cp)) return fail("decode: the causal forward takes ONE group of views (CausalMUSt3R has no list dispatch) and no context parallelism");
     if (A->cp) {   // context-parallel cross attention: the one-view update of the streaming schedule, nothing else
         const must3r_hip_cp& P = *A->cp;
         if (P.world < 1 || P.rank < 0 || P.rank >= P.world) return fail("decode: context parallel: bad rank %d of %d", P.rank, P.world);

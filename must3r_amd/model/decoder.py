@@ -324,7 +324,7 @@ class MUSt3R(HipModule):
         args = _lib.DecodeArgs(odt | (_lib.ATTN_FP8 if self.attention_fp8 else 0), _MEM_MODE[self.memory_mode],
                                1 if render else 0, 1 if current_mem is None else 0,
                                len(xs), groups, Nm, ptrs, feats_buf.data_ptr() if return_feats else None,
-                               cap, B, stride, C.pointer(cp_struct) if cp_struct is not None else None)
+                               cap, B, stride, C.pointer(cp_struct) if cp_struct is not None else None, 1 if self._causal else 0)
         rc = ctx.lib.must3r_hip_decode(ctx.handle, C.byref(args), self._stream(dev))
         if cp is not None and rc != 0:
             cp.reraise()          # an exception raised inside the exchange callback (ctypes cannot propagate it) comes out here
@@ -352,7 +352,7 @@ class MUSt3R(HipModule):
             if runs is not None and B == 1:
                 attach_label_runs(mem_labels, runs)
             tot = mem_nimgs + sum(nimgs)
-            out = (new_vals, mem_labels, tot, tot, mem_labels.shape[1])
+            out = self._memory_tail(new_vals, mem_labels, tot, mem_prot_imgs, mem_prot_tok, sum(nimgs), Ns[0])
         feats = None
         if return_feats:
             feats, r0 = [], 0
@@ -364,11 +364,42 @@ class MUSt3R(HipModule):
     def forward_list(self, x, pos, true_shape, current_mem=None, render=False, return_feats=False):  # decoder.py:158
         return self._forward(list(x), list(pos), list(true_shape), current_mem, render, return_feats)
 
+    # MUSt3R: every image is "protected" (decoder.py:336: (mem, labels, n, n, Nm')); CausalMUSt3R overrides both
+    _causal = False
+
+    def _memory_tail(self, vals, labels, n_imgs, prot_imgs, prot_tok, n_new, N):
+        return (vals, labels, n_imgs, n_imgs, labels.shape[1])
+
 
 class CausalMUSt3R(MUSt3R):
-    """Training class of the reference (decoder.py:353).  Not part of the inference forward path; kept only so
-    that checkpoint constructor strings naming it resolve (model/__init__.py:53-63 rewrites them to MUSt3R)."""
+    """The class the reference's checkpoints are TRAINED as (decoder.py:352-553): ONE forward over a sequence of views in which view i cross-attends the memory of the
+    views before it.  Built in r06 for SURVEY.md section 8(f) "later" as a FORWARD (what a function of its inputs can be checked against): the memory dropout of the
+    training recipe (``mem_dropout > 0``: random token selection, decoder.py:470-485) is refused.  ``use_mem_mask`` / ``use_xformers_mask`` choose between two
+    equivalent ways of masking in the reference (physically removed rows / an additive mask) and change nothing here: the native cross attention reads a key PREFIX per
+    view (``must3r_hip_decode_args.causal``).  Tensor inputs only, like the reference's class (its forward has no list dispatch).  Render calls and one-view updates are
+    MUSt3R's; the tuple's tail follows decoder.py:461-464 (``protected_imgs``)."""
 
-    def __init__(self, *a, **k):
-        raise NotImplementedError("CausalMUSt3R is the reference's training module and is out of scope; "
-                                  "use convert_decoder_args() / load_model()")
+    _causal = True
+
+    def __init__(self, protected_imgs=1, mem_dropout=0.0, dropout_mode="temporary", use_xformers_mask=False, use_mem_mask=False, **kv):
+        if dropout_mode not in ("temporary", "permanent"):
+            raise ValueError(f"Invalid dropout mode = {dropout_mode}")            # decoder.py:376
+        if float(mem_dropout) > 0.0:
+            raise NotImplementedError("CausalMUSt3R(mem_dropout > 0) is the training-time random token dropout (decoder.py:470-485): not part of the forward path")
+        super().__init__(**kv)
+        self.protected_imgs = int(protected_imgs)
+        self.dropout_mode = dropout_mode
+        self.use_xformers_mask, self.use_mem_mask = bool(use_xformers_mask), bool(use_mem_mask)
+
+    @torch.no_grad()
+    def forward(self, x, pos, true_shape, current_mem=None, render=False, return_feats=False, pointmaps_out=None):
+        if isinstance(x, (list, tuple)):
+            raise TypeError("CausalMUSt3R.forward takes tensors [B, nimgs, N, C] (the reference's class has no list dispatch, decoder.py:435-439)")
+        return self._forward(x, pos, true_shape, current_mem, render, return_feats, pointmaps_out)
+
+    def forward_list(self, *a, **k):
+        raise TypeError("CausalMUSt3R has no forward_list (decoder.py:352-553)")
+
+    def _memory_tail(self, vals, labels, n_imgs, prot_imgs, prot_tok, n_new, N):
+        prot = min(self.protected_imgs, int(prot_imgs) + int(n_new))             # decoder.py:461-464
+        return (vals, labels, n_imgs, prot, int(prot_tok) + (prot - int(prot_imgs)) * int(N))

@@ -97,6 +97,33 @@ def main(cases=None, mixed=True):
     print("tiny_mixed_ar ok, Nm", mem2[0][0].shape[1])
 
 
+# r06: CausalMUSt3R (decoder.py:352-553; SURVEY.md section 8f "later"), the reference's class itself on the leaf shims: ONE forward over a sequence of views, view i
+# cross-attending the memory of the views before it.  Calls of [3, 2, 1] views + a render of all six; protected_imgs = 1 (the default).
+def main_causal(name="small_224_causal", cfg=SMALL, H=224, W=224, calls=(3, 2, 1), ps=4, tks=4):
+    torch.set_num_threads(os.cpu_count() or 8)
+    V = sum(calls)
+    sde, sdd = S.make_encoder_state_dict(cfg, 0), S.make_decoder_state_dict(cfg, 0)
+    imgs, ts = S.make_images(V, H, W, 0)
+    enc, _ = ref_shims.build_reference(cfg, sde, sdd, "kv")
+    dec = ref_shims.build_reference_causal(cfg, sdd, "kv")
+    with torch.no_grad():
+        x, pos = enc(imgs, ts)
+        mem, upd, tails, i = None, [], [], 0
+        for nb in calls:
+            mem, pm = dec(x[i:i + nb].unsqueeze(0), pos[i:i + nb].unsqueeze(0), ts[i:i + nb].unsqueeze(0), mem)
+            upd.append(pm[0])
+            tails.append([int(v) for v in mem[2:]])
+            i += nb
+        _, ren = dec(x.unsqueeze(0), pos.unsqueeze(0), ts.unsqueeze(0), mem, render=True)
+    upd = torch.cat(upd, 0)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), meta=np.array([H, W, V, ps, tks] + list(calls), dtype=np.int64),
+                        update=upd[:, ::ps, ::ps].numpy(), render=ren[0][:, ::ps, ::ps].numpy(),
+                        update_vmax=upd.double().abs().amax(dim=(1, 2, 3)).numpy(), render_vmax=ren[0].double().abs().amax(dim=(1, 2, 3)).numpy(),
+                        mem_first=mem[0][0][0, ::tks, ::tks].numpy(), mem_last=mem[0][-1][0, ::tks, ::tks].numpy(),
+                        labels=mem[1].numpy(), tails=np.array(tails, dtype=np.int64))
+    print(name, "update", tuple(upd.shape), "render", tuple(ren.shape), "Nm", mem[0][0].shape[1], "tails", tails)
+
+
 # r06: ALL pixels of the views of the headline scene that are worst against the oracle in the benched configuration -- the sub-sampled
 # fixture above sees every 8th pixel in each dimension (1/64 of them) and reads 5.9e-4 where the all-pixel figure is 7.1-7.3e-4.  Which views: the worst update /
 # render views of scene 0 of the 28-scene step (update 15, render 2) and of the one-scene-at-a-time run (update 1, render 19), gpurun_out/r06_c01_bench.json.
@@ -206,6 +233,8 @@ if __name__ == "__main__":
         main(BIG_CASES, mixed=False)
     if which == "full_views":
         main_full_views()
+    if which in ("all", "causal"):
+        main_causal()
     if which in BIG_CASES or which in CASES:
         main({which: {**CASES, **BIG_CASES}[which]}, mixed=False)
     if which in ("all", "cam"):

@@ -203,8 +203,13 @@ def empty_memory(cfg, memory_mode, dtype=torch.float32):
 
 
 def decoder_forward(sd, cfg, x, pos, true_shape, current_mem=None, render=False, memory_mode="kv",
-                    opq=_ID, sdpa=False, return_feats=False):
+                    opq=_ID, sdpa=False, return_feats=False, causal=False, protected_imgs=1):
     """MUSt3R.forward / forward_list decoder.py:158-350, batch B = 1.
+
+    ``causal=True``: CausalMUSt3R.forward (decoder.py:435-553) with its memory dropout off (p = 0: the only form that is a function of its inputs): in a memory
+    update, view i cross-attends the old memory and the NEW tokens of the views before it in the call (make_attn_mask decoder.py:389-433: labels < idx, != idx) instead
+    of the new tokens of all other views; at initialisation view 0 attends view 1's tokens (:399-402).  Tensor inputs only (the class has no list dispatch); the tuple's
+    tail is (n_imgs, min(protected_imgs, ...), protected tokens) (:461-464).
 
     ``x``: tensor [1,n,N,Cenc] or a list of such tensors (one per aspect ratio); ``pos`` / ``true_shape``
     alike.  Returns ``(mem_tuple, pointmaps)`` with the same container type as the input
@@ -259,7 +264,13 @@ def decoder_forward(sd, cfg, x, pos, true_shape, current_mem=None, render=False,
         for g, c in enumerate(cur):
             outs = []
             for j in range(nimgs[g]):
-                if use_mask:  # a view never cross-attends to its own new tokens (make_mem_mask decoder.py:119-139)
+                if use_mask and causal:  # make_attn_mask decoder.py:389-433 (old memory labels are all < mem_nimgs <= idx)
+                    assert len(cur) == 1
+                    if Nm == 0 and j == 0:   # :399-402: idx of view 0 becomes 2 -> labels {1} (label 0 is its own)
+                        y = mem_l[:, Ns[g]:2 * Ns[g]]
+                    else:
+                        y = mem_l[:, :Nm + offs[g][j]]
+                elif use_mask:  # a view never cross-attends to its own new tokens (make_mem_mask decoder.py:119-139)
                     lo = Nm + offs[g][j]
                     y = torch.cat((mem_l[:, :lo], mem_l[:, lo + Ns[g]:]), dim=1)
                 else:
@@ -290,7 +301,11 @@ def decoder_forward(sd, cfg, x, pos, true_shape, current_mem=None, render=False,
             k += n
         mem_labels = torch.cat([mem_labels] + labels, dim=1)
         tot = mem_nimgs + sum(nimgs)
-        out_mem = (mem_out, mem_labels, tot, tot, mem_labels.shape[1])
+        if causal:   # decoder.py:461-464: protected images / tokens are bookkeeping of the training-time dropout
+            prot = min(protected_imgs, mem_prot_imgs + sum(nimgs))
+            out_mem = (mem_out, mem_labels, tot, prot, mem_prot_tok + (prot - mem_prot_imgs) * Ns[0])
+        else:
+            out_mem = (mem_out, mem_labels, tot, tot, mem_labels.shape[1])
     else:
         out_mem = (mem_vals, mem_labels, mem_nimgs, mem_prot_imgs, mem_prot_tok)  # decoder.py:252 / :339
     pms = []

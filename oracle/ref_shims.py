@@ -250,3 +250,17 @@ def build_reference(cfg, sd_enc, sd_dec, memory_mode="kv", feedback_type="single
     enc.load_state_dict(sd_enc, strict=True)
     dec.load_state_dict(sd_dec, strict=True)
     return enc.eval(), dec.eval()
+
+
+def build_reference_causal(cfg, sd_dec, memory_mode="kv", feedback_type="single_mlp", **causal_kw):
+    """The reference's CausalMUSt3R (decoder.py:352-553: the class the released checkpoints were TRAINED as -- one forward over a sequence of views in which view i
+    cross-attends the memory of the views before it) with the same state dict (it adds no parameters); ``causal_kw``: protected_imgs, use_mem_mask, ..."""
+    import importlib
+    import_reference_model()
+    dmod = importlib.import_module("must3r.model.decoder")
+    dec = dmod.CausalMUSt3R(img_size=(cfg.img_size, cfg.img_size), enc_embed_dim=cfg.enc_dim,
+                            patch_size=cfg.patch_size, embed_dim=cfg.dec_dim, output_dim=cfg.output_dim,
+                            depth=cfg.dec_depth, num_heads=cfg.dec_heads, feedback_type=feedback_type,
+                            memory_mode=memory_mode, landscape_only=False, **causal_kw)
+    dec.load_state_dict(sd_dec, strict=True)
+    return dec.eval()

@@ -390,3 +390,25 @@ def test_set_option_is_validated(monkeypatch):
     for name, ok in (("PERSIST", 0), ("PERSIST", 1), ("GEMM256", 2), ("GEMM256", 1), ("ENC_CHUNK_ROWS", 32768), ("ATTN_LZ", 1), ("LNFOLD", 1), ("SPARSE_LO", 1)):
         _lib.set_option(name, ok)
 
+
+
+def test_causal_module_constructor_and_memory_tail():
+    """r06: CausalMUSt3R is a forward now (must3r/model/decoder.py:352-553).  Its constructor takes the reference's arguments, refuses the training-time memory dropout
+    and unknown dropout modes like the reference (decoder.py:376), and its tuple tail follows decoder.py:461-464."""
+    import must3r_amd.model as M
+    from must3r_amd.config import TINY as cfg
+    kw = dict(img_size=(cfg.img_size,) * 2, enc_embed_dim=cfg.enc_dim, embed_dim=cfg.dec_dim, depth=cfg.dec_depth, num_heads=cfg.dec_heads,
+              feedback_type="single_mlp", memory_mode="kv", landscape_only=False)
+    dec = M.CausalMUSt3R(protected_imgs=2, use_xformers_mask=True, use_mem_mask=True, **kw)
+    assert isinstance(dec, M.MUSt3R) and dec._causal and dec.protected_imgs == 2
+    assert set(dec.state_dict().keys()) == set(M.MUSt3R(**kw).state_dict().keys())          # the class adds no parameters
+    labels = torch.zeros((1, 36), dtype=torch.int64)
+    assert dec._memory_tail([], labels, 3, 0, 0, 3, 12)[2:] == (3, 2, 24)                   # init with 3 views: 2 protected images = 24 tokens
+    assert dec._memory_tail([], labels, 5, 2, 24, 2, 12)[2:] == (5, 2, 24)                  # later calls add none
+    assert M.MUSt3R(**kw)._memory_tail([], labels, 3, 0, 0, 3, 12)[2:] == (3, 3, 36)        # MUSt3R: every image protected (decoder.py:336)
+    with pytest.raises(NotImplementedError, match="mem_dropout"):
+        M.CausalMUSt3R(mem_dropout=0.1, **kw)
+    with pytest.raises(ValueError, match="dropout mode"):
+        M.CausalMUSt3R(dropout_mode="sometimes", **kw)
+    with pytest.raises(TypeError, match="no list dispatch"):
+        dec([torch.zeros(1)], [torch.zeros(1)], [torch.zeros(1)])

@@ -37,6 +37,66 @@ def test_restatement_equals_reference(mode):
         assert rel_inf(pmo, pmr) < 2e-5
 
 
+@pytest.mark.parametrize("mode,kw", [("kv", {}), ("norm_y", {"use_mem_mask": True}), ("kv", {"protected_imgs": 2})])
+def test_causal_restatement_equals_reference(mode, kw):
+    """r06, SURVEY.md section 8f "later": CausalMUSt3R.forward (decoder.py:435-553), memory dropout off.  The reference's class itself on the leaf shims (both of its
+    mask forms: the boolean attention mask and `use_mem_mask`'s physically removed rows) against the restatement's `causal=True`: calls of 3 (init: view 0 attends view 1,
+    decoder.py:399-402), 2 and 1 views, render; pointmaps, memory, labels and the tuple's tail."""
+    from oracle import ref_shims, must3r_ref as R
+    cfg = TINY
+    sde, sdd = S.make_encoder_state_dict(cfg, 5), S.make_decoder_state_dict(cfg, 5)
+    imgs, ts = S.make_images(6, 48, 64, 5)
+    enc, plain = ref_shims.build_reference(cfg, sde, sdd, mode)
+    dec = ref_shims.build_reference_causal(cfg, sdd, mode, **kw)
+    prot = kw.get("protected_imgs", 1)
+    with torch.no_grad():
+        x, pos = enc(imgs, ts)
+        memr = memo = None
+        i = 0
+        for nb in (3, 2, 1):
+            sl = slice(i, i + nb)
+            a = (x[sl].unsqueeze(0), pos[sl].unsqueeze(0), ts[sl].unsqueeze(0))
+            memr, pmr = dec(*a, memr)
+            memo, pmo = R.decoder_forward(sdd, cfg, *a, memo, False, mode, causal=True, protected_imgs=prot)
+            assert rel_inf(pmo, pmr) < 2e-5
+            assert max(rel_inf(u, v) for u, v in zip(memo[0], memr[0])) < 2e-5
+            assert torch.equal(memo[1], memr[1]) and tuple(int(v) for v in memo[2:]) == tuple(int(v) for v in memr[2:])
+            if i == 0:   # the causal mask is a different computation from MUSt3R's own-token mask as soon as a call holds more than one view
+                _, pmp = plain(*a, None)
+                assert rel_inf(pmp, pmr) > 1e-2
+            i += nb
+        a = (x.unsqueeze(0), pos.unsqueeze(0), ts.unsqueeze(0))
+        _, pmr = dec(*a, memr, render=True)
+        _, pmo = R.decoder_forward(sdd, cfg, *a, memo, True, mode, causal=True, protected_imgs=prot)
+        assert rel_inf(pmo, pmr) < 2e-5
+
+
+def test_causal_fixture_is_what_the_restatement_computes():
+    """tests/golden/small_224_causal.npz (oracle/make_golden.py main_causal: the REFERENCE's CausalMUSt3R, calls of [3, 2, 1] views + render) against the restatement."""
+    import numpy as np
+    import os
+    from oracle import must3r_ref as R
+    from must3r_amd.config import SMALL
+    fx = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "small_224_causal.npz"))
+    H, W, V, ps, tks = (int(v) for v in fx["meta"][:5])
+    calls = [int(v) for v in fx["meta"][5:]]
+    cfg = SMALL
+    sde, sdd = S.make_encoder_state_dict(cfg, 0), S.make_decoder_state_dict(cfg, 0)
+    imgs, ts = S.make_images(V, H, W, 0)
+    with torch.no_grad():
+        x, pos = R.encoder_forward(sde, cfg, imgs, ts)
+        mem, upd, i = None, [], 0
+        for k, nb in enumerate(calls):
+            mem, pm = R.decoder_forward(sdd, cfg, x[i:i + nb].unsqueeze(0), pos[i:i + nb].unsqueeze(0), ts[i:i + nb].unsqueeze(0), mem, False, "kv", causal=True)
+            upd.append(pm[0])
+            assert [int(v) for v in mem[2:]] == [int(v) for v in fx["tails"][k]]
+            i += nb
+        _, ren = R.decoder_forward(sdd, cfg, x.unsqueeze(0), pos.unsqueeze(0), ts.unsqueeze(0), mem, True, "kv", causal=True)
+    upd = torch.cat(upd, 0)
+    assert rel_inf(upd[:, ::ps, ::ps], torch.from_numpy(fx["update"])) < 2e-5 and rel_inf(ren[0][:, ::ps, ::ps], torch.from_numpy(fx["render"])) < 2e-5
+    assert rel_inf(mem[0][-1][0, ::tks, ::tks], torch.from_numpy(fx["mem_last"])) < 2e-5 and np.array_equal(mem[1].numpy(), fx["labels"])
+
+
 def test_postprocess_equals_reference_geometry():
     from oracle import ref_shims, must3r_ref as R
     ref_shims.install()

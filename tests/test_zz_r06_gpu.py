@@ -290,3 +290,51 @@ def test_default_library_refuses_the_parked_fp8_attention_flag():
     P = lambda t: C.c_void_p(t.data_ptr())   # noqa: E731
     rc = L.must3r_hip_op_attention(_lib.F16 | _lib.ATTN_FP8, P(q), P(q), P(q), P(q), 64, 64, 64, 64, 1, P(tab), 1, 64, 0, None, 0, torch.cuda.current_stream().cuda_stream)
     assert rc != 0 and b"M3R_ATTN_FP8" in L.must3r_hip_last_error()
+
+
+# ------------------------------------------------------------------------------------------------------------------------------------------------
+# r06: CausalMUSt3R.forward (must3r/model/decoder.py:352-553; SURVEY.md section 8f "later")
+# ------------------------------------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("precision", ["fp16w2", "fp16wa"])
+def test_causal_forward_matches_the_reference_fixture(precision):
+    """The reference's CausalMUSt3R (memory dropout off) on the leaf shims wrote tests/golden/small_224_causal.npz (oracle/make_golden.py main_causal): calls of
+    [3, 2, 1] views -- the first one against an EMPTY memory, where view 0 attends view 1's tokens (decoder.py:399-402) and views 1, 2 the views before them -- then a
+    render of all six.  The HIP module (must3r_hip_decode_args.causal: a key PREFIX per view) must give the same pointmaps, memory, labels and tuple tails, and something
+    else than MUSt3R's own-token rule on the same inputs."""
+    import numpy as np
+    import must3r_amd.model as M
+    from util import rel_inf_view
+    fx = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "small_224_causal.npz"))
+    H, W, Vn, ps, tks = (int(v) for v in fx["meta"][:5])
+    calls = [int(v) for v in fx["meta"][5:]]
+    cfg = SMALL
+    enc, plain = build(cfg, precision)
+    dec = M.CausalMUSt3R(img_size=(cfg.img_size,) * 2, enc_embed_dim=cfg.enc_dim, embed_dim=cfg.dec_dim, depth=cfg.dec_depth, num_heads=cfg.dec_heads,
+                         feedback_type="single_mlp", memory_mode="kv", landscape_only=False, use_mem_mask=True)
+    dec.load_state_dict(S.make_decoder_state_dict(cfg, 0), strict=True)
+    dec = dec.cuda().eval()
+    dec.precision = precision
+    imgs, ts = S.make_images(Vn, H, W, 0)
+    x, pos = enc(imgs.cuda(), ts)
+    mem, upd, i = None, [], 0
+    for k, nb in enumerate(calls):
+        a = (x[i:i + nb].unsqueeze(0), pos[i:i + nb].unsqueeze(0), ts[i:i + nb].unsqueeze(0))
+        if i == 0:
+            _, pm_plain = plain(*a, None)
+        mem, pm = dec(*a, mem)
+        upd.append(pm[0])
+        assert [int(v) for v in mem[2:]] == [int(v) for v in fx["tails"][k]], (k, mem[2:])
+        i += nb
+    _, ren = dec(x.unsqueeze(0), pos.unsqueeze(0), ts.unsqueeze(0), mem, render=True)
+    torch.cuda.synchronize()
+    upd = torch.cat(upd, 0).cpu()
+    e_u = [rel_inf_view(upd[v, ::ps, ::ps], fx["update"][v], fx["update_vmax"][v]) for v in range(Vn)]
+    e_r = [rel_inf_view(ren[0, v, ::ps, ::ps].cpu(), fx["render"][v], fx["render_vmax"][v]) for v in range(Vn)]
+    e_m = rel_inf(mem[0][-1][0, ::tks, ::tks].float().cpu(), torch.from_numpy(fx["mem_last"]))
+    record("causal_forward", precision=precision, update_per_view=e_u, render_per_view=e_r, mem_last=e_m)
+    assert np.array_equal(mem[1].cpu().numpy(), fx["labels"])
+    assert max(e_u) < TOL[precision] and max(e_r) < TOL[precision] and e_m < 2 * TOL[precision], (e_u, e_r, e_m)
+    # the causal rule is a different computation: MUSt3R's init call lets view 0 attend views 1 AND 2, view 1 attend views 0 AND 2, ...
+    assert rel_inf(pm_plain[0].cpu(), upd[:calls[0]]) > 1e-2
+    with pytest.raises(TypeError):
+        dec([x[:1].unsqueeze(0)], [pos[:1].unsqueeze(0)], [ts[:1].unsqueeze(0)], mem)
