@@ -9,7 +9,7 @@ import pytest
 import torch
 
 from must3r_amd import synthetic as S
-from must3r_amd.config import SMALL
+from must3r_amd.config import SMALL, TINY
 from util import TOL, rel_inf
 from test_model_gpu import build
 from test_ops_gpu import record
@@ -338,3 +338,34 @@ def test_causal_forward_matches_the_reference_fixture(precision):
     assert rel_inf(pm_plain[0].cpu(), upd[:calls[0]]) > 1e-2
     with pytest.raises(TypeError):
         dec([x[:1].unsqueeze(0)], [pos[:1].unsqueeze(0)], [ts[:1].unsqueeze(0)], mem)
+
+
+def test_causal_forward_batched_scenes_equal_their_single_scene_calls():
+    """B = 2 scenes through ONE causal call (the batch dimension of decoder.py:437: the scenes never interact): the key prefixes are per scene, so every scene must come
+    out as from its own call -- init call of 3 views, update of 2, render of 5."""
+    import must3r_amd.model as M
+    cfg = TINY
+    enc, _ = build(cfg, "fp16w2")
+    dec = M.CausalMUSt3R(img_size=(cfg.img_size,) * 2, enc_embed_dim=cfg.enc_dim, embed_dim=cfg.dec_dim, depth=cfg.dec_depth, num_heads=cfg.dec_heads,
+                         feedback_type="single_mlp", memory_mode="kv", landscape_only=False)
+    dec.load_state_dict(S.make_decoder_state_dict(cfg, 0), strict=True)
+    dec = dec.cuda().eval()
+    dec.precision = "fp16w2"
+    xs, ps = [], []
+    for b in range(2):
+        imgs, ts = S.make_images(5, 48, 64, 20 + b)
+        x, pos = enc(imgs.cuda(), ts)
+        xs.append(x); ps.append(pos)
+    X, P_ = torch.stack(xs), torch.stack(ps)
+    T = ts.unsqueeze(0).expand(2, -1, -1)
+    mem, pm0 = dec(X[:, :3], P_[:, :3], T[:, :3], None)
+    mem, pm1 = dec(X[:, 3:5], P_[:, 3:5], T[:, 3:5], mem)
+    _, ren = dec(X, P_, T, mem, render=True)
+    for b in range(2):
+        m, q0 = dec(X[b:b + 1, :3], P_[b:b + 1, :3], T[b:b + 1, :3], None)
+        m, q1 = dec(X[b:b + 1, 3:5], P_[b:b + 1, 3:5], T[b:b + 1, 3:5], m)
+        _, qr = dec(X[b:b + 1], P_[b:b + 1], T[b:b + 1], m, render=True)
+        torch.cuda.synchronize()
+        e = max(rel_inf(pm0[b].cpu(), q0[0].cpu()), rel_inf(pm1[b].cpu(), q1[0].cpu()), rel_inf(ren[b].cpu(), qr[0].cpu()))
+        assert e < 0.25 * TOL["fp16w2"], (b, e)
+        assert tuple(int(v) for v in mem[2:]) == tuple(int(v) for v in m[2:]) == (5, 1, 12)
